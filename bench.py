@@ -1,0 +1,158 @@
+"""bench.py -- meshes/sec of the ico2ico training step (BASELINE.json metric) on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch: forward -> P2P loss -> zero_grad -> backward -> Adam -> CyclicLR
+(reference run.py:244-254) on 36 synthetic I5 meshes per GPU already resident in HBM.  Weak scaling: per-GPU
+batch fixed; gradients averaged by bucketed RCCL all-reduce overlapped with backward.
+Rank 0 prints ONE JSON line, with
+  roofline     : the dominant MFMA kernel, timed live with HIP events on its launch stream over the timed region
+                 (achieved = algorithmic FLOPs per launch / mean launch duration), vs 157.3 TFLOP/s dense fp32 MFMA;
+  cpu_baseline : the CPU restatement of the same step (oracle/) timed on this host's cores (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from geniconet_amd import _lib, data, models  # noqa: E402
+from geniconet_amd.train import Trainer  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
+# algorithmic work per mesh per TRAINING step (SURVEY.md 8d / BASELINE.md): 3 x forward conv FLOPs
+TRAIN_GFLOP_PER_MESH = {('ico2ico', 5): 31.49, ('ico2ico_vae', 5): 35.46, ('ico2ico', 6): 125.96}
+CONFIGS = {
+    'ae': dict(model='ico2ico', R=5, batch=36, workload='ico2ico AE training, I5, batch 36 per GPU (BASELINE configs[1])'),
+    'vae': dict(model='ico2ico_vae', R=5, batch=36, workload='ico2ico_vae training, I5, batch 36 per GPU (configs[3])'),
+    'i6': dict(model='ico2ico', R=6, batch=8, workload='ico2ico AE training, I6, batch 8 per GPU (configs[4])'),
+}
+
+
+def cpu_baseline(cfg, budget_s=25.0):
+    """The CPU restatement (oracle/) of the same training step on this host's cores: the only runnable 'reference
+    CPU path' (upstream icocnn is absent; parity unpinned).  detect_anomaly off (conservative for the GPU/CPU ratio)."""
+    from geniconet_amd.train import build_criterion
+    from oracle import models_ref
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    torch.set_num_threads(cores)
+    p = models.default_params(cfg['model'], subdivisions=cfg['R'])
+    torch.manual_seed(0)
+    net = getattr(models_ref, cfg['model'])(R=cfg['R']).train()
+    tr = Trainer(p, 'cpu', model=net, criterion=build_criterion(p, 'cpu'), channels_last=False)
+    x, t = data.synthetic_batch(cfg['batch'], cfg['R'], seed=1234)
+    t0 = time.perf_counter()
+    tr.step(x, t)                                   # warm-up (also sizes the sample)
+    warm = time.perf_counter() - t0
+    steps = max(1, min(3, int(budget_s / max(warm, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(x, t)
+    dt = time.perf_counter() - t0
+    return {'value': round(cfg['batch'] * steps / dt, 3), 'unit': 'meshes/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed training step(s) of batch %d at I%d after 1 warm-up, torch CPU, %d threads, '
+                      'detect_anomaly off' % (steps, cfg['batch'], cfg['R'], cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='ae')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py: no GPU visible; the HIP path has no CPU fallback')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)      # RCCL over xGMI
+
+    _lib.lib()
+    p = models.default_params(cfg['model'], subdivisions=cfg['R'])
+    tr = Trainer(p, device, seed=0)
+    x, t = data.synthetic_batch(cfg['batch'], cfg['R'], seed=1234 + rank, device=device)
+    x = x.contiguous(memory_format=torch.channels_last)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(x, t)
+    events = not args.no_kernel_events
+    barrier()
+    if events:
+        _lib.profile_start(200 * args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step(x, t)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_stop() if events else []
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el)
+    final_loss = float(loss)
+
+    if rank == 0:
+        meshes = cfg['batch'] * world * args.steps
+        value = meshes / elapsed
+        roofline = None
+        if prof:
+            dom = max(prof, key=lambda e: e['total_ms'])
+            per_launch_ms = dom['total_ms'] / dom['launches']
+            achieved = dom['total_flops'] / (dom['total_ms'] * 1e-3) / 1e12
+            mfma_ms = sum(e['total_ms'] for e in prof)
+            roofline = {
+                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'kernel': dom['kernel'], 'launches_per_step': dom['launches'] / args.steps,
+                'avg_launch_us': round(per_launch_ms * 1e3, 2),
+                'algorithmic_gflop_per_launch': round(dom['total_flops'] / dom['launches'] / 1e9, 3),
+                'all_mfma_kernels': [{'kernel': e['kernel'], 'launches_per_step': e['launches'] / args.steps,
+                                      'avg_launch_us': round(e['total_ms'] / e['launches'] * 1e3, 2),
+                                      'tflops': round(e['total_flops'] / (e['total_ms'] * 1e-3) / 1e12, 2)} for e in prof],
+                'mfma_kernels_ms_per_step': round(mfma_ms / args.steps, 3),
+                'step_tflops': round(value * TRAIN_GFLOP_PER_MESH[(cfg['model'], cfg['R'])] / 1e3, 2),
+                'step_frac_of_mfma_peak': round(value * TRAIN_GFLOP_PER_MESH[(cfg['model'], cfg['R'])] / 1e3
+                                                / PEAK_FP32_MFMA_TFLOPS / world, 4),
+            }
+        out = {
+            'metric': 'meshes/sec training throughput, ico2ico I5 batch=36' if args.config == 'ae'
+                      else 'meshes/sec training throughput, %s' % cfg['workload'],
+            'value': round(value, 2), 'unit': 'meshes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': cfg['workload'], 'per_gpu_batch': cfg['batch'], 'global_batch': cfg['batch'] * world,
+                       'subdivisions': cfg['R'], 'parallelism': 'dp%d' % world, 'final_loss': final_loss},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

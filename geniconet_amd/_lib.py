@@ -1,0 +1,151 @@
+"""ctypes binding of libicn.so (C ABI declared in include/icn.h).
+
+The library is the product: there is NO Python/CPU fallback.  If it is missing, loading fails loudly with
+the build command; if a call fails, the library's own message is raised as RuntimeError.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libicn.so')
+
+OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT = 0, 1, 2
+CORNER_MODES = {'zeros': 0, 'average': 1}
+ABI_VERSION = 1
+
+_c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_f32p = ctypes.POINTER(ctypes.c_float)
+_intp = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); mirrors include/icn.h one to one (checked by tests/test_abi.py)
+SIGNATURES = {
+    'icn_abi_version': (ctypes.c_int, []),
+    'icn_last_error': (ctypes.c_char_p, []),
+    'icn_prepare_conv': (ctypes.c_int, [ctypes.c_int] * 3),
+    'icn_prepare_upsample': (ctypes.c_int, [ctypes.c_int] * 2),
+    'icn_conv_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 6),
+    'icn_conv_fwd': (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'icn_conv_bwd_data': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'icn_conv_bwd_weight': (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'icn_upsample_fwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    'icn_upsample_bwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    'icn_table_conv_fwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t]),
+    'icn_table_conv_bwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t, _intp]),
+    'icn_table_upsample': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, _f32p, ctypes.c_size_t, _intp]),
+    'icn_table_upsample_pairs': (ctypes.c_long, [ctypes.c_int, _i32p, ctypes.c_size_t]),
+    'icn_table_faces': (ctypes.c_long, [ctypes.c_int, _i32p, ctypes.c_size_t]),
+}
+
+
+
+class ProfileEntry(ctypes.Structure):
+    _fields_ = [('kernel', ctypes.c_char_p), ('launches', ctypes.c_long), ('total_ms', ctypes.c_double),
+                ('total_flops', ctypes.c_double)]
+
+
+SIGNATURES['icn_profile_start'] = (ctypes.c_int, [ctypes.c_int])
+SIGNATURES['icn_profile_stop'] = (ctypes.c_int, [ctypes.POINTER(ProfileEntry), ctypes.c_int])
+
+_lib = None
+
+
+def lib():
+    """Load libicn.so once; raise with the build recipe if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'geniconet_amd: %s is missing -- the HIP extension is the product and has no fallback. '
+                'Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(or `make -C geniconet_amd/csrc`).' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if handle.icn_abi_version() != ABI_VERSION:
+            raise RuntimeError('geniconet_amd: libicn.so ABI %d != binding ABI %d; rebuild'
+                               % (handle.icn_abi_version(), ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed: %s' % (what, lib().icn_last_error().decode()))
+
+
+def corner_code(corner_mode):
+    try:
+        return CORNER_MODES[corner_mode]
+    except KeyError:
+        raise ValueError("corner_mode must be 'zeros' or 'average', got %r" % (corner_mode,))
+
+
+# ---- host-side table introspection (no device needed) ------------------------------------------------------
+def table_conv_fwd(r_in, stride, corner_mode):
+    L, m = lib(), corner_code(corner_mode)
+    n = L.icn_table_conv_fwd(r_in, stride, m, None, 0)
+    if n < 0:
+        check(-1, 'icn_table_conv_fwd')
+    out = np.empty(n, dtype=np.int32)
+    L.icn_table_conv_fwd(r_in, stride, m, out.ctypes.data_as(_i32p), n)
+    return out.reshape(7, -1)
+
+
+def table_conv_bwd(r_in, stride, corner_mode):
+    L, m = lib(), corner_code(corner_mode)
+    w = ctypes.c_int(0)
+    n = L.icn_table_conv_bwd(r_in, stride, m, None, 0, ctypes.byref(w))
+    if n < 0:
+        check(-1, 'icn_table_conv_bwd')
+    out = np.empty(n, dtype=np.int32)
+    L.icn_table_conv_bwd(r_in, stride, m, out.ctypes.data_as(_i32p), n, ctypes.byref(w))
+    return out.reshape(7, w.value, -1)
+
+
+def table_upsample(r_in, corner_mode, transpose=False):
+    L, m = lib(), corner_code(corner_mode)
+    w = ctypes.c_int(0)
+    n = L.icn_table_upsample(r_in, m, int(transpose), None, None, 0, ctypes.byref(w))
+    if n < 0:
+        check(-1, 'icn_table_upsample')
+    idx, coef = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.float32)
+    L.icn_table_upsample(r_in, m, int(transpose), idx.ctypes.data_as(_i32p), coef.ctypes.data_as(_f32p), n, ctypes.byref(w))
+    return idx.reshape(-1, w.value), coef.reshape(-1, w.value)
+
+
+def table_faces(r):
+    L = lib()
+    n = L.icn_table_faces(r, None, 0)
+    if n < 0:
+        check(-1, 'icn_table_faces')
+    out = np.empty(n, dtype=np.int32)
+    L.icn_table_faces(r, out.ctypes.data_as(_i32p), n)
+    return out.reshape(-1, 3)
+
+
+def table_upsample_pairs(r_in):
+    L = lib()
+    n = L.icn_table_upsample_pairs(r_in, None, 0)
+    if n < 0:
+        check(-1, 'icn_table_upsample_pairs')
+    out = np.empty(n, dtype=np.int32)
+    L.icn_table_upsample_pairs(r_in, out.ctypes.data_as(_i32p), n)
+    return out.reshape(2, -1)
+
+
+def profile_start(max_launches=100000):
+    check(lib().icn_profile_start(max_launches), 'icn_profile_start')
+
+
+def profile_stop():
+    """-> list of dicts(kernel, launches, total_ms, total_flops) for the MFMA kernels launched since profile_start."""
+    buf = (ProfileEntry * 16)()
+    n = lib().icn_profile_stop(buf, 16)
+    if n < 0:
+        check(-1, 'icn_profile_stop')
+    return [dict(kernel=buf[i].kernel.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms,
+                 total_flops=buf[i].total_flops) for i in range(n)]

@@ -1,0 +1,381 @@
+// C ABI of libicn (see include/icn.h): argument checking, per-device index-table cache, kernel dispatch.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/icn.h"
+#include "icn_geometry.h"
+#include "icn_launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg) {
+    g_err = msg;
+    return -1;
+}
+
+#define ICN_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+T* upload(const std::vector<T>& v) {
+    T* d = nullptr;
+    if (v.empty()) return d;
+    ICN_HIP(hipMalloc(reinterpret_cast<void**>(&d), v.size() * sizeof(T)));
+    ICN_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+struct ConvTables {
+    int Pin = 0, Pout = 0, n_in = 0, n_out = 0, E = 1;
+    int32_t* fwd = nullptr;    // [7][Pout]
+    int32_t* bwd = nullptr;    // [7][E][Pin]
+    int32_t* perm = nullptr;   // [Pin] (stride 2 only)
+    uint8_t* mask32 = nullptr; // [Pin/32] (stride 2 only)
+};
+struct UpTables {
+    int Pc = 0, Pf = 0, Wf = 0, Wb = 0;
+    int32_t *idx_f = nullptr, *idx_b = nullptr;
+    float *coef_f = nullptr, *coef_b = nullptr;
+};
+
+std::mutex g_mu;
+std::map<std::tuple<int, int, int, int>, ConvTables> g_conv;   // (device, r, stride, mode)
+std::map<std::tuple<int, int, int>, UpTables> g_up;            // (device, r, mode)
+
+const ConvTables& conv_tables(int r_in, int stride, int mode) {
+    int dev = 0;
+    ICN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(dev, r_in, stride, mode);
+    auto it = g_conv.find(key);
+    if (it != g_conv.end()) return it->second;
+    ConvTables t;
+    t.n_in = 1 << r_in;
+    t.n_out = t.n_in / stride;
+    t.Pin = icn::pixels(r_in);
+    t.Pout = 10 * t.n_out * t.n_out;
+    std::vector<int32_t> fwd, bwd, perm;
+    std::vector<uint8_t> mask;
+    icn::build_conv_fwd(r_in, stride, mode, fwd);
+    t.E = icn::build_conv_bwd(r_in, stride, mode, bwd);
+    t.fwd = upload(fwd);
+    t.bwd = upload(bwd);
+    if (stride == 2) {
+        icn::build_bwd_row_order(r_in, stride, bwd, t.E, perm, mask);
+        t.perm = upload(perm);
+        t.mask32 = upload(mask);
+    }
+    return g_conv.emplace(key, t).first->second;
+}
+
+const UpTables& up_tables(int r_in, int mode) {
+    int dev = 0;
+    ICN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(dev, r_in, mode);
+    auto it = g_up.find(key);
+    if (it != g_up.end()) return it->second;
+    icn::Ell f, b;
+    icn::build_upsample(r_in, mode, f, b);
+    UpTables t;
+    t.Pc = b.rows;
+    t.Pf = f.rows;
+    t.Wf = f.width;
+    t.Wb = b.width;
+    t.idx_f = upload(f.idx);
+    t.coef_f = upload(f.coef);
+    t.idx_b = upload(b.idx);
+    t.coef_b = upload(b.coef);
+    return g_up.emplace(key, t).first->second;
+}
+
+// ---- profiling state (off by default) ------------------------------------------------------------------
+struct ProfRec { int kind; double flops; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_prof;          // pre-created events
+size_t g_prof_used = 0;
+bool g_prof_on = false, g_prof_open = false;
+
+void check_conv(const void* a, const void* b, const void* c, int B, int Cin, int Cout, int r_in, int stride) {
+    if (!a || !b || !c) throw std::invalid_argument("icn: null tensor pointer");
+    if (B < 1 || Cin < 1 || Cout < 1) throw std::invalid_argument("icn: B, Cin, Cout must be positive");
+    if (r_in < 0 || r_in > 10) throw std::invalid_argument("icn: subdivisions out of range [0,10]");
+    if (stride != 1 && stride != 2) throw std::invalid_argument("icn: stride must be 1 or 2");
+    if ((size_t)B * icn::pixels(r_in) >= (size_t)1 << 31) throw std::invalid_argument("icn: B * pixels exceeds int32 rows");
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// workspace layout of bwd-weight: [wgrad partial slabs][colsum partials]
+size_t wgrad_partial_bytes(int M, int Cin, int Cout) {
+    const int S = icn::wgrad_supported(Cin, Cout) ? icn::wgrad_splits(M, Cin, Cout) : icn::wgrad_generic_splits(M);
+    return align256((size_t)S * 7 * Cin * Cout * sizeof(float));
+}
+
+}  // namespace
+
+namespace icn {
+const char* const PROF_NAMES[PROF_KINDS] = {"k_gather_gemm<128,128>", "k_gather_gemm<128,64>", "k_gather_gemm<64,64>",
+                                            "k_wgrad<128,128>", "k_wgrad<128,64>", "k_wgrad<64,128>", "k_wgrad<64,64>"};
+void prof_mark_begin(int kind, double flops, hipStream_t s) {
+    if (!g_prof_on || g_prof_used >= g_prof.size()) return;
+    ProfRec& r = g_prof[g_prof_used];
+    r.kind = kind;
+    r.flops = flops;
+    (void)hipEventRecord(r.e0, s);
+    g_prof_open = true;
+}
+void prof_mark_end(hipStream_t s) {
+    if (!g_prof_open) return;
+    (void)hipEventRecord(g_prof[g_prof_used].e1, s);
+    ++g_prof_used;
+    g_prof_open = false;
+}
+}  // namespace icn
+
+extern "C" {
+
+int icn_profile_start(int max_launches) {
+    try {
+        if (max_launches < 1) throw std::invalid_argument("icn_profile_start: max_launches must be positive");
+        while ((int)g_prof.size() < max_launches) {
+            ProfRec r{};
+            ICN_HIP(hipEventCreate(&r.e0));
+            ICN_HIP(hipEventCreate(&r.e1));
+            g_prof.push_back(r);
+        }
+        g_prof_used = 0;
+        g_prof_on = true;
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_profile_stop(icn_profile_entry* out, int cap) {
+    try {
+        g_prof_on = false;
+        ICN_HIP(hipDeviceSynchronize());
+        icn_profile_entry acc[icn::PROF_KINDS];
+        for (int k = 0; k < icn::PROF_KINDS; ++k) acc[k] = icn_profile_entry{icn::PROF_NAMES[k], 0, 0.0, 0.0};
+        for (size_t i = 0; i < g_prof_used; ++i) {
+            float ms = 0.f;
+            ICN_HIP(hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1));
+            acc[g_prof[i].kind].launches += 1;
+            acc[g_prof[i].kind].total_ms += ms;
+            acc[g_prof[i].kind].total_flops += g_prof[i].flops;
+        }
+        int n = 0;
+        for (int k = 0; k < icn::PROF_KINDS && n < cap; ++k)
+            if (acc[k].launches > 0) out[n++] = acc[k];
+        return n;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+
+int icn_abi_version(void) { return ICN_ABI_VERSION; }
+const char* icn_last_error(void) { return g_err.c_str(); }
+
+int icn_prepare_conv(int r_in, int stride, int corner_mode) {
+    try {
+        (void)conv_tables(r_in, stride, corner_mode);
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_prepare_upsample(int r_in, int corner_mode) {
+    try {
+        (void)up_tables(r_in, corner_mode);
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+size_t icn_conv_workspace_bytes(int op, int B, int Cin, int Cout, int r_in, int stride) {
+    if (B < 1 || Cin < 1 || Cout < 1 || r_in < 0 || r_in > 10 || (stride != 1 && stride != 2)) return 0;
+    const int n_out = (1 << r_in) / stride;
+    const int M = B * 10 * n_out * n_out;
+    const size_t wbytes = align256((size_t)7 * Cin * Cout * sizeof(float));
+    switch (op) {
+        case ICN_OP_CONV_FWD: return icn::gather_gemm_supported(Cin, Cout) ? wbytes : 0;
+        case ICN_OP_CONV_BWD_DATA: return icn::gather_gemm_supported(Cout, Cin) ? wbytes : 0;
+        case ICN_OP_CONV_BWD_WEIGHT:
+            return wgrad_partial_bytes(M, Cin, Cout) + align256((size_t)icn::colsum_chunks(M) * Cout * sizeof(float));
+        default: return 0;
+    }
+}
+
+int icn_conv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int r_in,
+                 int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream) {
+    try {
+        check_conv(x, w, y, B, Cin, Cout, r_in, stride);
+        const ConvTables& t = conv_tables(r_in, stride, corner_mode);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (icn::gather_gemm_supported(Cin, Cout)) {
+            if (!ws || ws_bytes < icn_conv_workspace_bytes(ICN_OP_CONV_FWD, B, Cin, Cout, r_in, stride))
+                throw std::invalid_argument("icn_conv_fwd: workspace too small");
+            float* wf = static_cast<float*>(ws);
+            icn::launch_pack_weights(w, wf, Cout, Cin, 0, s);
+            icn::GatherGemmArgs a{x, wf, bias, y, t.fwd, nullptr, nullptr, B * t.Pout, t.Pin, t.Pout, Cin, Cout, 1, t.n_in,
+                                  2.0 * 7 * Cin * Cout * (double)B * t.Pout};
+            icn::launch_gather_gemm_auto(a, s);
+        } else {
+            icn::launch_conv_generic(x, w, bias, y, t.fwd, B, t.Pin, t.Pout, Cin, Cout, 1, t.n_in, 0, s);
+        }
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_conv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int r_in, int stride,
+                      int corner_mode, void* ws, size_t ws_bytes, void* stream) {
+    try {
+        check_conv(dy, w, dx, B, Cin, Cout, r_in, stride);
+        const ConvTables& t = conv_tables(r_in, stride, corner_mode);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (icn::gather_gemm_supported(Cout, Cin)) {
+            if (!ws || ws_bytes < icn_conv_workspace_bytes(ICN_OP_CONV_BWD_DATA, B, Cin, Cout, r_in, stride))
+                throw std::invalid_argument("icn_conv_bwd_data: workspace too small");
+            float* wb = static_cast<float*>(ws);
+            icn::launch_pack_weights(w, wb, Cout, Cin, 1, s);
+            // source = dy at the output level (pole corners of THAT level), rows = input pixels
+            icn::GatherGemmArgs a{dy, wb, nullptr, dx, t.bwd, t.perm, t.mask32, B * t.Pin, t.Pout, t.Pin, Cout, Cin, t.E, t.n_out,
+                                  2.0 * 7 * Cin * Cout * (double)B * t.Pout};
+            icn::launch_gather_gemm_auto(a, s);
+        } else {
+            icn::launch_conv_generic(dy, w, nullptr, dx, t.bwd, B, t.Pout, t.Pin, Cout, Cin, t.E, t.n_out, 1, s);
+        }
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_conv_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int r_in,
+                        int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream) {
+    try {
+        check_conv(x, dy, dw, B, Cin, Cout, r_in, stride);
+        const ConvTables& t = conv_tables(r_in, stride, corner_mode);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (!ws || ws_bytes < icn_conv_workspace_bytes(ICN_OP_CONV_BWD_WEIGHT, B, Cin, Cout, r_in, stride))
+            throw std::invalid_argument("icn_conv_bwd_weight: workspace too small");
+        const int M = B * t.Pout;
+        float* partial = static_cast<float*>(ws);
+        icn::WgradArgs a{x, dy, t.fwd, partial, dw, M, t.Pin, t.Pout, Cin, Cout, t.n_in, 2.0 * 7 * Cin * Cout * (double)M};
+        if (icn::wgrad_supported(Cin, Cout)) icn::launch_wgrad(a, s);
+        else icn::launch_wgrad_generic(a, s);
+        if (dbias) {
+            float* cs = reinterpret_cast<float*>(static_cast<char*>(ws) + wgrad_partial_bytes(M, Cin, Cout));
+            icn::launch_colsum(dy, cs, dbias, M, Cout, s);
+        }
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_upsample_fwd(const float* x, float* y, int B, int C, int r_in, int corner_mode, void* stream) {
+    try {
+        if (!x || !y || B < 1 || C < 1) throw std::invalid_argument("icn_upsample_fwd: bad arguments");
+        const UpTables& t = up_tables(r_in, corner_mode);
+        icn::launch_spmm_ell(x, y, t.idx_f, t.coef_f, B, t.Pc, t.Pf, C, t.Wf, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_upsample_bwd(const float* dy, float* dx, int B, int C, int r_in, int corner_mode, void* stream) {
+    try {
+        if (!dy || !dx || B < 1 || C < 1) throw std::invalid_argument("icn_upsample_bwd: bad arguments");
+        const UpTables& t = up_tables(r_in, corner_mode);
+        icn::launch_spmm_ell(dy, dx, t.idx_b, t.coef_b, B, t.Pf, t.Pc, C, t.Wb, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+// ---- host-side introspection ----------------------------------------------------------------------------
+long icn_table_conv_fwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap) {
+    try {
+        std::vector<int32_t> v;
+        icn::build_conv_fwd(r_in, stride, corner_mode, v);
+        if (out) std::memcpy(out, v.data(), std::min(cap, v.size()) * sizeof(int32_t));
+        return (long)v.size();
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+long icn_table_conv_bwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap, int* width) {
+    try {
+        std::vector<int32_t> v;
+        const int E = icn::build_conv_bwd(r_in, stride, corner_mode, v);
+        if (width) *width = E;
+        if (out) std::memcpy(out, v.data(), std::min(cap, v.size()) * sizeof(int32_t));
+        return (long)v.size();
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+long icn_table_upsample(int r_in, int corner_mode, int transpose, int32_t* idx, float* coef, size_t cap, int* width) {
+    try {
+        icn::Ell f, b;
+        icn::build_upsample(r_in, corner_mode, f, b);
+        const icn::Ell& e = transpose ? b : f;
+        if (width) *width = e.width;
+        if (idx) std::memcpy(idx, e.idx.data(), std::min(cap, e.idx.size()) * sizeof(int32_t));
+        if (coef) std::memcpy(coef, e.coef.data(), std::min(cap, e.coef.size()) * sizeof(float));
+        return (long)e.idx.size();
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+long icn_table_upsample_pairs(int r_in, int32_t* out, size_t cap) {
+    try {
+        std::vector<int32_t> v;
+        icn::build_upsample_pairs(r_in, v);
+        if (out) std::memcpy(out, v.data(), std::min(cap, v.size()) * sizeof(int32_t));
+        return (long)v.size();
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+long icn_table_faces(int r, int32_t* out, size_t cap) {
+    try {
+        std::vector<int32_t> v;
+        icn::build_faces(r, v);
+        if (out) std::memcpy(out, v.data(), std::min(cap, v.size()) * sizeof(int32_t));
+        return (long)v.size();
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+// Host-side chart geometry (see icn_geometry.h).  Pure C++, no device code.
+#include "icn_geometry.h"
+
+#include <algorithm>
+#include <array>
+#include <stdexcept>
+
+namespace icn {
+
+const int TAP_DA[NTAPS] = {0, 1, 0, -1, -1, 0, 1};
+const int TAP_DB[NTAPS] = {0, 0, 1, 1, 0, -1, -1};
+
+namespace {
+
+// Lattice point (a, b) expressed in chart c's hex-axial frame.  Chart c is the closed parallelogram
+// a in [0,n], b in [0,2n]; it owns a in [0,n-1], b in [1,2n]; pixel (i,j) <-> (a=i, b=j+1).
+struct Pt {
+    int c, a, b;
+};
+
+// The three seams between chart c and chart c-1, as affine maps of chart-c coordinates into chart c-1
+// coordinates (valid in a neighbourhood of the seam):
+//   seam 1 (north cap, 60 deg rotation about N):  (0,b)_c == (b,0)_{c-1},      b in [0,n]
+//   seam 2 (equatorial band, pure translation):   (0,b)_c == (n,b-n)_{c-1},    b in [n,2n]
+//   seam 3 (south cap, 60 deg rotation about S):  (a,2n)_c == (n,a+n)_{c-1},   a in [0,n]
+inline Pt prev1(int, Pt p) { return {(p.c + 4) % 5, p.a + p.b, -p.a}; }
+inline Pt prev2(int n, Pt p) { return {(p.c + 4) % 5, p.a + n, p.b - n}; }
+inline Pt prev3(int n, Pt p) { return {(p.c + 4) % 5, 3 * n - p.b, p.a + p.b - n}; }
+// ... and their inverses (chart c -> chart c+1).
+inline Pt next1(int, Pt p) { return {(p.c + 1) % 5, -p.b, p.a + p.b}; }
+inline Pt next2(int n, Pt p) { return {(p.c + 1) % 5, p.a - n, p.b + n}; }
+inline Pt next3(int n, Pt p) { return {(p.c + 1) % 5, p.a + p.b - 2 * n, 3 * n - p.a}; }
+
+constexpr int32_t NORTH = -100, SOUTH = -101;
+
+// Owner of lattice point (a,b) of chart c, a in [-1,n], b in [0,2n+1] (one step outside the owned block).
+// Returns a pixel id, NORTH or SOUTH.  At the two five-valent pixels of a chart one of the six lattice
+// directions has no distinct neighbour; the seam chosen by the target's b decides which neighbour is
+// duplicated.
+int32_t resolve(int n, int c, int a, int b) {
+    Pt p{c, a, b};
+    for (int guard = 0; guard < 8; ++guard) {
+        if (p.a == 0 && p.b == 0) return NORTH;
+        if (p.a == n && p.b == 2 * n) return SOUTH;
+        if (p.a == -1)
+            p = (p.b <= n) ? prev1(n, p) : prev2(n, p);
+        else if (p.b == 2 * n + 1)
+            p = prev3(n, p);
+        else if (p.b == 0)
+            p = next1(n, p);
+        else if (p.a == n)
+            p = (p.b <= n) ? next2(n, p) : next3(n, p);
+        else {
+            if (p.a < 0 || p.a >= n || p.b < 1 || p.b > 2 * n) throw std::logic_error("icn: resolve left the chart");
+            return (p.c * n + p.a) * 2 * n + (p.b - 1);
+        }
+    }
+    throw std::logic_error("icn: resolve did not converge");
+}
+
+inline int32_t pole_code(int32_t v, int corner_mode) {
+    if (v == NORTH) return corner_mode == CORNER_AVERAGE ? IDX_POLE : IDX_ZERO;
+    if (v == SOUTH) return corner_mode == CORNER_AVERAGE ? IDX_POLE - 1 : IDX_ZERO;
+    return v;
+}
+
+// corner pixel c of pole k at a level with n = 2^r (reference: ico_utils.py:13-18)
+inline int32_t corner_pixel(int n, int k, int c) {
+    return k == 0 ? (c * n) * 2 * n : ((c + 1) * n - 1) * 2 * n + (2 * n - 1);
+}
+
+void check_args(int r_in, int stride, int corner_mode) {
+    if (r_in < 0 || r_in > 10) throw std::invalid_argument("icn: subdivisions out of range [0,10]");
+    if (stride != 1 && stride != 2) throw std::invalid_argument("icn: stride must be 1 or 2");
+    if (stride == 2 && r_in < 1) throw std::invalid_argument("icn: stride 2 needs subdivisions >= 1");
+    if (corner_mode != CORNER_ZEROS && corner_mode != CORNER_AVERAGE)
+        throw std::invalid_argument("icn: corner_mode must be 0 (zeros) or 1 (average)");
+}
+
+}  // namespace
+
+void build_conv_fwd(int r_in, int stride, int corner_mode, std::vector<int32_t>& out) {
+    check_args(r_in, stride, corner_mode);
+    const int n = 1 << r_in, no = n / stride;
+    const int Pout = 10 * no * no;
+    out.assign((size_t)NTAPS * Pout, IDX_ZERO);
+    for (int c = 0; c < 5; ++c)
+        for (int i = 0; i < no; ++i)
+            for (int j = 0; j < 2 * no; ++j) {
+                const int p = (c * no + i) * 2 * no + j;
+                // fine site of the output pixel (App. A.4): (i,j) or (2i, 2j+1); lattice (a,b) = (I, J+1)
+                const int a = stride == 1 ? i : 2 * i, b = (stride == 1 ? j : 2 * j + 1) + 1;
+                for (int t = 0; t < NTAPS; ++t)
+                    out[(size_t)t * Pout + p] = pole_code(resolve(n, c, a + TAP_DA[t], b + TAP_DB[t]), corner_mode);
+            }
+}
+
+int build_conv_bwd(int r_in, int stride, int corner_mode, std::vector<int32_t>& out) {
+    std::vector<int32_t> fwd;
+    build_conv_fwd(r_in, stride, corner_mode, fwd);
+    const int n = 1 << r_in, no = n / stride;
+    const int Pin = 10 * n * n, Pout = 10 * no * no;
+    std::vector<std::vector<int32_t>> lists((size_t)NTAPS * Pin);
+    for (int t = 0; t < NTAPS; ++t) {
+        std::array<std::vector<int32_t>, 2> pole_src;
+        for (int p = 0; p < Pout; ++p) {
+            const int32_t q = fwd[(size_t)t * Pout + p];
+            if (q >= 0)
+                lists[(size_t)t * Pin + q].push_back(p);
+            else if (q <= IDX_POLE)
+                pole_src[IDX_POLE - q].push_back(p);
+        }
+        for (int k = 0; k < 2; ++k) {
+            if (pole_src[k].empty()) continue;
+            // d(pole_k) = W_t^T sum_{p taps pole} dy[p]; each of the 5 corner inputs receives 1/5 of it.  That is
+            // the "pole mean" of dy iff the tapping pixels are exactly dy's corner pixels of pole k.
+            std::vector<int32_t> want;
+            for (int c = 0; c < 5; ++c) want.push_back(corner_pixel(no, k, c));
+            std::sort(want.begin(), want.end());
+            std::sort(pole_src[k].begin(), pole_src[k].end());
+            if (want != pole_src[k]) throw std::logic_error("icn: pole taps are not the corner pixels");
+            for (int c = 0; c < 5; ++c) lists[(size_t)t * Pin + corner_pixel(n, k, c)].push_back(IDX_POLE - k);
+        }
+    }
+    size_t E = 1;
+    for (auto& l : lists) E = std::max(E, l.size());
+    out.assign((size_t)NTAPS * E * Pin, IDX_ZERO);
+    for (int t = 0; t < NTAPS; ++t)
+        for (int q = 0; q < Pin; ++q) {
+            auto& l = lists[(size_t)t * Pin + q];
+            // regular (single-source) entry first so that slot 0 is the fast path
+            std::stable_sort(l.begin(), l.end(), [](int32_t x, int32_t y) { return (x >= 0) > (y >= 0); });
+            for (size_t e = 0; e < l.size(); ++e) out[((size_t)t * E + e) * Pin + q] = l[e];
+        }
+    return (int)E;
+}
+
+void build_upsample(int r_in, int corner_mode, Ell& fwd, Ell& bwd) {
+    check_args(r_in, 1, corner_mode);
+    const int n = 1 << r_in, nf = 2 * n;
+    const int Pc = 10 * n * n, Pf = 10 * nf * nf;
+    std::vector<std::vector<std::pair<int32_t, float>>> rows(Pf), cols(Pc);
+    auto add = [&](int q, int32_t v, float w) {
+        if (v >= 0) {
+            rows[q].push_back({v, w});
+        } else if (corner_mode == CORNER_AVERAGE) {
+            const int k = v == NORTH ? 0 : 1;
+            for (int c = 0; c < 5; ++c) rows[q].push_back({corner_pixel(n, k, c), w * 0.2f});
+        }
+    };
+    for (int c = 0; c < 5; ++c)
+        for (int I = 0; I < nf; ++I)
+            for (int J = 0; J < 2 * nf; ++J) {
+                const int q = (c * nf + I) * 2 * nf + J;
+                const int a = I, b = J + 1;   // fine lattice; coarse lattice points are the (even, even) ones
+                if (a % 2 == 0 && b % 2 == 0) {
+                    add(q, resolve(n, c, a / 2, b / 2), 1.0f);
+                } else {
+                    int a0, b0, a1, b1;
+                    if (a % 2 != 0 && b % 2 == 0) { a0 = a - 1; b0 = b; a1 = a + 1; b1 = b; }
+                    else if (a % 2 == 0) { a0 = a; b0 = b - 1; a1 = a; b1 = b + 1; }
+                    else { a0 = a + 1; b0 = b - 1; a1 = a - 1; b1 = b + 1; }
+                    add(q, resolve(n, c, a0 / 2, b0 / 2), 0.5f);
+                    add(q, resolve(n, c, a1 / 2, b1 / 2), 0.5f);
+                }
+            }
+    for (int q = 0; q < Pf; ++q)
+        for (auto& e : rows[q]) cols[e.first].push_back({q, e.second});
+    auto pack = [](const std::vector<std::vector<std::pair<int32_t, float>>>& m, Ell& ell) {
+        size_t w = 1;
+        for (auto& r : m) w = std::max(w, r.size());
+        ell.rows = (int)m.size();
+        ell.width = (int)w;
+        ell.idx.assign(m.size() * w, IDX_ZERO);
+        ell.coef.assign(m.size() * w, 0.0f);
+        for (size_t r = 0; r < m.size(); ++r)
+            for (size_t e = 0; e < m[r].size(); ++e) {
+                ell.idx[r * w + e] = m[r][e].first;
+                ell.coef[r * w + e] = m[r][e].second;
+            }
+    };
+    pack(rows, fwd);
+    pack(cols, bwd);
+}
+
+void build_upsample_pairs(int r_in, std::vector<int32_t>& out) {
+    check_args(r_in, 1, CORNER_AVERAGE);
+    const int n = 1 << r_in, nf = 2 * n;
+    const int Pc = 10 * n * n, Pf = 10 * nf * nf;
+    auto vid = [&](int c, int a, int b) {
+        const int32_t v = resolve(n, c, a, b);
+        return v == NORTH ? Pc : v == SOUTH ? Pc + 1 : v;
+    };
+    out.assign((size_t)2 * Pf, 0);
+    for (int c = 0; c < 5; ++c)
+        for (int I = 0; I < nf; ++I)
+            for (int J = 0; J < 2 * nf; ++J) {
+                const int q = (c * nf + I) * 2 * nf + J;
+                const int a = I, b = J + 1;
+                int a0 = a, b0 = b, a1 = a, b1 = b;
+                if (a % 2 != 0 && b % 2 == 0) { a0 = a - 1; a1 = a + 1; }
+                else if (a % 2 == 0 && b % 2 != 0) { b0 = b - 1; b1 = b + 1; }
+                else if (a % 2 != 0) { a0 = a + 1; b0 = b - 1; a1 = a - 1; b1 = b + 1; }
+                out[q] = vid(c, a0 / 2, b0 / 2);
+                out[(size_t)Pf + q] = vid(c, a1 / 2, b1 / 2);
+            }
+}
+
+void build_bwd_row_order(int r_in, int stride, const std::vector<int32_t>& bwd_idx, int E,
+                         std::vector<int32_t>& perm, std::vector<uint8_t>& mask32) {
+    const int n = 1 << r_in, Pin = 10 * n * n;
+    perm.resize(Pin);
+    for (int q = 0; q < Pin; ++q) perm[q] = q;
+    if (stride == 2) {
+        auto cls = [n](int q) { const int I = (q / (2 * n)) % n, J = q % (2 * n); return (I & 1) * 2 + (J & 1); };
+        std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return cls(x) < cls(y); });
+    }
+    mask32.assign((Pin + 31) / 32, 0);
+    for (int k = 0; k < Pin; ++k)
+        for (int t = 0; t < NTAPS; ++t)
+            for (int e = 0; e < E; ++e)
+                if (bwd_idx[((size_t)t * E + e) * Pin + perm[k]] != IDX_ZERO) mask32[k / 32] |= (uint8_t)(1u << t);
+}
+
+void build_faces(int r, std::vector<int32_t>& faces) {
+    check_args(r, 1, CORNER_AVERAGE);
+    const int n = 1 << r, P = 10 * n * n;
+    auto vid = [&](int c, int a, int b) {
+        const int32_t v = resolve(n, c, a, b);
+        return v == NORTH ? P : v == SOUTH ? P + 1 : v;
+    };
+    faces.clear();
+    faces.reserve((size_t)60 * n * n);
+    for (int c = 0; c < 5; ++c)
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < 2 * n; ++b) {
+                faces.insert(faces.end(), {vid(c, a, b), vid(c, a + 1, b), vid(c, a, b + 1)});
+                faces.insert(faces.end(), {vid(c, a + 1, b), vid(c, a + 1, b + 1), vid(c, a, b + 1)});
+            }
+}
+
+}  // namespace icn

@@ -1,0 +1,55 @@
+// Host-side icosahedral chart geometry: index tables consumed by the HIP kernels.
+//
+// Replaces the (absent) icocnn pad/index buffers behind IcoConvS2S / IcoUpsampleS2S
+// (reference call sites: models.py:13-14,25-33,45-55).  Convention: SURVEY.md App. A.
+// Derivation here is by the three seam affine maps between neighbouring charts (not by the
+// pad-slice table the oracle uses), so the two can be cross-checked.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace icn {
+
+enum CornerMode { CORNER_ZEROS = 0, CORNER_AVERAGE = 1 };
+
+// Index codes shared by every table:
+//   >= 0        pixel id (row-major over the (5n, 2n) grid of the source level)
+//   IDX_ZERO    contributes nothing
+//   IDX_POLE-k  mean over the 5 corner pixels of pole k (0 = north, 1 = south) of the source tensor
+constexpr int32_t IDX_ZERO = -1;
+constexpr int32_t IDX_POLE = -2;   // north = -2, south = -3
+
+constexpr int NTAPS = 7;
+// Tap order (centre, then hex ring counter-clockwise in lattice coords (a=row, b=col)).
+extern const int TAP_DA[NTAPS];
+extern const int TAP_DB[NTAPS];
+
+inline int pixels(int r) { return 10 << (2 * r); }
+
+// Forward gather table of a stride-s conv reading level r_in: out[t * P_out + p].
+void build_conv_fwd(int r_in, int stride, int corner_mode, std::vector<int32_t>& out);
+
+// Transposed gather table (for bwd-data): out[(t * E + e) * P_in + q] indexes dy pixels (level
+// r_in - log2(stride)); E is the max multiplicity (returned).
+int build_conv_bwd(int r_in, int stride, int corner_mode, std::vector<int32_t>& out);
+
+// ELL sparse matrices of the r -> r+1 upsample and of its transpose.
+struct Ell {
+    int rows = 0, width = 0;
+    std::vector<int32_t> idx;    // rows * width, IDX_ZERO padded
+    std::vector<float> coef;     // rows * width
+};
+void build_upsample(int r_in, int corner_mode, Ell& fwd, Ell& bwd);
+// Raw endpoints of the upsample: out[q], out[Pf + q] = the two level-r vertex ids (pixels, or P / P+1 for the
+// N / S pole) whose mean is fine pixel q (equal at coarse sites).
+void build_upsample_pairs(int r_in, std::vector<int32_t>& out);
+
+// Row permutation + per-32-row tap masks for stride-2 bwd-data (rows grouped by lattice parity class so
+// that all-empty taps can be skipped tile-wise).  perm[k] = input pixel handled by row k.
+void build_bwd_row_order(int r_in, int stride, const std::vector<int32_t>& bwd_idx, int E,
+                         std::vector<int32_t>& perm, std::vector<uint8_t>& mask32);
+
+// Faces (20*4^r, 3) in the reference vertex order (grid row-major, then N, S).
+void build_faces(int r, std::vector<int32_t>& faces);
+
+}  // namespace icn

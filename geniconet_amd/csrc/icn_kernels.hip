@@ -1,0 +1,584 @@
+// gfx950 (MI355X / CDNA4) kernels of the icosahedral hex-convolution hot path.
+//
+// Everything here works on channels-last chart tensors (B, P, C) fp32, P = 10*4^r pixels, and on the
+// int32 index tables built by icn_geometry.cpp (codes: >=0 pixel, -1 nothing, -2/-3 pole mean).
+//
+//   k_gather_gemm   implicit GEMM  dst[m, :] = bias + sum_t (sum_e src[idx_t,e(m), :]) @ Wt[t]^T
+//                   on v_mfma_f32_32x32x2_f32 (exact fp32).  Used by conv forward (E = 1) and by conv
+//                   backward-data (transposed table, E <= 3).  The pad-exchange between charts, the pole
+//                   mean and the duplicated tap at five-valent pixels are all folded into the gather that
+//                   fills the LDS tile, so no padded copy of the activations ever exists in HBM.
+//   k_wgrad         dW_t = X_t^T dY, split over pixel rows, MFMA, deterministic two-pass reduction.
+//   k_spmm_ell      HBM-bound sparse row mix (upsample forward and its transpose).
+//   k_*_generic     scalar fall-backs for channel counts the MFMA tiles do not cover (e.g. the 3->64 stem).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "icn_launch.h"
+
+namespace icn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ int corner_pixel(int n, int k, int c) {
+    return k == 0 ? (c * n) * 2 * n : ((c + 1) * n - 1) * 2 * n + (2 * n - 1);
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// mean over the 5 corner pixels of pole k of sample b, 4 channels starting at `ch`
+__device__ __forceinline__ f32x4 pole_mean4(const float* src, int b, int Ps, int ns, int k, int K, int ch) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 5; ++c) s += ld4(src + ((size_t)b * Ps + corner_pixel(ns, k, c)) * K + ch);
+    return s * 0.2f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight re-layouts:  w[Cout][Cin][7]  ->  wf[t][Cout][Cin]  (forward B operand, k = ci contiguous)
+//                                      ->  wb[t][Cin][Cout]  (backward-data B operand, k = co contiguous)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_pack_weights(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int transpose) {
+    const int total = Cout * Cin * 7;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        // i enumerates the OUTPUT layout so that stores are coalesced
+        int t, co, ci;
+        if (!transpose) { ci = i % Cin; co = (i / Cin) % Cout; t = i / (Cin * Cout); }
+        else { co = i % Cout; ci = (i / Cout) % Cin; t = i / (Cin * Cout); }
+        out[i] = w[((size_t)co * Cin + ci) * 7 + t];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA gather-GEMM
+// ---------------------------------------------------------------------------------------------------------
+constexpr int BK = 32;        // k (channel) depth of one LDS stage = one 128-byte row segment
+constexpr int EMAX = 3;       // max entries per (tap, row) in a transposed table
+
+// 16-byte chunk swizzle of a [rows][32 floats] LDS tile: conflict-free ds_read_b128 by 32 consecutive rows
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_gather_gemm(
+    const float* __restrict__ src,      // (B, Ps, K)
+    const float* __restrict__ wt,       // [7][N][K]
+    const float* __restrict__ bias,     // [N] or null
+    float* __restrict__ dst,            // (B, Pd, N)
+    const int32_t* __restrict__ idx,    // [7][E][Pd]
+    const int32_t* __restrict__ perm,   // [Pd] row -> dst pixel, or null (identity)
+    const uint8_t* __restrict__ mask32, // [Pd/32] taps in use per 32 rows, or null (all)
+    int M, int Ps, int Pd, int K, int N, int E, int ns) {
+    constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (waves are 2 x 2)
+    constexpr int RA = BM / 32, RB = BN / 32;      // 16-byte chunks each thread stages per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);                       // [2][BM*32]
+    float* Bs = As + 2 * BM * BK;                                     // [2][BN*32]
+    int32_t* s_code = reinterpret_cast<int32_t*>(Bs + 2 * BN * BK);   // [7][E][BM]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run of tiles
+    // so that neighbouring M-tiles (shared halo rows, same weight panel) hit the same L2.
+    const int ntn = N / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, rem = nblk % 8, x = bid % 8;
+        bid = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + bid / 8;
+    }
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+
+    // ---- per-row gather codes -> LDS; taps in use by this tile
+    unsigned tapmask = 0;
+    if (mask32) {
+#pragma unroll
+        for (int g = 0; g < BM / 32; ++g) {
+            const int m = m0 + g * 32;
+            if (m < M) tapmask |= mask32[(m % Pd) >> 5];
+        }
+    } else {
+        tapmask = 0x7f;
+    }
+    for (int i = tid; i < 7 * E * BM; i += 256) {
+        const int row = i % BM, te = i / BM;
+        const int m = m0 + row;
+        int32_t code = -1;
+        if (m < M) {
+            const int b = m / Pd, kk = m % Pd;
+            const int q = perm ? perm[kk] : kk;
+            const int32_t v = idx[(size_t)te * Pd + q];
+            code = v >= 0 ? b * Ps + v : v;
+        }
+        s_code[i] = code;
+    }
+    __syncthreads();
+
+    const int chunk = tid & 7, srow = tid >> 3;        // staging: row srow + 32*i, 16-byte chunk `chunk`
+    // rows (of this thread) x taps that need the slow path: extra entries or a pole mean
+    unsigned slow = 0;
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+        for (int t = 0; t < 7; ++t) {
+            bool s = s_code[(t * E) * BM + srow + 32 * i] <= -2;
+            for (int e = 1; e < E; ++e) s |= s_code[(t * E + e) * BM + srow + 32 * i] != -1;
+            slow |= (unsigned)s << (i * 7 + t);
+        }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ntap = __popc(tapmask);
+    const int nsteps = ntap * (K / BK);
+    f32x4 ra[RA], rb[RB];
+
+    // step -> (tap, k0): taps innermost so that the 7 gathers of one channel chunk reuse the same lines
+    unsigned rem_taps = tapmask;
+    int k0 = 0;
+    auto next_tap = [&]() {
+        if (rem_taps == 0) { rem_taps = tapmask; k0 += BK; }
+        const int t = __ffs(rem_taps) - 1;
+        rem_taps &= rem_taps - 1;
+        return t;
+    };
+    auto stage_load = [&](int t, int kc) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int32_t code = s_code[(t * E) * BM + srow + 32 * i];
+            ra[i] = code >= 0 ? ld4(src + (size_t)code * K + kc + 4 * chunk) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            rb[i] = ld4(wt + ((size_t)t * N + n0 + srow + 32 * i) * K + kc + 4 * chunk);
+    };
+    auto stage_write = [&](int buf, int t, int kc) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int row = srow + 32 * i;
+            f32x4 v = ra[i];
+            if ((slow >> (i * 7 + t)) & 1) {
+                const int b = (m0 + row) / Pd;
+                for (int e = 0; e < E; ++e) {
+                    const int32_t code = s_code[(t * E + e) * BM + row];
+                    if (e > 0 && code >= 0) v += ld4(src + (size_t)code * K + kc + 4 * chunk);
+                    if (code <= -2) v += pole_mean4(src, b, Ps, ns, -2 - code, K, kc + 4 * chunk);
+                }
+            }
+            *reinterpret_cast<f32x4*>(As + buf * BM * BK + row * BK + 4 * (chunk ^ swz(row))) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int row = srow + 32 * i;
+            *reinterpret_cast<f32x4*>(Bs + buf * BN * BK + row * BK + 4 * (chunk ^ swz(row))) = rb[i];
+        }
+    };
+
+    if (nsteps > 0) {
+        const int t_cur = next_tap();
+        stage_load(t_cur, k0);
+        stage_write(0, t_cur, k0);
+    }
+    __syncthreads();
+
+    const int fl = swz(l31);   // rows read by this lane are (32-aligned base) + l31
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        int t_nxt = 0, k_nxt = 0;
+        const bool more = step + 1 < nsteps;
+        if (more) {
+            t_nxt = next_tap();
+            k_nxt = k0;
+            stage_load(t_nxt, k_nxt);
+        }
+        const float* a_base = As + buf * BM * BK + (wr * (BM / 2) + l31) * BK;
+        const float* b_base = Bs + buf * BN * BK + (wc * (BN / 2) + l31) * BK;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int off = 4 * ((2 * kk + h) ^ fl);
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + off);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BK + off);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (more) stage_write(buf ^ 1, t_nxt, k_nxt);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wc * (BN / 2) + j * 32 + l31;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = m0 + row;
+                if (m < M) {
+                    size_t drow = m;
+                    if (perm) drow = (size_t)(m / Pd) * Pd + perm[m % Pd];
+                    dst[drow * N + col] = acc[i][j][r] + bv;
+                }
+            }
+    }
+}
+
+template <int BM, int BN>
+static void launch_gather_gemm(const GatherGemmArgs& a, hipStream_t s) {
+    const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * 4 + (size_t)7 * a.E * BM * 4;
+    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in (idempotent, so a race is harmless)
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gather_gemm<BM, BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    prof_mark_begin(BM == 64 ? PROF_GG_64x64 : (BN == 128 ? PROF_GG_128x128 : PROF_GG_128x64), a.algo_flops, s);
+    hipLaunchKernelGGL((k_gather_gemm<BM, BN>), dim3(ntiles), dim3(256), lds, s, a.src, a.wt, a.bias, a.dst, a.idx,
+                       a.perm, a.mask32, a.M, a.Ps, a.Pd, a.K, a.N, a.E, a.ns);
+    prof_mark_end(s);
+}
+
+bool gather_gemm_supported(int K, int N) { return K % BK == 0 && N % 64 == 0 && K >= BK; }
+
+void launch_gather_gemm_auto(const GatherGemmArgs& a, hipStream_t s) {
+    // tile choice: fill 256 CUs; prefer the biggest tile that still yields >= ~2 blocks per CU
+    const long t128 = (long)((a.M + 127) / 128) * (a.N / 128);
+    if (a.N % 128 == 0 && t128 >= 512) return launch_gather_gemm<128, 128>(a, s);
+    const long t12864 = (long)((a.M + 127) / 128) * (a.N / 64);
+    if (t12864 >= 384) return launch_gather_gemm<128, 64>(a, s);
+    return launch_gather_gemm<64, 64>(a, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient:  partial[s][t][ci][co] = sum_{m in split s} x[gather_t(m)][ci] * dy[m][co]
+// ---------------------------------------------------------------------------------------------------------
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void k_wgrad(
+    const float* __restrict__ x,        // (B, Ps, Cin)
+    const float* __restrict__ dy,       // (B, Pd, Cout)
+    const int32_t* __restrict__ idx,    // forward table [7][Pd]
+    float* __restrict__ partial,        // [S][7][Cin][Cout]
+    int M, int Ps, int Pd, int Cin, int Cout, int ns, int rows_per_split) {
+    constexpr int TI = BI / 64, TJ = BJ / 64;
+    constexpr int CI = BI / 4, CJ = BJ / 4;             // 16-byte chunks per row
+    constexpr int RI = 32 * CI / 256, RJ = 32 * CJ / 256;   // chunks per thread per stage (32 rows per stage)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Xs = reinterpret_cast<float*>(smem);          // [2][32][BI]
+    float* Ys = Xs + 2 * 32 * BI;                        // [2][32][BJ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ntj = Cout / BJ;
+    const int ci0 = (blockIdx.x / ntj) * BI, co0 = (blockIdx.x % ntj) * BJ;
+    const int t = blockIdx.y, split = blockIdx.z;
+    const int m_begin = split * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 rx[RI], ry[RJ];
+    auto stage_load = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+            const int c = tid + 256 * i, row = c / CI, ch = c % CI;
+            const int m = mb + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) {
+                const int b = m / Pd, p = m % Pd;
+                const int32_t code = idx[(size_t)t * Pd + p];
+                if (code >= 0) v = ld4(x + ((size_t)b * Ps + code) * Cin + ci0 + 4 * ch);
+                else if (code <= -2) v = pole_mean4(x, b, Ps, ns, -2 - code, Cin, ci0 + 4 * ch);
+            }
+            rx[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RJ; ++i) {
+            const int c = tid + 256 * i, row = c / CJ, ch = c % CJ;
+            const int m = mb + row;
+            ry[i] = m < m_end ? ld4(dy + (size_t)m * Cout + co0 + 4 * ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(Xs + buf * 32 * BI + 4 * c) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < RJ; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(Ys + buf * 32 * BJ + 4 * c) = ry[i];
+        }
+    };
+
+    const int nsteps = (m_end - m_begin + 31) / 32;
+    if (nsteps > 0) {
+        stage_load(m_begin);
+        stage_write(0);
+    }
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const bool more = step + 1 < nsteps;
+        if (more) stage_load(m_begin + (step + 1) * 32);
+        const float* xa = Xs + buf * 32 * BI + wr * (BI / 2) + l31;
+        const float* yb = Ys + buf * 32 * BJ + wc * (BJ / 2) + l31;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int k = 2 * k2 + h;
+            float a[TI], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = xa[k * BI + i * 32];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[j] = yb[k * BJ + j * 32];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stage_write(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = partial + ((size_t)split * 7 + t) * Cin * Cout;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wr * (BI / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int co = co0 + wc * (BJ / 2) + j * 32 + l31;
+                out[(size_t)ci * Cout + co] = acc[i][j][r];
+            }
+}
+
+// dw[co][ci][t] = sum_s partial[s][t][ci][co]
+__global__ void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, int S, int Cin, int Cout) {
+    const int total = 7 * Cin * Cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += partial[(size_t)k * total + i];
+        const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cin * Cout);
+        dw[((size_t)co * Cin + ci) * 7 + t] = s;
+    }
+}
+
+bool wgrad_supported(int Cin, int Cout) { return Cin % 64 == 0 && Cout % 64 == 0; }
+
+int wgrad_splits(int M, int Cin, int Cout) {
+    const int bi = (Cin % 128 == 0) ? 128 : 64, bj = (Cout % 128 == 0) ? 128 : 64;
+    const long tiles = 7L * (Cin / bi) * (Cout / bj);
+    long s = (1024 + tiles - 1) / tiles;                   // ~4 blocks per CU in flight
+    const long max_s = (M + 255) / 256;                    // >= 8 stages of 32 rows per block
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+void launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    const int S = wgrad_splits(a.M, a.Cin, a.Cout);
+    int rows = (a.M + S - 1) / S;
+    rows = (rows + 31) / 32 * 32;
+    const bool bi128 = a.Cin % 128 == 0, bj128 = a.Cout % 128 == 0;
+    const int BI = bi128 ? 128 : 64, BJ = bj128 ? 128 : 64;
+    dim3 grid((a.Cin / BI) * (a.Cout / BJ), 7, S);
+    const size_t lds = (size_t)2 * 32 * (BI + BJ) * 4;
+#define ICN_WG(I, J)                                                                                              \
+    hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.M, a.Ps, a.Pd, a.Cin, \
+                       a.Cout, a.ns, rows)
+    prof_mark_begin(bi128 ? (bj128 ? PROF_WG_128x128 : PROF_WG_128x64) : (bj128 ? PROF_WG_64x128 : PROF_WG_64x64),
+                    a.algo_flops, s);
+    if (bi128 && bj128) ICN_WG(128, 128);
+    else if (bi128) ICN_WG(128, 64);
+    else if (bj128) ICN_WG(64, 128);
+    else ICN_WG(64, 64);
+    prof_mark_end(s);
+#undef ICN_WG
+    const int total = 7 * a.Cin * a.Cout;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, s, a.partial, a.dw, S, a.Cin, a.Cout);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// column sums (bias gradient): partial[chunk][C] then reduce
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_colsum_partial(const float* __restrict__ dy, float* __restrict__ partial, int M, int C, int rows_per_block) {
+    const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int m = m0; m < m1; ++m) s += dy[(size_t)m * C + c];
+        partial[(size_t)blockIdx.x * C + c] = s;
+    }
+}
+__global__ void k_reduce_rows(const float* __restrict__ partial, float* __restrict__ out, int S, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += partial[(size_t)k * C + c];
+    out[c] = s;
+}
+
+int colsum_chunks(int M) { return std::min(1024, (M + 63) / 64); }
+
+void launch_colsum(const float* dy, float* partial, float* out, int M, int C, hipStream_t s) {
+    const int chunks = colsum_chunks(M);
+    const int rows = (M + chunks - 1) / chunks;
+    hipLaunchKernelGGL(k_colsum_partial, dim3(chunks), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)), 0, s, dy, partial, M,
+                       C, rows);
+    hipLaunchKernelGGL(k_reduce_rows, dim3((C + 63) / 64), dim3(64), 0, s, partial, out, chunks, C);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ELL sparse row mix: out[b, r, :] = sum_e coef[r][e] * in[b, idx[r][e], :]     (HBM-bound)
+// ---------------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void k_spmm_ell(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ idx,
+                           const float* __restrict__ coef, int B, int Pin, int Pout, int C, int W) {
+    const int cv = C / VEC;
+    const size_t total = (size_t)B * Pout * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VEC;
+        const size_t br = i / cv;
+        const int r = (int)(br % Pout), b = (int)(br / Pout);
+        float accv[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) accv[v] = 0.f;
+        for (int e = 0; e < W; ++e) {
+            const int32_t j = idx[(size_t)r * W + e];
+            if (j < 0) break;   // rows are left-packed
+            const float w = coef[(size_t)r * W + e];
+            const float* p = in + ((size_t)b * Pin + j) * C + c;
+            if (VEC == 4) {
+                const f32x4 x = ld4(p);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) accv[v] += w * x[v];
+            } else {
+                accv[0] += w * p[0];
+            }
+        }
+        float* o = out + br * C + c;
+        if (VEC == 4) *reinterpret_cast<f32x4*>(o) = f32x4{accv[0], accv[1], accv[2], accv[3]};
+        else o[0] = accv[0];
+    }
+}
+
+void launch_spmm_ell(const float* in, float* out, const int32_t* idx, const float* coef, int B, int Pin, int Pout, int C,
+                     int W, hipStream_t s) {
+    const int vec = (C % 4 == 0) ? 4 : 1;
+    const size_t total = (size_t)B * Pout * (C / vec);
+    const int blocks = (int)std::min((size_t)8192, (total + 255) / 256);
+    if (vec == 4)
+        hipLaunchKernelGGL(k_spmm_ell<4>, dim3(blocks), dim3(256), 0, s, in, out, idx, coef, B, Pin, Pout, C, W);
+    else
+        hipLaunchKernelGGL(k_spmm_ell<1>, dim3(blocks), dim3(256), 0, s, in, out, idx, coef, B, Pin, Pout, C, W);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scalar fall-backs (any Cin / Cout)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gather1(const float* src, int32_t code, int b, int Ps, int ns, int K, int ch) {
+    if (code >= 0) return src[((size_t)b * Ps + code) * K + ch];
+    if (code <= -2) {
+        float s = 0.f;
+        for (int c = 0; c < 5; ++c) s += src[((size_t)b * Ps + corner_pixel(ns, -2 - code, c)) * K + ch];
+        return s * 0.2f;
+    }
+    return 0.f;
+}
+
+// dst[b,p,n] = bias[n] + sum_t sum_e sum_k gather(src, idx[t][e][p])[k] * w(n,k,t)
+// w is the parameter tensor [Cout][Cin][7]; transpose = 0: n = co, k = ci (forward); 1: n = ci, k = co (bwd-data)
+__global__ void k_conv_generic(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias,
+                               float* __restrict__ dst, const int32_t* __restrict__ idx, int B, int Ps, int Pd, int K, int N,
+                               int E, int ns, int transpose) {
+    const size_t total = (size_t)B * Pd * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        const size_t bp = i / N;
+        const int p = (int)(bp % Pd), b = (int)(bp / Pd);
+        float s = bias ? bias[n] : 0.f;
+        for (int t = 0; t < 7; ++t)
+            for (int e = 0; e < E; ++e) {
+                const int32_t code = idx[((size_t)t * E + e) * Pd + p];
+                if (code == -1) continue;
+                for (int k = 0; k < K; ++k) {
+                    const float wv = transpose ? w[((size_t)k * N + n) * 7 + t] : w[((size_t)n * K + k) * 7 + t];
+                    s += gather1(src, code, b, Ps, ns, K, k) * wv;
+                }
+            }
+        dst[i] = s;
+    }
+}
+
+void launch_conv_generic(const float* src, const float* w, const float* bias, float* dst, const int32_t* idx, int B, int Ps,
+                         int Pd, int K, int N, int E, int ns, int transpose, hipStream_t s) {
+    const size_t total = (size_t)B * Pd * N;
+    const int blocks = (int)std::min((size_t)16384, (total + 255) / 256);
+    hipLaunchKernelGGL(k_conv_generic, dim3(blocks), dim3(256), 0, s, src, w, bias, dst, idx, B, Ps, Pd, K, N, E, ns,
+                       transpose);
+}
+
+// partial[chunk][t][ci][co] over row chunks; reduced by k_wgrad_reduce
+__global__ void k_wgrad_generic(const float* __restrict__ x, const float* __restrict__ dy, const int32_t* __restrict__ idx,
+                                float* __restrict__ partial, int M, int Ps, int Pd, int Cin, int Cout, int ns,
+                                int rows_per_split) {
+    const int total = 7 * Cin * Cout;
+    const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cin * Cout);
+        float s = 0.f;
+        for (int m = m0; m < m1; ++m) {
+            const int b = m / Pd, p = m % Pd;
+            const int32_t code = idx[(size_t)t * Pd + p];
+            if (code == -1) continue;
+            s += gather1(x, code, b, Ps, ns, Cin, ci) * dy[(size_t)m * Cout + co];
+        }
+        partial[(size_t)blockIdx.y * total + i] = s;
+    }
+}
+
+int wgrad_generic_splits(int M) { return std::min(512, (M + 127) / 128); }
+
+void launch_wgrad_generic(const WgradArgs& a, hipStream_t s) {
+    const int S = wgrad_generic_splits(a.M);
+    const int rows = (a.M + S - 1) / S;
+    const int total = 7 * a.Cin * a.Cout;
+    dim3 grid(std::min(64, (total + 255) / 256), S);
+    hipLaunchKernelGGL(k_wgrad_generic, grid, dim3(256), 0, s, a.x, a.dy, a.idx, a.partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout,
+                       a.ns, rows);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, s, a.partial, a.dw, S, a.Cin, a.Cout);
+}
+
+void launch_pack_weights(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t s) {
+    const int total = Cout * Cin * 7;
+    hipLaunchKernelGGL(k_pack_weights, dim3(std::min(2048, (total + 255) / 256)), dim3(256), 0, s, w, out, Cout, Cin, transpose);
+}
+
+}  // namespace icn

@@ -1,0 +1,57 @@
+// Internal launch interface between the C ABI (icn_api.cpp) and the kernels (icn_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace icn {
+
+struct GatherGemmArgs {
+    const float* src;       // (B, Ps, K)
+    const float* wt;        // [7][N][K]
+    const float* bias;      // [N] or null
+    float* dst;             // (B, Pd, N)
+    const int32_t* idx;     // [7][E][Pd]
+    const int32_t* perm;    // [Pd] or null
+    const uint8_t* mask32;  // [Pd/32] or null
+    int M, Ps, Pd, K, N, E, ns;
+    double algo_flops;      // algorithmic FLOPs of this launch (profiling only)
+};
+
+struct WgradArgs {
+    const float* x;         // (B, Ps, Cin)
+    const float* dy;        // (B, Pd, Cout)
+    const int32_t* idx;     // forward table [7][Pd]
+    float* partial;         // [S][7][Cin][Cout]
+    float* dw;              // [Cout][Cin][7]
+    int M, Ps, Pd, Cin, Cout, ns;
+    double algo_flops;
+};
+
+bool gather_gemm_supported(int K, int N);
+void launch_gather_gemm_auto(const GatherGemmArgs& a, hipStream_t s);
+
+bool wgrad_supported(int Cin, int Cout);
+int wgrad_splits(int M, int Cin, int Cout);
+void launch_wgrad(const WgradArgs& a, hipStream_t s);
+int wgrad_generic_splits(int M);
+void launch_wgrad_generic(const WgradArgs& a, hipStream_t s);
+
+int colsum_chunks(int M);
+void launch_colsum(const float* dy, float* partial, float* out, int M, int C, hipStream_t s);
+
+void launch_spmm_ell(const float* in, float* out, const int32_t* idx, const float* coef, int B, int Pin, int Pout, int C,
+                     int W, hipStream_t s);
+
+void launch_conv_generic(const float* src, const float* w, const float* bias, float* dst, const int32_t* idx, int B, int Ps,
+                         int Pd, int K, int N, int E, int ns, int transpose, hipStream_t s);
+
+void launch_pack_weights(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t s);
+
+// ---- optional per-launch HIP-event timing of the MFMA kernels (bench.py's live roofline measurement) ----------
+enum ProfKind { PROF_GG_128x128 = 0, PROF_GG_128x64, PROF_GG_64x64, PROF_WG_128x128, PROF_WG_128x64, PROF_WG_64x128,
+                PROF_WG_64x64, PROF_KINDS };
+extern const char* const PROF_NAMES[PROF_KINDS];
+void prof_mark_begin(int kind, double flops, hipStream_t s);   // no-ops unless profiling is on
+void prof_mark_end(hipStream_t s);
+
+}  // namespace icn

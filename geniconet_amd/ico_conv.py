@@ -1,0 +1,191 @@
+"""`IcoConvS2S` / `IcoUpsampleS2S`: the nn.Module plugin surface of `icocnn.ico_conv`, on the HIP path.
+
+Reference call sites (the only specification of the surface that survives; upstream icocnn is absent):
+  IcoConvS2S(in_features, out_features, stride, bias, subdivisions, corner_mode)   models.py:14,25-33,104-109
+  IcoUpsampleS2S(in_features, subdivisions, corner_mode)                            models.py:13,45,53
+Tensors are (B, C, 5*2^r, 2^(r+1)) fp32 (data.py:64-69).  `subdivisions` is the level of the INPUT
+(models.py:25-29).  Parameters: `weight` (Cout, Cin, 7), `bias` (Cout).
+
+Every forward/backward goes through the C ABI of libicn.so (include/icn.h) on the caller's current HIP
+stream.  There is no CPU implementation here: CPU tensors are rejected (the CPU restatement used for parity
+is test infrastructure under oracle/).
+"""
+import math
+
+import torch
+
+from . import _lib
+
+
+def _require_gpu(x, who):
+    if not x.is_cuda:
+        raise RuntimeError(
+            '%s: got a %s tensor; this operator only runs on the MI355X HIP path (libicn.so). '
+            'Move the module and its input to a ROCm device.' % (who, x.device))
+    if x.dtype != torch.float32:
+        raise TypeError('%s: fp32 only, got %s' % (who, x.dtype))
+
+
+def _check_grid(x, r, who):
+    n = 2 ** r
+    if x.dim() != 4 or x.shape[2] != 5 * n or x.shape[3] != 2 * n:
+        raise ValueError('%s: expected (B, C, %d, %d) at subdivisions=%d, got %s'
+                         % (who, 5 * n, 2 * n, r, tuple(x.shape)))
+
+
+def _nhwc(x):
+    """(B,C,H,W) logical -> contiguous (B,H,W,C) storage; free when x is already channels_last."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+class _IcoConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, r, stride, mode):
+        L = _lib.lib()
+        B, Cin = x.shape[0], x.shape[1]
+        Cout = weight.shape[0]
+        n_out = 2 ** r // stride
+        xp = _nhwc(x)
+        w = weight.contiguous()
+        b = bias.contiguous() if bias is not None else None
+        y = torch.empty(B, 5 * n_out, 2 * n_out, Cout, dtype=torch.float32, device=x.device)
+        ws_bytes = L.icn_conv_workspace_bytes(_lib.OP_CONV_FWD, B, Cin, Cout, r, stride)
+        ws = _workspace(ws_bytes, x.device)
+        with torch.cuda.device(x.device):
+            rc = L.icn_conv_fwd(xp.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(),
+                                B, Cin, Cout, r, stride, mode, ws.data_ptr(), ws_bytes, _stream())
+        _lib.check(rc, 'icn_conv_fwd')
+        ctx.save_for_backward(xp, w)
+        ctx.cfg = (B, Cin, Cout, r, stride, mode, bias is not None)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        L = _lib.lib()
+        xp, w = ctx.saved_tensors
+        B, Cin, Cout, r, stride, mode, has_bias = ctx.cfg
+        gyp = _nhwc(gy)
+        dx = dw = db = None
+        with torch.cuda.device(gyp.device):
+            if ctx.needs_input_grad[0]:
+                dxp = torch.empty_like(xp)
+                ws_bytes = L.icn_conv_workspace_bytes(_lib.OP_CONV_BWD_DATA, B, Cin, Cout, r, stride)
+                ws = _workspace(ws_bytes, gyp.device)
+                rc = L.icn_conv_bwd_data(gyp.data_ptr(), w.data_ptr(), dxp.data_ptr(), B, Cin, Cout, r, stride, mode,
+                                         ws.data_ptr(), ws_bytes, _stream())
+                _lib.check(rc, 'icn_conv_bwd_data')
+                dx = dxp.permute(0, 3, 1, 2)
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                dw = torch.empty_like(w)
+                db = torch.empty(Cout, dtype=torch.float32, device=w.device) if has_bias else None
+                ws_bytes = L.icn_conv_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, B, Cin, Cout, r, stride)
+                ws = _workspace(ws_bytes, gyp.device)
+                rc = L.icn_conv_bwd_weight(xp.data_ptr(), gyp.data_ptr(), dw.data_ptr(),
+                                           db.data_ptr() if db is not None else None, B, Cin, Cout, r, stride, mode,
+                                           ws.data_ptr(), ws_bytes, _stream())
+                _lib.check(rc, 'icn_conv_bwd_weight')
+        return dx, dw, db, None, None, None
+
+
+class _IcoUpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r, mode):
+        L = _lib.lib()
+        B, C = x.shape[0], x.shape[1]
+        n = 2 ** r
+        xp = _nhwc(x)
+        y = torch.empty(B, 10 * n, 4 * n, C, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L.icn_upsample_fwd(xp.data_ptr(), y.data_ptr(), B, C, r, mode, _stream())
+        _lib.check(rc, 'icn_upsample_fwd')
+        ctx.cfg = (B, C, r, mode)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        L = _lib.lib()
+        B, C, r, mode = ctx.cfg
+        n = 2 ** r
+        gyp = _nhwc(gy)
+        dx = torch.empty(B, 5 * n, 2 * n, C, dtype=torch.float32, device=gy.device)
+        with torch.cuda.device(gy.device):
+            rc = L.icn_upsample_bwd(gyp.data_ptr(), dx.data_ptr(), B, C, r, mode, _stream())
+        _lib.check(rc, 'icn_upsample_bwd')
+        return dx.permute(0, 3, 1, 2), None, None
+
+
+def ico_conv(x, weight, bias, subdivisions, stride=1, corner_mode='zeros'):
+    """Functional form of IcoConvS2S.forward."""
+    _require_gpu(x, 'ico_conv')
+    _check_grid(x, subdivisions, 'ico_conv')
+    if weight.dim() != 3 or weight.shape[1] != x.shape[1] or weight.shape[2] != 7:
+        raise ValueError('ico_conv: weight must be (Cout, %d, 7), got %s' % (x.shape[1], tuple(weight.shape)))
+    if stride not in (1, 2):
+        raise ValueError('ico_conv: stride must be 1 or 2')
+    return _IcoConvFn.apply(x, weight, bias, subdivisions, stride, _lib.corner_code(corner_mode))
+
+
+def ico_upsample(x, subdivisions, corner_mode='zeros'):
+    """Functional form of IcoUpsampleS2S.forward."""
+    _require_gpu(x, 'ico_upsample')
+    _check_grid(x, subdivisions, 'ico_upsample')
+    return _IcoUpsampleFn.apply(x, subdivisions, _lib.corner_code(corner_mode))
+
+
+class IcoConvS2S(torch.nn.Module):
+    """7-tap hexagonal conv over the 5 icosahedral charts (scalar-to-scalar features), stride 1 or 2."""
+
+    def __init__(self, in_features, out_features, stride=1, bias=True, subdivisions=0, corner_mode='zeros'):
+        super().__init__()
+        if stride not in (1, 2):
+            raise ValueError('IcoConvS2S: stride must be 1 or 2')
+        if stride == 2 and subdivisions < 1:
+            raise ValueError('IcoConvS2S: stride 2 needs subdivisions >= 1')
+        _lib.corner_code(corner_mode)
+        self.in_features, self.out_features = in_features, out_features
+        self.stride, self.subdivisions, self.corner_mode = stride, subdivisions, corner_mode
+        self.weight = torch.nn.Parameter(torch.empty(out_features, in_features, 7))
+        if bias:
+            self.bias = torch.nn.Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # upstream init is unknown; kaiming_uniform(a=sqrt(5)) on fan_in = 7*Cin, i.e. nn.Conv2d's default
+        bound = 1.0 / math.sqrt(7 * self.in_features)
+        torch.nn.init.uniform_(self.weight, -bound, bound)
+        if self.bias is not None:
+            torch.nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return ico_conv(x, self.weight, self.bias, self.subdivisions, self.stride, self.corner_mode)
+
+    def extra_repr(self):
+        return '%d, %d, stride=%d, subdivisions=%d, corner_mode=%s, bias=%s' % (
+            self.in_features, self.out_features, self.stride, self.subdivisions, self.corner_mode, self.bias is not None)
+
+
+class IcoUpsampleS2S(torch.nn.Module):
+    """subdivisions -> subdivisions+1: copy at coarse sites, edge-midpoint mean elsewhere."""
+
+    def __init__(self, in_features, subdivisions=0, corner_mode='zeros'):
+        super().__init__()
+        _lib.corner_code(corner_mode)
+        self.in_features, self.subdivisions, self.corner_mode = in_features, subdivisions, corner_mode
+
+    def forward(self, x):
+        return ico_upsample(x, self.subdivisions, self.corner_mode)
+
+    def extra_repr(self):
+        return '%d, subdivisions=%d, corner_mode=%s' % (self.in_features, self.subdivisions, self.corner_mode)

@@ -1,0 +1,120 @@
+"""Losses of the ico2ico / ico2ico_vae training step (reference losses.py:10-145).
+
+Same classes, constructor arguments and reporting methods as the reference.  The mesh helpers the reference
+imports from the absent `PythonFunctions/mesh/utils.py` (losses.py:7) are restated here:
+  * vertex normals: area-weighted face-normal accumulation, normalised -- the formula the reference itself
+    ships for its preprocessing, generate.py:20-43;
+  * Laplacian: uniform umbrella operator  mean(1-ring) - v  (upstream's sign/normalisation is unpinned).
+Loss values are kept as device tensors; `.item()` (a host sync in the reference on every iteration,
+losses.py:72,81,129) only happens when get_last_losses() is called.
+"""
+import torch
+
+from . import geometry
+
+
+def grid_to_vertices(x, subdivisions):
+    """(B, C, 5n, 2n) -> (B, 10*4^r + 2, C): row-major grid then N, S poles (mean of the 5 corner pixels);
+    reference losses.py:47-51, ico_utils.py:10-24."""
+    n = 2 ** subdivisions
+    B, C = x.shape[:2]
+    x5 = x.reshape(B, C, 5, n, 2 * n)
+    poles = torch.stack((x5[:, :, :, 0, 0].mean(-1), x5[:, :, :, n - 1, 2 * n - 1].mean(-1)), dim=2)
+    return torch.cat((x.reshape(B, C, -1), poles), dim=2).transpose(1, 2).contiguous()
+
+
+def compute_vertex_normals(v, faces, eps=1e-10):
+    """v (B, N, 3), faces (F, 3) int64 -> unit vertex normals (B, N, 3), face-area weighted (generate.py:20-43)."""
+    v0, v1, v2 = v[:, faces[:, 0]], v[:, faces[:, 1]], v[:, faces[:, 2]]
+    fn = torch.cross(v1 - v0, v2 - v0, dim=2)
+    vn = torch.zeros_like(v)
+    for k in range(3):
+        vn = vn.index_add(1, faces[:, k], fn)
+    return vn / vn.norm(dim=2, keepdim=True).clamp_min(eps)
+
+
+def compute_laplacian_batch(v, nbr_idx, nbr_w):
+    """Uniform Laplacian: mean of the 1-ring minus the vertex.  nbr_idx (N, 6) int64 (padding entries point at
+    vertex 0 with weight 0), nbr_w (N, 6) = 1/valence or 0."""
+    ring = v[:, nbr_idx]                       # (B, N, 6, 3)
+    return (ring * nbr_w[None, :, :, None]).sum(2) - v
+
+
+class Point2Point_Loss(torch.nn.Module):
+    """factor_pos * MSE(v) + factor_nor * mean(1 - cos(normals)) + factor_lap * MSE(laplacian)
+    against target rows [0:3], [3:6], [6:9]  -- reference losses.py:10-85."""
+
+    def __init__(self, subdivisions, factor_pos, factor_nor, factor_lap):
+        super().__init__()
+        self.subdivisions = subdivisions
+        self.factor_pos, self.factor_nor, self.factor_lap = factor_pos, factor_nor, factor_lap
+        self.register_buffer('ico_faces', torch.from_numpy(geometry.get_ico_faces(subdivisions)))
+        nbr = torch.from_numpy(geometry.vertex_neighbours(subdivisions).copy())
+        valid = nbr >= 0
+        self.register_buffer('nbr_idx', nbr.clamp_min(0))
+        self.register_buffer('nbr_w', valid.float() / valid.sum(1, keepdim=True).float())
+        self.last_loss_mse = self.last_loss_cos = self.last_loss_lap = self.last_loss_total = 0
+
+    def forward(self, inputs, target):
+        v = grid_to_vertices(inputs, self.subdivisions)
+        normals = compute_vertex_normals(v, self.ico_faces)       # evaluated even when their factor is 0,
+        lap = compute_laplacian_batch(v, self.nbr_idx, self.nbr_w)  # as the reference does (losses.py:54,57)
+        tgt = target.transpose(1, 2)
+        l_pos = torch.nn.functional.mse_loss(v, tgt[:, :, :3])
+        l_nor = torch.mean(1 - torch.nn.functional.cosine_similarity(normals, tgt[:, :, 3:6], dim=2))
+        l_lap = torch.nn.functional.mse_loss(lap, tgt[:, :, 6:9])
+        loss = self.factor_pos * l_pos + self.factor_nor * l_nor + self.factor_lap * l_lap
+        self.last_loss_mse, self.last_loss_cos, self.last_loss_lap = l_pos.detach(), l_nor.detach(), l_lap.detach()
+        self.last_loss_total = loss.detach()
+        return loss
+
+    def get_last_losses(self):
+        return float(self.last_loss_mse), self.last_loss_cos, self.last_loss_lap, float(self.last_loss_total)
+
+
+class KLD_Loss(torch.nn.Module):
+    """mean_b( -0.5 * mean_d(1 + logvar - mu^2 - exp(logvar)) )   -- reference losses.py:87-118."""
+
+    def forward(self, output, target):
+        _, mu, logvar = output
+        mu, logvar = torch.flatten(mu, start_dim=1), torch.flatten(logvar, start_dim=1)
+        if self.factor_kl:
+            self.loss = torch.mean(-0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp(), dim=1), dim=0)
+        else:
+            self.loss = torch.tensor(0.)
+        return self.loss
+
+    def get_last_losses(self):
+        return 0, 0, 0, 0, -float(self.loss)
+
+    def get_factor(self):
+        return self.factor_kl
+
+    def update_factor(self, epoch, factor_step_size, factor_gamma):
+        if epoch % factor_step_size == 0:
+            self.factor_kl *= factor_gamma
+
+
+class P2P_Loss(Point2Point_Loss):
+    """reference losses.py:121-130."""
+
+    def get_last_losses(self):
+        return (float(self.last_loss_mse), float(self.last_loss_cos), float(self.last_loss_lap), 0.,
+                float(self.last_loss_total))
+
+
+class P2PKLD_Loss(P2P_Loss, KLD_Loss):
+    """reconstruction + factor_kl * KLD   -- reference losses.py:132-145."""
+
+    def __init__(self, subdivisions, factor_pos, factor_nor, factor_lap, factor_kl):
+        super().__init__(subdivisions, factor_pos, factor_nor, factor_lap)
+        self.factor_kl = factor_kl
+
+    def forward(self, output, target):
+        self.kld_loss = KLD_Loss.forward(self, output, target)
+        self.recons_loss = P2P_Loss.forward(self, output[0], target)
+        self.loss = self.recons_loss + self.factor_kl * self.kld_loss
+        return self.loss
+
+    def get_last_losses(self):
+        return float(self.recons_loss), 0, 0, -float(self.kld_loss), float(self.loss)

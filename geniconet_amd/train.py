@@ -1,0 +1,87 @@
+"""Training step of the hot path: forward -> loss -> zero_grad -> backward -> Adam -> CyclicLR, per batch.
+
+Mirrors the reference's inner loop (run.py:240-254) and its optimiser/scheduler setup (run.py:436-454):
+`P2P_Loss(subdivisions, 1, 0, 0)` / `P2PKLD_Loss(..., 0.6, 0.2, 0.2, factor_KL=1)`, `Adam(lr=1e-6)`,
+`CyclicLR(base_lr=1e-9, max_lr=1e-3, cycle_momentum=False)` stepped every batch.  `detect_anomaly`
+(run.py:237) is a debugging aid and is off by default here; pass anomaly=True to reproduce it.
+
+Data parallelism (new; the reference is single-device): one process per GPU, full replica per rank, per-rank
+batch and BatchNorm statistics (a rank reproduces the single-GPU computation on its shard), gradients
+averaged by bucketed all-reduce over RCCL overlapped with backward (torch DistributedDataParallel), identical
+initial weights by broadcast from rank 0, optimiser/scheduler replicated.
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+
+from . import losses, models
+
+GRAD_BUCKET_MB = 5   # ~4 buckets for the 18.5 MB (AE) / 24 MB (VAE) of fp32 gradients, decoder first
+
+
+def build_model(params, device):
+    cls = getattr(models, params['model_name'])
+    return cls(params).to(device)
+
+
+def build_criterion(params, device):
+    """run.py:432-444."""
+    ico, loss_kind = params['ico'], params[params['model_name']]['loss']
+    args = (ico['subdivisions'], ico['factor_pos'], ico['factor_nor'], ico['factor_lap'])
+    if loss_kind == 'p2p':
+        crit = losses.P2P_Loss(*args)
+    elif loss_kind == 'p2pkld':
+        crit = losses.P2PKLD_Loss(*args, 1.)
+    else:
+        raise ValueError('loss for %s model not specified' % params['model_name'])
+    return crit.to(device)
+
+
+class Trainer:
+    def __init__(self, params, device, model=None, criterion=None, seed=0, anomaly=False, channels_last=True):
+        self.params, self.device, self.anomaly = params, torch.device(device), anomaly
+        cfg = params[params['model_name']]
+        torch.manual_seed(seed)
+        self.model = model if model is not None else build_model(params, self.device)
+        if channels_last and self.device.type == 'cuda':
+            # (B,C,H,W) tensors stored (B,H,W,C) = the (B, 5, n, 2n, C) chart layout of the kernels: BatchNorm,
+            # ReLU and the 1x1 head then read/write that layout directly and no transposes are needed.
+            self.model = self.model.to(memory_format=torch.channels_last)
+        self.criterion = criterion if criterion is not None else build_criterion(params, self.device)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.net = self.model
+        if self.world > 1:
+            ids = [self.device.index] if self.device.type == 'cuda' else None
+            self.net = torch.nn.parallel.DistributedDataParallel(
+                self.model, device_ids=ids, bucket_cap_mb=GRAD_BUCKET_MB, gradient_as_bucket_view=True,
+                broadcast_buffers=False)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=cfg['lr'])               # run.py:446
+        self.scheduler = None
+        if 'lr_base' in cfg and 'lr_max' in cfg:                                               # run.py:448-450
+            self.scheduler = torch.optim.lr_scheduler.CyclicLR(self.optimizer, cfg['lr_base'], cfg['lr_max'],
+                                                               cycle_momentum=False)
+        self.model.train()
+
+    def step(self, img, lbl):
+        """One batch of run.py:244-254.  Returns the loss tensor (no host sync)."""
+        ctx = torch.autograd.detect_anomaly() if self.anomaly else contextlib.nullcontext()
+        with ctx:
+            output = self.net(img)
+            loss = self.criterion(output, lbl)
+            self.optimizer.zero_grad()
+            loss.backward()
+            self.optimizer.step()
+            if self.scheduler is not None:
+                self.scheduler.step()
+        return loss.detach()
+
+    @torch.no_grad()
+    def evaluate(self, img, lbl):
+        """Forward + loss with the module in eval mode (run.py:280-296), restoring train mode after."""
+        was_training = self.model.training
+        self.model.eval()
+        try:
+            return self.criterion(self.model(img), lbl)
+        finally:
+            self.model.train(was_training)

@@ -1,0 +1,97 @@
+/* libicn -- C ABI of the MI355X-native icosahedral hex-convolution hot path.
+ *
+ * Drop-in boundary for the operators GenIcoNet imports from the (un-vendored) `icocnn` package:
+ *   icocnn.ico_conv.IcoConvS2S      reference call sites models.py:14,25-33,46-55,104-109,165-170,269-284
+ *   icocnn.ico_conv.IcoUpsampleS2S  reference call sites models.py:13,45,53
+ *   icocnn.utils.ico_geometry.get_ico_faces   reference call sites losses.py:34, run.py:144,529
+ * The reference has no FFI of its own (it is pure Python over PyTorch); these entry points are what a
+ * ctypes binding of those modules binds (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - All activations are fp32, channels-last per chart: x[b][c5][i][j][ch] == PyTorch
+ *     `torch.channels_last` storage of the (B, C, 5*2^r, 2^(r+1)) tensor the reference passes around
+ *     (layout pinned by data.py:64-69).  Row-major pixel id p = (c5*n + i)*2n + j, n = 2^r.
+ *   - Weights: w[Cout][Cin][7] fp32; tap order = centre, then the six hex neighbours (di,dj) =
+ *     (+1,0),(0,+1),(-1,+1),(-1,0),(0,-1),(+1,-1).  bias[Cout] or NULL.
+ *   - `r_in` is the subdivision level of the op's INPUT (models.py:25-29 semantics); stride 2 halves it.
+ *   - corner_mode: 0 = 'zeros', 1 = 'average' (run.py:683); pole value = mean of its 5 corner pixels
+ *     (losses.py:49-51).
+ *   - Every device buffer (incl. workspace) is owned by the caller.  Calls are asynchronous on `stream`
+ *     (a hipStream_t).  The library keeps only immutable per-(device, r, stride, corner_mode) index tables,
+ *     built once under a mutex on first use (icn_prepare builds them eagerly, e.g. before graph capture).
+ *   - Return 0 on success, negative on error; message via icn_last_error() (thread-local).  Nothing
+ *     throws across the boundary.
+ */
+#ifndef ICN_H
+#define ICN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICN_ABI_VERSION 1
+
+#define ICN_CORNER_ZEROS 0
+#define ICN_CORNER_AVERAGE 1
+
+/* index codes of the host tables (see icn_table_*): >=0 pixel id, -1 nothing, -2/-3 north/south pole mean */
+#define ICN_IDX_ZERO (-1)
+#define ICN_IDX_POLE (-2)
+
+#define ICN_OP_CONV_FWD 0
+#define ICN_OP_CONV_BWD_DATA 1
+#define ICN_OP_CONV_BWD_WEIGHT 2
+
+int icn_abi_version(void);
+const char* icn_last_error(void);
+
+/* Build (and upload to the current device) the index tables of one conv / upsample configuration. */
+int icn_prepare_conv(int r_in, int stride, int corner_mode);
+int icn_prepare_upsample(int r_in, int corner_mode);
+
+/* Bytes of caller-provided workspace an op needs (0 is a valid answer). */
+size_t icn_conv_workspace_bytes(int op, int B, int Cin, int Cout, int r_in, int stride);
+
+/* y[b,p,co] = bias[co] + sum_t sum_ci w[co,ci,t] * x[b, nbr_t(p), ci]         (IcoConvS2S.forward) */
+int icn_conv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout,
+                 int r_in, int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream);
+
+/* dx = transpose of the gather, incl. the pole-mean and duplicated taps at five-valent pixels */
+int icn_conv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int r_in,
+                      int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream);
+
+/* dw[co,ci,t] = sum_{b,p} dy[b,p,co] * x[b,nbr_t(p),ci];  dbias[co] = sum dy (dbias may be NULL) */
+int icn_conv_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout,
+                        int r_in, int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream);
+
+/* r_in -> r_in+1: copy at coarse sites (2i,2j+1), mean of the two edge endpoints elsewhere  (IcoUpsampleS2S) */
+int icn_upsample_fwd(const float* x, float* y, int B, int C, int r_in, int corner_mode, void* stream);
+int icn_upsample_bwd(const float* dy, float* dx, int B, int C, int r_in, int corner_mode, void* stream);
+
+/* Host-side introspection (no device needed).  Each writes at most `cap` elements and returns the element
+ * count required (negative on error). */
+long icn_table_conv_fwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap);      /* [7][P_out]     */
+long icn_table_conv_bwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap, int* width); /* [7][E][P_in] */
+long icn_table_upsample(int r_in, int corner_mode, int transpose, int32_t* idx, float* coef, size_t cap, int* width);
+long icn_table_upsample_pairs(int r_in, int32_t* out, size_t cap);                            /* [2][P_fine]   */
+long icn_table_faces(int r, int32_t* out, size_t cap);                                         /* [20*4^r][3]   */
+
+/* Optional diagnostics: HIP-event timing of every MFMA kernel launch between start and stop, on the launch
+ * stream.  `stop` synchronises the device and returns the number of entries written (one per kernel that ran).
+ * total_flops is ALGORITHMIC: 2*7*Cin*Cout*B*P_out per launch.  Not thread-safe; off by default. */
+typedef struct icn_profile_entry {
+    const char* kernel;
+    long launches;
+    double total_ms;
+    double total_flops;
+} icn_profile_entry;
+int icn_profile_start(int max_launches);
+int icn_profile_stop(icn_profile_entry* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICN_H */

@@ -1,0 +1,66 @@
+"""ORACLE (test infrastructure, NOT product code) -- numpy restatement of the training losses.
+
+Follows /root/reference/losses.py:47-82 (Point2Point_Loss.forward), :105 (KLD), :137-142 (P2PKLD), with the
+absent mesh helpers restated as: vertex normals = /root/reference/generate.py:20-43 (mesh_vertexnormals,
+area-weighted), Laplacian = uniform umbrella mean(1-ring) - v (upstream unpinned).  float64 throughout.
+"""
+import numpy as np
+
+from .ico_ref import faces_from_lattice
+
+
+def grid_to_vertices(x, r):
+    """(B, C, 5n, 2n) -> (B, N, C); poles = mean of px[c*n, 0] / px[(c+1)*n-1, 2n-1]  (losses.py:23-31,49-51)."""
+    n = 2 ** r
+    B, C = x.shape[:2]
+    top = x[:, :, np.arange(5) * n, 0].mean(-1)
+    bot = x[:, :, np.arange(1, 6) * n - 1, -1].mean(-1)
+    v = np.concatenate([x.reshape(B, C, -1), top[:, :, None], bot[:, :, None]], axis=2)
+    return v.transpose(0, 2, 1)
+
+
+def vertex_normals(v, f, eps=1e-10):                      # generate.py:20-43, one mesh
+    fn = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]], axis=1)
+    vn = np.zeros_like(v)
+    for k in range(3):
+        np.add.at(vn, f[:, k], fn)
+    return vn / np.clip(np.sqrt((vn ** 2).sum(1)), eps, None)[:, None]
+
+
+def laplacian(v, f):
+    n = v.shape[0]
+    acc, deg = np.zeros_like(v), np.zeros(n)
+    seen = set()
+    for a, b, c in f:
+        for u, w in ((a, b), (b, c), (c, a)):
+            if (u, w) not in seen:
+                seen.add((u, w)); seen.add((w, u))
+                acc[u] += v[w]; acc[w] += v[u]
+                deg[u] += 1; deg[w] += 1
+    return acc / deg[:, None] - v
+
+
+def p2p_terms(pred, target, r):
+    """pred (B,3,5n,2n), target (B,9,N) -> (mse_pos, mean(1-cos), mse_lap)  (losses.py:66-80)."""
+    pred, target = np.asarray(pred, np.float64), np.asarray(target, np.float64)
+    f = faces_from_lattice(r)
+    v = grid_to_vertices(pred, r)
+    t = target.transpose(0, 2, 1)
+    cos, lap_err = [], []
+    for b in range(v.shape[0]):
+        nrm, tn = vertex_normals(v[b], f), t[b, :, 3:6]
+        den = np.maximum(np.linalg.norm(nrm, axis=1) * np.linalg.norm(tn, axis=1), 1e-8)   # CosineSimilarity eps
+        cos.append(1 - (nrm * tn).sum(1) / den)
+        lap_err.append((laplacian(v[b], f) - t[b, :, 6:9]) ** 2)
+    return ((v - t[:, :, :3]) ** 2).mean(), np.mean(cos), np.mean(lap_err)
+
+
+def p2p_loss(pred, target, r, f_pos, f_nor, f_lap):
+    a, b, c = p2p_terms(pred, target, r)
+    return f_pos * a + f_nor * b + f_lap * c
+
+
+def kld(mu, logvar):                                      # losses.py:105
+    mu = np.asarray(mu, np.float64).reshape(mu.shape[0], -1)
+    lv = np.asarray(logvar, np.float64).reshape(logvar.shape[0], -1)
+    return np.mean(-0.5 * np.mean(1 + lv - mu ** 2 - np.exp(lv), axis=1))

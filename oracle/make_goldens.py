@@ -1,0 +1,108 @@
+"""ORACLE (test infrastructure) -- writes the committed golden fixtures under tests/golden/.
+
+Run here (CPU container):  python -m oracle.make_goldens
+The vectors pin GPU == CPU-restatement (NOT == upstream: parity with hrdkjain/IcosahedralCNN is unpinned,
+see oracle/ico_ref.py).  Inputs are seeded; every array a test needs is stored, except the I5 model's
+weights (18.5 MB), which tests re-create from `torch.manual_seed(MODEL_SEED)` on the CPU generator.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ico_ref, loss_ref, models_ref
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+MODEL_SEED = 0
+
+# (name, r, stride, Cin, Cout, B, corner_mode)
+CONV_CASES = [
+    ('conv_r2_s1_c64x64_avg', 2, 1, 64, 64, 2, 'average'),      # MFMA path
+    ('conv_r2_s2_c64x128_avg', 2, 2, 64, 128, 2, 'average'),    # MFMA path, stride 2
+    ('conv_r2_s1_c3x8_avg', 2, 1, 3, 8, 2, 'average'),          # scalar path (stem-like)
+    ('conv_r1_s1_c5x7_zeros', 1, 1, 5, 7, 3, 'zeros'),
+    ('conv_r2_s2_c6x4_zeros', 2, 2, 6, 4, 2, 'zeros'),
+]
+UP_CASES = [('up_r2_c8_avg', 2, 8, 2, 'average'), ('up_r1_c5_zeros', 1, 5, 3, 'zeros'), ('up_r0_c4_avg', 0, 4, 2, 'average')]
+
+
+def conv_case(r, stride, cin, cout, B, mode, seed):
+    g = torch.Generator().manual_seed(seed)
+    n = 2 ** r
+    x = torch.randn(B, cin, 5 * n, 2 * n, generator=g, requires_grad=True)
+    w = (torch.randn(cout, cin, 7, generator=g) / (7 * cin) ** 0.5).requires_grad_()
+    b = torch.randn(cout, generator=g).requires_grad_()
+    y = ico_ref.ico_conv(x, w, b, r, stride, mode)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    return dict(x=x.detach(), w=w.detach(), b=b.detach(), y=y.detach(), gy=gy, dx=x.grad, dw=w.grad, db=b.grad)
+
+
+def up_case(r, C, B, mode, seed):
+    g = torch.Generator().manual_seed(seed)
+    n = 2 ** r
+    x = torch.randn(B, C, 5 * n, 2 * n, generator=g, requires_grad=True)
+    y = ico_ref.ico_upsample(x, r, mode)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    return dict(x=x.detach(), y=y.detach(), gy=gy, dx=x.grad)
+
+
+def synthetic_np(batch, r, seed):
+    """Seeded smooth radial perturbation of the unit icosphere; positions only (numpy, float64)."""
+    rs = np.random.RandomState(seed)
+    # unit directions from the oracle's own subdivision: normalised barycentric walk is not needed -- use faces
+    # to define nothing; directions come from recursive midpoint subdivision of the oracle's upsample table.
+    lat = np.arctan(0.5)
+    v = np.zeros((12, 3))
+    for c in range(5):
+        lu = -2 * np.pi * c / 5
+        v[2 * c] = (np.cos(lat) * np.cos(lu), np.cos(lat) * np.sin(lu), np.sin(lat))
+        v[2 * c + 1] = (np.cos(lat) * np.cos(lu + np.pi / 5), np.cos(lat) * np.sin(lu + np.pi / 5), -np.sin(lat))
+    v[10], v[11] = (0, 0, 1), (0, 0, -1)
+    for k in range(r):
+        a, b = ico_ref.upsample_table(k)
+        fine = 0.5 * (v[a] + v[b])
+        v = np.concatenate([fine / np.linalg.norm(fine, axis=1, keepdims=True), v[-2:]])
+    out = []
+    for _ in range(batch):
+        amp, freq, ph = (rs.rand(3) - .5) * 2 / 3, rs.randn(3, 3) * 2, rs.rand(3) * 2 * np.pi
+        rad = 0.75 * (1 + 0.25 * (amp[:, None] * np.sin(freq @ v.T + ph[:, None])).sum(0))
+        out.append(np.clip(v * rad[:, None], -0.95, 0.95))
+    return np.stack(out)                                                        # (B, N, 3)
+
+
+def model_case():
+    """BASELINE config 1: ico2ico forward + loss on 4 synthetic I5 samples, CPU restatement."""
+    r, B = 5, 4
+    f = ico_ref.faces_from_lattice(r)
+    pos = synthetic_np(B, r, seed=1234)
+    tgt = np.stack([np.concatenate([p, loss_ref.vertex_normals(p, f), loss_ref.laplacian(p, f)], 1).T for p in pos])
+    tgt = tgt.astype(np.float32)                                                 # (B, 9, N)
+    n = 2 ** r
+    x = torch.from_numpy(tgt[:, :3, :-2].reshape(B, 3, 5 * n, 2 * n).copy())
+    torch.manual_seed(MODEL_SEED)
+    model = models_ref.ico2ico(R=r, mode='average').train()
+    with torch.no_grad():
+        y = model(x)
+    terms = loss_ref.p2p_terms(y.numpy(), tgt, r)
+    return dict(target=tgt, y=y.numpy(), loss_terms=np.asarray(terms), model_seed=np.asarray(MODEL_SEED))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for k, (name, *cfg) in enumerate(CONV_CASES):
+        d = conv_case(*cfg, seed=100 + k)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), cfg=np.asarray(cfg[:5]), mode=cfg[5],
+                            **{k2: v.numpy() for k2, v in d.items()})
+    for k, (name, *cfg) in enumerate(UP_CASES):
+        d = up_case(*cfg, seed=200 + k)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), cfg=np.asarray(cfg[:3]), mode=cfg[3],
+                            **{k2: v.numpy() for k2, v in d.items()})
+    np.savez_compressed(os.path.join(OUT, 'ico2ico_I5_b4.npz'), **model_case())
+    for f in sorted(os.listdir(OUT)):
+        print('%-34s %8d B' % (f, os.path.getsize(os.path.join(OUT, f))))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,39 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol include/icn.h declares."""
+import ctypes
+import os
+import re
+
+from geniconet_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'icn.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(icn_[a-z_0-9]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_symbols()
+    assert len(names) >= 15
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), 'libicn.so does not export %s' % n
+    assert sorted(_lib.SIGNATURES) == names, 'ctypes binding and include/icn.h disagree'
+
+
+def test_abi_version_and_error_channel():
+    L = _lib.lib()
+    assert L.icn_abi_version() == _lib.ABI_VERSION
+    assert L.icn_table_conv_fwd(99, 1, 1, None, 0) < 0
+    assert b'subdivisions' in L.icn_last_error()
+
+
+def test_workspace_query_is_host_only():
+    L = _lib.lib()
+    # AE I5/B36 largest layers: packed weights (fwd) and split-K slabs (bwd-weight) are bounded
+    assert L.icn_conv_workspace_bytes(_lib.OP_CONV_FWD, 36, 128, 64, 5, 1) == 7 * 128 * 64 * 4
+    assert L.icn_conv_workspace_bytes(_lib.OP_CONV_FWD, 36, 3, 64, 5, 1) == 0
+    assert 0 < L.icn_conv_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, 36, 256, 256, 3, 1) < 256 << 20
+    assert L.icn_conv_workspace_bytes(7, 36, 256, 256, 3, 1) == 0

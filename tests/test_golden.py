@@ -1,0 +1,106 @@
+"""Committed golden vectors (tests/golden/, written by oracle/make_goldens.py).
+
+CPU: the oracle still reproduces them (guards the oracle against drift).
+GPU: the HIP path, called through the C ABI via the nn.Module surface, reproduces them.
+Tolerance (stated by BASELINE.json north_star): forward rel-L2 <= 1e-4 in fp32; gradients are held to the same.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_l2
+from oracle import ico_ref, loss_ref, models_ref
+
+TOL = 1e-4
+CONV = sorted(glob.glob(os.path.join(GOLDEN, 'conv_*.npz')))
+UP = sorted(glob.glob(os.path.join(GOLDEN, 'up_*.npz')))
+
+
+def T(a, dev='cpu', grad=False):
+    return torch.from_numpy(np.asarray(a)).to(dev).requires_grad_(grad)
+
+
+def test_fixtures_present():
+    assert len(CONV) == 5 and len(UP) == 3 and os.path.exists(os.path.join(GOLDEN, 'ico2ico_I5_b4.npz'))
+
+
+@pytest.mark.parametrize('path', CONV, ids=os.path.basename)
+def test_oracle_reproduces_conv_golden(path):
+    g = np.load(path)
+    r, stride = int(g['cfg'][0]), int(g['cfg'][1])
+    x, w, b = T(g['x'], grad=True), T(g['w'], grad=True), T(g['b'], grad=True)
+    y = ico_ref.ico_conv(x, w, b, r, stride, str(g['mode']))
+    y.backward(T(g['gy']))
+    for got, key in ((y, 'y'), (x.grad, 'dx'), (w.grad, 'dw'), (b.grad, 'db')):
+        assert rel_l2(got.detach().numpy(), g[key]) < 1e-6, key
+
+
+@pytest.mark.parametrize('path', UP, ids=os.path.basename)
+def test_oracle_reproduces_upsample_golden(path):
+    g = np.load(path)
+    x = T(g['x'], grad=True)
+    y = ico_ref.ico_upsample(x, int(g['cfg'][0]), str(g['mode']))
+    y.backward(T(g['gy']))
+    assert rel_l2(y.detach().numpy(), g['y']) < 1e-6 and rel_l2(x.grad.numpy(), g['dx']) < 1e-6
+
+
+def test_oracle_reproduces_model_golden():
+    """BASELINE config 1: ico2ico forward + loss on 4 synthetic I5 samples, CPU path."""
+    g = np.load(os.path.join(GOLDEN, 'ico2ico_I5_b4.npz'))
+    tgt = g['target']
+    x = T(tgt[:, :3, :-2].reshape(4, 3, 160, 64).copy())
+    torch.manual_seed(int(g['model_seed']))
+    model = models_ref.ico2ico(R=5).train()
+    with torch.no_grad():
+        y = model(x).numpy()
+    assert rel_l2(y, g['y']) < 1e-5
+    np.testing.assert_allclose(loss_ref.p2p_terms(y, tgt, 5), g['loss_terms'], rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', CONV, ids=os.path.basename)
+def test_hip_reproduces_conv_golden(path):
+    from geniconet_amd.ico_conv import ico_conv
+    g = np.load(path)
+    r, stride = int(g['cfg'][0]), int(g['cfg'][1])
+    x, w, b = T(g['x'], 'cuda', True), T(g['w'], 'cuda', True), T(g['b'], 'cuda', True)
+    y = ico_conv(x, w, b, r, stride, str(g['mode']))
+    y.backward(T(g['gy'], 'cuda'))
+    for got, key in ((y, 'y'), (x.grad, 'dx'), (w.grad, 'dw'), (b.grad, 'db')):
+        assert rel_l2(got.detach().cpu().numpy(), g[key]) < TOL, key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', UP, ids=os.path.basename)
+def test_hip_reproduces_upsample_golden(path):
+    from geniconet_amd.ico_conv import ico_upsample
+    g = np.load(path)
+    x = T(g['x'], 'cuda', True)
+    y = ico_upsample(x, int(g['cfg'][0]), str(g['mode']))
+    y.backward(T(g['gy'], 'cuda'))
+    assert rel_l2(y.detach().cpu().numpy(), g['y']) < TOL and rel_l2(x.grad.cpu().numpy(), g['dx']) < TOL
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_model_golden():
+    """BASELINE config 1 on the GPU: same weights (CPU-seeded), same 4 meshes, forward within 1e-4 rel-L2."""
+    from geniconet_amd import losses, models
+    g = np.load(os.path.join(GOLDEN, 'ico2ico_I5_b4.npz'))
+    tgt = g['target']
+    torch.manual_seed(int(g['model_seed']))
+    ref = models_ref.ico2ico(R=5)                                 # re-creates the golden's weights
+    net = models.ico2ico(models.default_params('ico2ico'))
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.cuda().train()
+    x = T(tgt[:, :3, :-2].reshape(4, 3, 160, 64).copy(), 'cuda')
+    with torch.no_grad():
+        y = net(x)
+    assert rel_l2(y.cpu().numpy(), g['y']) < TOL
+    crit = losses.P2P_Loss(5, 1., 0., 0.).cuda()
+    crit(y, T(tgt, 'cuda'))
+    mse, cos, lap, _, _ = crit.get_last_losses()
+    np.testing.assert_allclose([mse, cos, lap], g['loss_terms'], rtol=2e-3)

@@ -1,0 +1,203 @@
+"""GPU parity proper: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): forward output within 1e-4 rel-L2 of the CPU path, fp32.  Gradients of single
+operators are held to the same 1e-4; whole-network gradients (13 convs + 19 batch-norms deep) to 2e-3.
+Full-size cases (I5 / batch 36, I6 / batch 8) use size-independent properties instead of the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import ico_ref, models_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def conv_both(r, stride, cin, cout, B, mode, seed, bias=True):
+    from geniconet_amd.ico_conv import ico_conv
+    g = torch.Generator().manual_seed(seed)
+    n = 2 ** r
+    x = torch.randn(B, cin, 5 * n, 2 * n, generator=g)
+    w = torch.randn(cout, cin, 7, generator=g) / (7 * cin) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    yr = ico_ref.ico_conv(xr, wr, br, r, stride, mode)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg, wg = x.cuda().requires_grad_(), w.cuda().requires_grad_()
+    bg = b.cuda().requires_grad_() if bias else None
+    yg = ico_conv(xg, wg, bg, r, stride, mode)
+    yg.backward(gy.cuda())
+    out = {'y': (yg, yr), 'dx': (xg.grad, xr.grad), 'dw': (wg.grad, wr.grad)}
+    if bias:
+        out['db'] = (bg.grad, br.grad)
+    return out
+
+
+# MFMA tiles: 128x128, 128x64, 64x64 forward; bwd-data swaps the roles; wgrad 128/64 in both dims
+MFMA_CASES = [
+    (2, 1, 64, 64, 2, 'average'), (3, 1, 64, 128, 3, 'average'), (3, 2, 128, 256, 2, 'average'),
+    (4, 1, 128, 64, 2, 'average'), (2, 2, 256, 256, 3, 'average'), (3, 1, 256, 128, 2, 'zeros'),
+    (4, 2, 64, 128, 1, 'zeros'), (2, 1, 96, 192, 2, 'average'), (1, 1, 64, 64, 1, 'average'),
+    (5, 1, 128, 128, 1, 'average'),
+]
+SCALAR_CASES = [
+    (2, 1, 3, 64, 2, 'average'), (1, 1, 5, 7, 2, 'average'), (2, 2, 3, 8, 2, 'zeros'), (0, 1, 4, 4, 2, 'average'),
+    (3, 1, 3, 64, 2, 'zeros'), (2, 1, 64, 3, 2, 'average'), (1, 2, 33, 65, 1, 'average'),
+]
+
+
+@pytest.mark.parametrize('case', MFMA_CASES + SCALAR_CASES, ids=lambda c: 'r%d_s%d_%dx%d_b%d_%s' % c)
+def test_conv_forward_backward(case):
+    for k, (got, want) in conv_both(*case, seed=11).items():
+        assert got.shape == want.shape, k
+        assert rel_l2(got.detach().cpu().numpy(), want.detach().numpy()) < TOL, k
+
+
+def test_conv_without_bias_and_noncontiguous_input():
+    from geniconet_amd.ico_conv import ico_conv
+    for k, (got, want) in conv_both(2, 1, 64, 64, 2, 'average', seed=5, bias=False).items():
+        assert rel_l2(got.detach().cpu().numpy(), want.detach().numpy()) < TOL, k
+    x = torch.randn(2, 64, 20, 8)
+    w = torch.randn(64, 64, 7) / 21
+    want = ico_ref.ico_conv(x, w, None, 2, 1, 'average')
+    for xg in (x.cuda(), x.cuda().to(memory_format=torch.channels_last), x.cuda().transpose(2, 3).contiguous().transpose(2, 3)):
+        assert rel_l2(ico_conv(xg, w.cuda(), None, 2, 1, 'average').cpu().numpy(), want.numpy()) < TOL
+
+
+def test_argument_errors_on_gpu():
+    from geniconet_amd.ico_conv import ico_conv, ico_upsample
+    x = torch.zeros(1, 4, 20, 8, device='cuda')
+    with pytest.raises(ValueError, match='expected'):
+        ico_conv(x, torch.zeros(4, 4, 7, device='cuda'), None, 3, 1, 'average')
+    with pytest.raises(ValueError, match='weight'):
+        ico_conv(x, torch.zeros(4, 5, 7, device='cuda'), None, 2, 1, 'average')
+    with pytest.raises(TypeError):
+        ico_upsample(x.double(), 2, 'average')
+
+
+@pytest.mark.parametrize('r,C,B,mode', [(0, 4, 2, 'average'), (2, 64, 3, 'average'), (3, 5, 2, 'zeros'), (4, 128, 2, 'average'), (1, 7, 1, 'zeros')])
+def test_upsample_forward_backward(r, C, B, mode):
+    from geniconet_amd.ico_conv import ico_upsample
+    g = torch.Generator().manual_seed(3)
+    n = 2 ** r
+    x = torch.randn(B, C, 5 * n, 2 * n, generator=g)
+    xr = x.clone().requires_grad_()
+    yr = ico_ref.ico_upsample(xr, r, mode)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg = x.cuda().requires_grad_()
+    yg = ico_upsample(xg, r, mode)
+    yg.backward(gy.cuda())
+    assert rel_l2(yg.detach().cpu().numpy(), yr.detach().numpy()) < 1e-6
+    assert rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-6
+
+
+def _load_into_product(ref, name, R):
+    from geniconet_amd import models
+    net = getattr(models, name)(models.default_params(name, subdivisions=R))
+    net.load_state_dict(ref.state_dict(), strict=True)
+    return net.cuda()
+
+
+@pytest.mark.parametrize('R,B', [(3, 3), (4, 2)])
+def test_autoencoder_forward_and_gradients(R, B):
+    """Whole ico2ico network, train-mode BatchNorm (batch statistics), vs the oracle network with the same weights."""
+    torch.manual_seed(R)
+    ref = models_ref.ico2ico(R=R).train()
+    net = _load_into_product(ref, 'ico2ico', R).train()
+    n = 2 ** R
+    x = torch.rand(B, 3, 5 * n, 2 * n) * 1.6 - 0.8
+    tgt = torch.rand(B, 3, 5 * n, 2 * n) * 1.6 - 0.8
+    yr = ref(x)
+    ((yr - tgt) ** 2).mean().backward()
+    yg = net(x.cuda())
+    ((yg - tgt.cuda()) ** 2).mean().backward()
+    assert rel_l2(yg.detach().cpu().numpy(), yr.detach().numpy()) < TOL
+    gr = dict(ref.named_parameters())
+    worst = max(rel_l2(p.grad.cpu().numpy(), gr[k].grad.numpy()) for k, p in net.named_parameters())
+    assert worst < 2e-3, worst
+    # BatchNorm running statistics were updated identically
+    sr = ref.state_dict()
+    for k, v in net.state_dict().items():
+        if 'running' in k:
+            assert rel_l2(v.cpu().numpy(), sr[k].numpy()) < 1e-4, k
+
+
+def test_vae_encode_decode():
+    R, B = 3, 3
+    torch.manual_seed(9)
+    ref = models_ref.ico2ico_vae(R=R).train()
+    net = _load_into_product(ref, 'ico2ico_vae', R).train()
+    n = 2 ** R
+    x = torch.rand(B, 3, 5 * n, 2 * n) - 0.5
+    mu_r, lv_r = ref.encode(x)
+    mu_g, lv_g = net.encode(x.cuda())
+    assert rel_l2(mu_g.detach().cpu().numpy(), mu_r.detach().numpy()) < TOL
+    assert rel_l2(lv_g.detach().cpu().numpy(), lv_r.detach().numpy()) < TOL
+    z = torch.randn_like(mu_r)
+    assert rel_l2(net.decode(z.cuda()).detach().cpu().numpy(), ref.decode(z).detach().numpy()) < TOL
+    out, mu, lv = net(x.cuda())
+    assert out.shape == (B, 3, 5 * n, 2 * n) and mu.shape == (B, 512, 5 * n // 8, 2 * n // 8)
+
+
+# ------------------------------------------------------------------ full-size, size-independent properties
+FULL = [('I5_b36_128to64', 5, 36, 128, 64, 1), ('I5_b36_64to128_s2', 5, 36, 64, 128, 2), ('I6_b8_128to64', 6, 8, 128, 64, 1),
+        ('I5_b36_stem_3to64', 5, 36, 3, 64, 1)]
+
+
+@pytest.mark.parametrize('name,r,B,cin,cout,stride', FULL, ids=[f[0] for f in FULL])
+def test_full_size_linearity_and_chart_equivariance(name, r, B, cin, cout, stride):
+    """At BASELINE's sizes: conv(a x1 + x2) - conv(0) == a (conv(x1) - conv(0)) + (conv(x2) - conv(0)), and rolling
+    the five charts of the input rolls the charts of the output (72-degree rotation about the pole axis)."""
+    from geniconet_amd.ico_conv import ico_conv
+    g = torch.Generator(device='cuda').manual_seed(1)
+    n = 2 ** r
+    x1 = torch.randn(B, cin, 5 * n, 2 * n, device='cuda', generator=g)
+    x2 = torch.randn(B, cin, 5 * n, 2 * n, device='cuda', generator=g)
+    w = torch.randn(cout, cin, 7, device='cuda', generator=g) / (7 * cin) ** 0.5
+    b = torch.randn(cout, device='cuda', generator=g)
+    f = lambda t: ico_conv(t, w, b, r, stride, 'average')
+    y0 = f(torch.zeros_like(x1))
+    assert float((y0 - b[None, :, None, None]).abs().max()) == 0.0
+    y1, y2, y12 = f(x1), f(x2), f(1.5 * x1 + x2)
+    lin = 1.5 * (y1 - y0) + (y2 - y0) + y0
+    assert float((y12 - lin).norm() / lin.norm()) < 1e-5
+    ys = f(torch.roll(x1, n, dims=2))
+    assert float((ys - torch.roll(y1, n // stride, dims=2)).abs().max()) == 0.0   # same arithmetic, other chart
+
+
+def test_full_size_backward_is_the_adjoint():
+    """<conv(x), gy> == <x, conv^T(gy)> at I5 / batch 36 (bias-free): bwd-data is the exact transpose."""
+    from geniconet_amd.ico_conv import ico_conv, ico_upsample
+    g = torch.Generator(device='cuda').manual_seed(2)
+    for stride, cin, cout in ((1, 128, 64), (2, 64, 128)):
+        x = torch.randn(36, cin, 160, 64, device='cuda', generator=g, requires_grad=True)
+        w = torch.randn(cout, cin, 7, device='cuda', generator=g, requires_grad=True) / 30
+        y = ico_conv(x, w, None, 5, stride, 'average')
+        gy = torch.randn(y.shape, device='cuda', generator=g)
+        dx, dw = torch.autograd.grad(y, (x, w), gy)
+        lhs = float((y.double() * gy.double()).sum())
+        assert abs(lhs - float((x.double() * dx.double()).sum())) < 1e-6 * abs(lhs) + 1e-3
+        assert abs(lhs - float((w.double() * dw.double()).sum())) < 1e-5 * abs(lhs) + 1e-3   # y is linear in w too
+    x = torch.randn(36, 128, 80, 32, device='cuda', generator=g, requires_grad=True)
+    u = ico_upsample(x, 4, 'average')
+    gu = torch.randn(u.shape, device='cuda', generator=g)
+    (dx,) = torch.autograd.grad(u, x, gu)
+    lhs = float((u.double() * gu.double()).sum())
+    assert abs(lhs - float((x.double() * dx.double()).sum())) < 1e-6 * abs(lhs) + 1e-3
+
+
+def test_training_step_runs_and_decreases_loss():
+    """A few steps of the mirrored run.py loop on one small batch: loss is finite and goes down."""
+    from geniconet_amd import data, models
+    from geniconet_amd.train import Trainer
+    p = models.default_params('ico2ico', subdivisions=4)
+    p['ico2ico'].update(lr=1e-3, lr_base=1e-4, lr_max=1e-3)
+    tr = Trainer(p, 'cuda', seed=0)
+    x, t = data.synthetic_batch(4, 4, seed=1, device='cuda')
+    losses_seen = [float(tr.step(x, t)) for _ in range(8)]
+    assert all(np.isfinite(losses_seen)) and losses_seen[-1] < losses_seen[0]

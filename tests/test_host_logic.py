@@ -1,0 +1,117 @@
+"""Host-side logic of the product (no GPU): module tree, state_dict keys, parameter counts, argument checks,
+loud failure on CPU tensors, loss + data format against the numpy oracle, reference drop-in import."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from geniconet_amd import data, geometry, losses, models
+from geniconet_amd.ico_conv import IcoConvS2S, IcoUpsampleS2S
+from oracle import loss_ref, models_ref
+
+REFERENCE = '/root/reference'
+
+
+def test_parameter_counts_and_keys():
+    ae = models.ico2ico(models.default_params('ico2ico'))
+    vae = models.ico2ico_vae(models.default_params('ico2ico_vae'))
+    assert sum(p.numel() for p in ae.parameters()) == 4627715           # 7 taps per (Cin, Cout) pair
+    assert sum(p.numel() for p in vae.parameters()) == 6004739
+    keys = list(ae.state_dict())
+    for k in ('encoder.0.weight', 'encoder.1.running_mean', 'encoder.3.conv00.weight', 'encoder.3.icobn00.weight',
+              'encoder.5.conv10.bias', 'decoder.0.conv00.weight', 'decoder.2.icobn10.bias', 'enc2icoConv.0.weight'):
+        assert k in keys
+    vkeys = list(vae.state_dict())
+    for k in ('mu.0.weight', 'mu.1.running_var', 'logvar.0.bias', 'final_layer.0.weight'):
+        assert k in vkeys
+    assert ae.encoder[0].weight.shape == (64, 3, 7) and vae.mu[0].weight.shape == (512, 256, 7)
+    # the oracle's restated topology is key-compatible (parity tests load product weights into it)
+    assert list(models_ref.ico2ico().state_dict()) == keys
+    assert list(models_ref.ico2ico_vae().state_dict()) == vkeys
+    # I6 configuration (BASELINE config 5) builds from the same factories
+    ae6 = models.ico2ico(models.default_params('ico2ico', subdivisions=6))
+    assert ae6.encoder[0].subdivisions == 6 and ae6.decoder[0].upsample00.subdivisions == 3
+    assert sum(p.numel() for p in ae6.parameters()) == 4627715
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason='reference checkout only exists in the build container')
+def test_reference_models_py_drops_in_unchanged():
+    """The reference's own models.py imports `icocnn` (models.py:4-6); with this repo's icocnn package on the
+    path it builds both networks with the same state_dict layout as our mirror."""
+    sys.path.insert(0, REFERENCE)
+    try:
+        sys.modules.pop('models', None)
+        ref = importlib.import_module('models')
+        assert ref.__file__.startswith(REFERENCE)
+        for name in ('ico2ico', 'ico2ico_vae'):
+            p = models.default_params(name)
+            a, b = getattr(ref, name)(p).state_dict(), getattr(models, name)(p).state_dict()
+            assert list(a) == list(b)
+            assert all(a[k].shape == b[k].shape for k in a)
+    finally:
+        sys.path.remove(REFERENCE)
+        sys.modules.pop('models', None)
+
+
+def test_operators_reject_cpu_tensors_loudly():
+    conv = IcoConvS2S(3, 8, 1, True, 2, 'average')
+    with pytest.raises(RuntimeError, match='HIP path'):
+        conv(torch.zeros(1, 3, 20, 8))
+    with pytest.raises(RuntimeError, match='HIP path'):
+        IcoUpsampleS2S(3, 2, 'average')(torch.zeros(1, 3, 20, 8))
+
+
+def test_constructor_argument_checks():
+    with pytest.raises(ValueError):
+        IcoConvS2S(3, 8, 3, True, 2, 'average')
+    with pytest.raises(ValueError):
+        IcoConvS2S(3, 8, 2, True, 0, 'average')
+    with pytest.raises(ValueError):
+        IcoConvS2S(3, 8, 1, True, 2, 'reflect')
+    assert IcoConvS2S(3, 8, 1, False, 2).bias is None
+    import icocnn
+    assert icocnn.ico_conv.IcoConvS2S is IcoConvS2S
+    assert icocnn.utils.ico_geometry.get_ico_faces(1).shape == (80, 3)     # run.py:28,144 access pattern
+
+
+@pytest.mark.parametrize('r', [2, 3])
+def test_losses_match_numpy_oracle(r):
+    torch.manual_seed(1)
+    n, N = 2 ** r, geometry.num_vertices(r)
+    pred = torch.tanh(torch.randn(3, 3, 5 * n, 2 * n))
+    _, tgt = data.synthetic_batch(3, r, seed=7)
+    crit = losses.P2P_Loss(r, 0.6, 0.2, 0.2)
+    loss = crit(pred, tgt)
+    terms = loss_ref.p2p_terms(pred.numpy(), tgt.numpy(), r)
+    mse, cos, lap, _, total = crit.get_last_losses()
+    np.testing.assert_allclose([mse, cos, lap], terms, rtol=2e-5)
+    np.testing.assert_allclose(total, 0.6 * terms[0] + 0.2 * terms[1] + 0.2 * terms[2], rtol=2e-5)
+    assert abs(float(loss) - total) < 1e-7
+    mu, lv = torch.randn(3, 8, 5, 2), torch.randn(3, 8, 5, 2) * 0.1
+    kl = losses.P2PKLD_Loss(r, 0.6, 0.2, 0.2, 1.)
+    out = kl((pred, mu, lv), tgt)
+    np.testing.assert_allclose(float(out), total + loss_ref.kld(mu.numpy(), lv.numpy()), rtol=2e-5)
+    kl.update_factor(25, 25, 0.9)
+    assert abs(kl.get_factor() - 0.9) < 1e-12
+
+
+def test_sample_format_round_trip(tmp_path):
+    r = 2
+    x, tgt = data.synthetic_batch(2, r, seed=3)
+    assert x.shape == (2, 3, 20, 8) and tgt.shape == (2, 9, 162) and tgt.dtype == torch.float32
+    assert float(tgt[:, :3].abs().max()) <= 0.95
+    np.testing.assert_allclose(tgt[:, 3:6].norm(dim=1).numpy(), 1.0, atol=1e-5)
+    # targets agree with the numpy oracle's normals / Laplacian
+    f = geometry.get_ico_faces(r)
+    v = tgt[0, :3].T.numpy().astype(np.float64)
+    assert rel_l2(tgt[0, 3:6].T.numpy(), loss_ref.vertex_normals(v, f)) < 1e-5
+    assert rel_l2(tgt[0, 6:9].T.numpy(), loss_ref.laplacian(v, f)) < 1e-4
+    path = str(tmp_path / 'mesh.npz')
+    data.save_sample(path, tgt[0].numpy())
+    xi, lbl = data.load_sample(path, r)
+    assert np.array_equal(lbl, tgt[0].numpy()) and np.array_equal(xi, x[0].numpy())
+    assert list(np.load(path).keys()) == ['data']                          # generate.py:203 / data.py:66
