@@ -37,29 +37,51 @@ CONFIGS = {
 }
 
 
-def cpu_baseline(cfg, budget_s=25.0):
+def usable_cores():
+    """Cores this process may really use: affinity, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(cfg, budget_s=20.0):
     """The CPU restatement (oracle/) of the same training step on this host's cores: the only runnable 'reference
-    CPU path' (upstream icocnn is absent; parity unpinned).  detect_anomaly off (conservative for the GPU/CPU ratio)."""
+    CPU path' (upstream icocnn is absent; parity unpinned).  detect_anomaly off (conservative for the GPU/CPU ratio).
+    Bounded sample: the batch is sized from a 2-mesh calibration step so that the timed work is about budget_s."""
     from geniconet_amd.train import build_criterion
     from oracle import models_ref
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    cores = min(usable_cores(), int(os.environ.get('ICN_CPU_THREADS', 64)))
     torch.set_num_threads(cores)
     p = models.default_params(cfg['model'], subdivisions=cfg['R'])
-    torch.manual_seed(0)
-    net = getattr(models_ref, cfg['model'])(R=cfg['R']).train()
-    tr = Trainer(p, 'cpu', model=net, criterion=build_criterion(p, 'cpu'), channels_last=False)
-    x, t = data.synthetic_batch(cfg['batch'], cfg['R'], seed=1234)
+
+    def trainer():
+        torch.manual_seed(0)
+        net = getattr(models_ref, cfg['model'])(R=cfg['R']).train()
+        return Trainer(p, 'cpu', model=net, criterion=build_criterion(p, 'cpu'), channels_last=False)
+    tr = trainer()
+    x, t = data.synthetic_batch(2, cfg['R'], seed=1234)
+    tr.step(x, t)
     t0 = time.perf_counter()
-    tr.step(x, t)                                   # warm-up (also sizes the sample)
-    warm = time.perf_counter() - t0
-    steps = max(1, min(3, int(budget_s / max(warm, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    tr.step(x, t)
+    per_mesh = (time.perf_counter() - t0) / 2
+    batch = int(max(2, min(cfg['batch'], budget_s / 2 / max(per_mesh, 1e-4))))
+    x, t = data.synthetic_batch(batch, cfg['R'], seed=1234)
+    tr = trainer()
+    tr.step(x, t)                                   # warm-up at the sample's batch size
+    steps, t0 = 0, time.perf_counter()
+    while steps < 3 and (steps == 0 or time.perf_counter() - t0 < budget_s / 2):
         tr.step(x, t)
+        steps += 1
     dt = time.perf_counter() - t0
-    return {'value': round(cfg['batch'] * steps / dt, 3), 'unit': 'meshes/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d timed training step(s) of batch %d at I%d after 1 warm-up, torch CPU, %d threads, '
-                      'detect_anomaly off' % (steps, cfg['batch'], cfg['R'], cores)}
+    return {'value': round(batch * steps / dt, 3), 'unit': 'meshes/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed training step(s) of batch %d at I%d after 1 warm-up (batch sized for ~%ds of CPU work), '
+                      'torch CPU restatement (oracle/), %d threads, detect_anomaly off'
+                      % (steps, batch, cfg['R'], int(budget_s), cores)}
 
 
 def main():

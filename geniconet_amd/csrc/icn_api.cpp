@@ -117,16 +117,16 @@ void check_conv(const void* a, const void* b, const void* c, int B, int Cin, int
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// workspace layout of bwd-weight: [wgrad partial slabs][colsum partials]
+// workspace layout of bwd-weight: [wgrad partial slabs S x 7 x Cin x Cout][bias partials S x Cout]
 size_t wgrad_partial_bytes(int M, int Cin, int Cout) {
-    const int S = icn::wgrad_supported(Cin, Cout) ? icn::wgrad_splits(M, Cin, Cout) : icn::wgrad_generic_splits(M);
-    return align256((size_t)S * 7 * Cin * Cout * sizeof(float));
+    return align256((size_t)icn::wgrad_splits(M, Cin, Cout) * 7 * Cin * Cout * sizeof(float));
 }
 
 }  // namespace
 
 namespace icn {
-const char* const PROF_NAMES[PROF_KINDS] = {"k_gather_gemm<128,128>", "k_gather_gemm<128,64>", "k_gather_gemm<64,64>",
+const char* const PROF_NAMES[PROF_KINDS] = {"k_gather_gemm<128,128>", "k_gather_gemm<128,64>", "k_gather_gemm<64,128>",
+                                            "k_gather_gemm<64,64>",
                                             "k_wgrad<128,128>", "k_wgrad<128,64>", "k_wgrad<64,128>", "k_wgrad<64,64>"};
 void prof_mark_begin(int kind, double flops, hipStream_t s) {
     if (!g_prof_on || g_prof_used >= g_prof.size()) return;
@@ -216,7 +216,7 @@ size_t icn_conv_workspace_bytes(int op, int B, int Cin, int Cout, int r_in, int 
         case ICN_OP_CONV_FWD: return icn::gather_gemm_supported(Cin, Cout) ? wbytes : 0;
         case ICN_OP_CONV_BWD_DATA: return icn::gather_gemm_supported(Cout, Cin) ? wbytes : 0;
         case ICN_OP_CONV_BWD_WEIGHT:
-            return wgrad_partial_bytes(M, Cin, Cout) + align256((size_t)icn::colsum_chunks(M) * Cout * sizeof(float));
+            return wgrad_partial_bytes(M, Cin, Cout) + align256((size_t)icn::wgrad_splits(M, Cin, Cout) * Cout * sizeof(float));
         default: return 0;
     }
 }
@@ -235,6 +235,8 @@ int icn_conv_fwd(const float* x, const float* w, const float* bias, float* y, in
             icn::GatherGemmArgs a{x, wf, bias, y, t.fwd, nullptr, nullptr, B * t.Pout, t.Pin, t.Pout, Cin, Cout, 1, t.n_in,
                                   2.0 * 7 * Cin * Cout * (double)B * t.Pout};
             icn::launch_gather_gemm_auto(a, s);
+        } else if (icn::stem_supported(Cin, Cout)) {
+            icn::launch_stem_fwd(x, w, bias, y, t.fwd, B * t.Pout, t.Pin, t.Pout, Cin, Cout, t.n_in, s);
         } else {
             icn::launch_conv_generic(x, w, bias, y, t.fwd, B, t.Pin, t.Pout, Cin, Cout, 1, t.n_in, 0, s);
         }
@@ -280,13 +282,10 @@ int icn_conv_bwd_weight(const float* x, const float* dy, float* dw, float* dbias
             throw std::invalid_argument("icn_conv_bwd_weight: workspace too small");
         const int M = B * t.Pout;
         float* partial = static_cast<float*>(ws);
-        icn::WgradArgs a{x, dy, t.fwd, partial, dw, M, t.Pin, t.Pout, Cin, Cout, t.n_in, 2.0 * 7 * Cin * Cout * (double)M};
-        if (icn::wgrad_supported(Cin, Cout)) icn::launch_wgrad(a, s);
-        else icn::launch_wgrad_generic(a, s);
-        if (dbias) {
-            float* cs = reinterpret_cast<float*>(static_cast<char*>(ws) + wgrad_partial_bytes(M, Cin, Cout));
-            icn::launch_colsum(dy, cs, dbias, M, Cout, s);
-        }
+        float* bpart = dbias ? reinterpret_cast<float*>(static_cast<char*>(ws) + wgrad_partial_bytes(M, Cin, Cout)) : nullptr;
+        icn::WgradArgs a{x, dy, t.fwd, partial, bpart, dw, dbias, M, t.Pin, t.Pout, Cin, Cout, t.n_in,
+                         2.0 * 7 * Cin * Cout * (double)M};
+        icn::launch_wgrad(a, s);
         ICN_HIP(hipGetLastError());
         return 0;
     } catch (const std::exception& e) {

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "icn_launch.h"
 
@@ -35,6 +36,17 @@ __device__ __forceinline__ f32x4 pole_mean4(const float* src, int b, int Ps, int
 #pragma unroll
     for (int c = 0; c < 5; ++c) s += ld4(src + ((size_t)b * Ps + corner_pixel(ns, k, c)) * K + ch);
     return s * 0.2f;
+}
+
+// scalar gather of one channel (pixel, pole mean or nothing)
+__device__ __forceinline__ float gather1(const float* src, int32_t code, int b, int Ps, int ns, int K, int ch) {
+    if (code >= 0) return src[((size_t)b * Ps + code) * K + ch];
+    if (code <= -2) {
+        float s = 0.f;
+        for (int c = 0; c < 5; ++c) s += src[((size_t)b * Ps + corner_pixel(ns, -2 - code, c)) * K + ch];
+        return s * 0.2f;
+    }
+    return 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(
     const int32_t* __restrict__ idx,    // [7][E][Pd]
     const int32_t* __restrict__ perm,   // [Pd] row -> dst pixel, or null (identity)
     const uint8_t* __restrict__ mask32, // [Pd/32] taps in use per 32 rows, or null (all)
-    int M, int Ps, int Pd, int K, int N, int E, int ns) {
+    int M, int Ps, int Pd, int K, int N, int E, int ns, int dbg) {
     constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (waves are 2 x 2)
     constexpr int RA = BM / 32, RB = BN / 32;      // 16-byte chunks each thread stages per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,6 +163,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(
         return t;
     };
     auto stage_load = [&](int t, int kc) {
+        if (dbg & 1) return;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int32_t code = s_code[(t * E) * BM + srow + 32 * i];
@@ -161,6 +174,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(
             rb[i] = ld4(wt + ((size_t)t * N + n0 + srow + 32 * i) * K + kc + 4 * chunk);
     };
     auto stage_write = [&](int buf, int t, int kc) {
+        if (dbg & 2) return;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int row = srow + 32 * i;
@@ -241,6 +255,12 @@ __global__ __launch_bounds__(256) void k_gather_gemm(
     }
 }
 
+static int dbg_flags() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ICN_DEBUG"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 template <int BM, int BN>
 static void launch_gather_gemm(const GatherGemmArgs& a, hipStream_t s) {
     const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
@@ -251,25 +271,52 @@ static void launch_gather_gemm(const GatherGemmArgs& a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    prof_mark_begin(BM == 64 ? PROF_GG_64x64 : (BN == 128 ? PROF_GG_128x128 : PROF_GG_128x64), a.algo_flops, s);
+    prof_mark_begin(BM == 64 ? (BN == 128 ? PROF_GG_64x128 : PROF_GG_64x64) : (BN == 128 ? PROF_GG_128x128 : PROF_GG_128x64),
+                    a.algo_flops, s);
     hipLaunchKernelGGL((k_gather_gemm<BM, BN>), dim3(ntiles), dim3(256), lds, s, a.src, a.wt, a.bias, a.dst, a.idx,
-                       a.perm, a.mask32, a.M, a.Ps, a.Pd, a.K, a.N, a.E, a.ns);
+                       a.perm, a.mask32, a.M, a.Ps, a.Pd, a.K, a.N, a.E, a.ns, dbg_flags());
     prof_mark_end(s);
 }
 
 bool gather_gemm_supported(int K, int N) { return K % BK == 0 && N % 64 == 0 && K >= BK; }
 
+// Tile choice.  All co-resident blocks of a CU share its 4 MFMA pipes, so a launch takes about
+//   rounds * occ * BM * BN / eff,   rounds = ceil(tiles / (256 CUs * occ)),
+// where occ = blocks resident per CU (LDS / register bound) and eff = relative MFMA efficiency of the tile
+// shape.  The last, partly filled round costs as much as a full one (the dispatcher packs the leftover blocks
+// `occ` to a CU), so the tile count should land just below a multiple of 256 * occ.
+struct TileCfg { int bm, bn, occ; double eff; };
+static const TileCfg kTiles[] = {{128, 128, 2, 1.00}, {128, 64, 3, 0.96}, {64, 128, 3, 0.96}, {64, 64, 4, 0.88}};
+
+static int pick_tile(int M, int N, int E) {
+    int best = -1;
+    double best_cost = 0;
+    for (int i = 0; i < 4; ++i) {
+        const TileCfg& c = kTiles[i];
+        if (N % c.bn != 0) continue;
+        int occ = c.occ;
+        if (E > 1 && c.bm == 128 && c.bn != 128) occ = 2;   // the transposed tables' code array costs LDS
+        const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
+        const long slots = 256L * occ;
+        const long rounds = (tiles + slots - 1) / slots;
+        const double cost = (double)rounds * occ * c.bm * c.bn / c.eff;
+        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+    }
+    return best;
+}
+
 void launch_gather_gemm_auto(const GatherGemmArgs& a, hipStream_t s) {
-    // tile choice: fill 256 CUs; prefer the biggest tile that still yields >= ~2 blocks per CU
-    const long t128 = (long)((a.M + 127) / 128) * (a.N / 128);
-    if (a.N % 128 == 0 && t128 >= 512) return launch_gather_gemm<128, 128>(a, s);
-    const long t12864 = (long)((a.M + 127) / 128) * (a.N / 64);
-    if (t12864 >= 384) return launch_gather_gemm<128, 64>(a, s);
-    return launch_gather_gemm<64, 64>(a, s);
+    switch (pick_tile(a.M, a.N, a.E)) {
+        case 0: return launch_gather_gemm<128, 128>(a, s);
+        case 1: return launch_gather_gemm<128, 64>(a, s);
+        case 2: return launch_gather_gemm<64, 128>(a, s);
+        default: return launch_gather_gemm<64, 64>(a, s);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // weight gradient:  partial[s][t][ci][co] = sum_{m in split s} x[gather_t(m)][ci] * dy[m][co]
+//                   bias_partial[s][co]   = sum_{m in split s} dy[m][co]          (blocks with t == 0, ci0 == 0)
 // ---------------------------------------------------------------------------------------------------------
 template <int BI, int BJ>
 __global__ __launch_bounds__(256) void k_wgrad(
@@ -277,6 +324,7 @@ __global__ __launch_bounds__(256) void k_wgrad(
     const float* __restrict__ dy,       // (B, Pd, Cout)
     const int32_t* __restrict__ idx,    // forward table [7][Pd]
     float* __restrict__ partial,        // [S][7][Cin][Cout]
+    float* __restrict__ bias_partial,   // [S][Cout] or null
     int M, int Ps, int Pd, int Cin, int Cout, int ns, int rows_per_split) {
     constexpr int TI = BI / 64, TJ = BJ / 64;
     constexpr int CI = BI / 4, CJ = BJ / 4;             // 16-byte chunks per row
@@ -293,6 +341,8 @@ __global__ __launch_bounds__(256) void k_wgrad(
     const int t = blockIdx.y, split = blockIdx.z;
     const int m_begin = split * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
+    const bool do_bias = bias_partial != nullptr && t == 0 && ci0 == 0;   // block-uniform
+    float bsum = 0.f;
 
     f32x16 acc[TI][TJ];
 #pragma unroll
@@ -363,6 +413,10 @@ __global__ __launch_bounds__(256) void k_wgrad(
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (do_bias && tid < BJ) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) bsum += Ys[buf * 32 * BJ + k * BJ + tid];
+        }
         if (more) stage_write(buf ^ 1);
         __syncthreads();
     }
@@ -378,81 +432,208 @@ __global__ __launch_bounds__(256) void k_wgrad(
                 const int co = co0 + wc * (BJ / 2) + j * 32 + l31;
                 out[(size_t)ci * Cout + co] = acc[i][j][r];
             }
+    if (do_bias && tid < BJ) bias_partial[(size_t)split * Cout + co0 + tid] = bsum;
 }
 
-// dw[co][ci][t] = sum_s partial[s][t][ci][co]
-__global__ void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, int S, int Cin, int Cout) {
+// dw[co][ci][t] = sum_s partial[s][t][ci][co];   dbias[co] = sum_s bias_partial[s][co]
+__global__ void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
+                               const float* __restrict__ bias_partial, float* __restrict__ dbias, int S, int Cin, int Cout) {
     const int total = 7 * Cin * Cout;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int total2 = total + (dbias ? Cout : 0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < S; ++k) s += partial[(size_t)k * total + i];
-        const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cin * Cout);
-        dw[((size_t)co * Cin + ci) * 7 + t] = s;
+        if (i < total) {
+            for (int k = 0; k < S; ++k) s += partial[(size_t)k * total + i];
+            const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cin * Cout);
+            dw[((size_t)co * Cin + ci) * 7 + t] = s;
+        } else {
+            const int c = i - total;
+            for (int k = 0; k < S; ++k) s += bias_partial[(size_t)k * Cout + c];
+            dbias[c] = s;
+        }
     }
+}
+
+// partial[chunk][t][ci][co] (+ bias_partial[chunk][co]) over row chunks, any Cin / Cout
+__global__ void k_wgrad_generic(const float* __restrict__ x, const float* __restrict__ dy, const int32_t* __restrict__ idx,
+                                float* __restrict__ partial, float* __restrict__ bias_partial, int M, int Ps, int Pd, int Cin,
+                                int Cout, int ns, int rows_per_split) {
+    const int total = 7 * Cin * Cout;
+    const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cin * Cout);
+        const bool do_bias = bias_partial != nullptr && t == 0 && ci == 0;
+        float s = 0.f, sb = 0.f;
+        for (int m = m0; m < m1; ++m) {
+            const int b = m / Pd, p = m % Pd;
+            const float dyv = dy[(size_t)m * Cout + co];
+            if (do_bias) sb += dyv;
+            const int32_t code = idx[(size_t)t * Pd + p];
+            if (code == -1) continue;
+            s += gather1(x, code, b, Ps, ns, Cin, ci) * dyv;
+        }
+        partial[(size_t)blockIdx.y * total + i] = s;
+        if (do_bias) bias_partial[(size_t)blockIdx.y * Cout + co] = sb;
+    }
+}
+
+// ---- stem (Cin <= 4, e.g. the 3->64 first layer): HBM-bound, VALU ---------------------------------------
+// Both stem kernels stage the gathered 7*CIN input values of a group of 64 pixels in LDS first (all 256 threads
+// issue independent gathers), then stream the wide side (y or dy, Cout floats per pixel) with coalesced accesses.
+constexpr int STEM_PIX = 64;
+
+template <int CIN>
+__device__ __forceinline__ void stem_gather(const float* __restrict__ x, const int32_t* __restrict__ idx, float* xs, int m0,
+                                            int M, int Ps, int Pd, int ns) {
+    for (int i = threadIdx.x; i < STEM_PIX * 7; i += 256) {
+        const int row = i / 7, t = i % 7, m = m0 + row;
+        float v[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) v[ci] = 0.f;
+        if (m < M) {
+            const int b = m / Pd, p = m % Pd;
+            const int32_t code = idx[(size_t)t * Pd + p];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) v[ci] = gather1(x, code, b, Ps, ns, CIN, ci);
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) xs[row * (7 * CIN) + t * CIN + ci] = v[ci];
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ y,
+                                                   const int32_t* __restrict__ idx, int M, int Ps, int Pd, int Cout, int ns) {
+    constexpr int KT = 7 * CIN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* w_s = reinterpret_cast<float*>(smem);       // [KT][Cout]
+    float* b_s = w_s + KT * Cout;                      // [Cout]
+    float* xs = b_s + Cout;                            // [STEM_PIX][KT]
+    for (int i = threadIdx.x; i < KT * Cout; i += 256) {
+        const int co = i % Cout, k = i / Cout, ci = k % CIN, t = k / CIN;
+        w_s[i] = w[((size_t)co * CIN + ci) * 7 + t];
+    }
+    for (int i = threadIdx.x; i < Cout; i += 256) b_s[i] = bias ? bias[i] : 0.f;
+    const int q = Cout / 4;                            // float4 column groups per pixel
+    for (int m0 = blockIdx.x * STEM_PIX; m0 < M; m0 += gridDim.x * STEM_PIX) {
+        __syncthreads();                               // previous xs consumed (and w_s ready on the first pass)
+        stem_gather<CIN>(x, idx, xs, m0, M, Ps, Pd, ns);
+        __syncthreads();
+        for (int i = threadIdx.x; i < STEM_PIX * q; i += 256) {
+            const int row = i / q, c4 = (i % q) * 4, m = m0 + row;
+            if (m >= M) continue;
+            f32x4 acc = *reinterpret_cast<const f32x4*>(b_s + c4);
+#pragma unroll
+            for (int k = 0; k < KT; ++k) acc += xs[row * KT + k] * *reinterpret_cast<const f32x4*>(w_s + k * Cout + c4);
+            *reinterpret_cast<f32x4*>(y + (size_t)m * Cout + c4) = acc;
+        }
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const int32_t* __restrict__ idx, float* __restrict__ partial,
+                                                     float* __restrict__ bias_partial, int M, int Ps, int Pd, int Cout, int ns,
+                                                     int rows_per_block) {
+    constexpr int KT = 7 * CIN, NA = KT + 1;           // 7*CIN weight sums + 1 bias sum
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);        // [STEM_PIX][KT]
+    float* red = xs + STEM_PIX * KT;                   // [G][NA][Cout]
+    const int G = 256 / Cout, g = threadIdx.x / Cout, co = threadIdx.x % Cout;
+    const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
+    float acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+    for (int m0 = mb; m0 < me; m0 += STEM_PIX) {
+        __syncthreads();
+        stem_gather<CIN>(x, idx, xs, m0, me, Ps, Pd, ns);
+        __syncthreads();
+        const int nrow = min(STEM_PIX, me - m0);
+        for (int row = g; row < nrow; row += G) {
+            const float dyv = dy[(size_t)(m0 + row) * Cout + co];
+            acc[KT] += dyv;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) acc[k] += dyv * xs[row * KT + k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) red[(g * NA + i) * Cout + co] = acc[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < NA * Cout; i += 256) {
+        float s = 0.f;
+        for (int k = 0; k < G; ++k) s += red[k * NA * Cout + i];
+        const int a = i / Cout, c = i % Cout;
+        if (a < KT) partial[((size_t)blockIdx.x * KT + a) * Cout + c] = s;               // [S][t][ci][co]
+        else if (bias_partial) bias_partial[(size_t)blockIdx.x * Cout + c] = s;
+    }
+}
+
+bool stem_supported(int Cin, int Cout) { return Cin >= 1 && Cin <= 4 && Cout >= 4 && Cout <= 256 && 256 % Cout == 0; }
+
+void launch_stem_fwd(const float* x, const float* w, const float* bias, float* y, const int32_t* idx, int M, int Ps, int Pd,
+                     int Cin, int Cout, int ns, hipStream_t s) {
+    const int blocks = std::min(4096, (M + STEM_PIX - 1) / STEM_PIX);
+    const size_t lds = ((size_t)(7 * Cin + 1) * Cout + (size_t)STEM_PIX * 7 * Cin) * 4;
+#define ICN_SF(C) hipLaunchKernelGGL((k_stem_fwd<C>), dim3(blocks), dim3(256), lds, s, x, w, bias, y, idx, M, Ps, Pd, Cout, ns)
+    switch (Cin) { case 1: ICN_SF(1); break; case 2: ICN_SF(2); break; case 3: ICN_SF(3); break; default: ICN_SF(4); }
+#undef ICN_SF
 }
 
 bool wgrad_supported(int Cin, int Cout) { return Cin % 64 == 0 && Cout % 64 == 0; }
 
+// number of row splits (= partial slabs) each wgrad flavour uses; shared by the workspace query and the launch
 int wgrad_splits(int M, int Cin, int Cout) {
-    const int bi = (Cin % 128 == 0) ? 128 : 64, bj = (Cout % 128 == 0) ? 128 : 64;
-    const long tiles = 7L * (Cin / bi) * (Cout / bj);
-    long s = (1024 + tiles - 1) / tiles;                   // ~4 blocks per CU in flight
-    const long max_s = (M + 255) / 256;                    // >= 8 stages of 32 rows per block
-    if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
-    return (int)s;
+    if (wgrad_supported(Cin, Cout)) {
+        const int bi = (Cin % 128 == 0) ? 128 : 64, bj = (Cout % 128 == 0) ? 128 : 64;
+        const long tiles = 7L * (Cin / bi) * (Cout / bj);
+        long s = (1024 + tiles - 1) / tiles;                   // ~4 blocks per CU in flight
+        const long max_s = (M + 255) / 256;                    // >= 8 stages of 32 rows per block
+        if (s > max_s) s = max_s;
+        return (int)(s < 1 ? 1 : s);
+    }
+    if (stem_supported(Cin, Cout)) return std::min(2048, (M + 255) / 256);
+    return std::min(512, (M + 127) / 128);
 }
 
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
     const int S = wgrad_splits(a.M, a.Cin, a.Cout);
-    int rows = (a.M + S - 1) / S;
-    rows = (rows + 31) / 32 * 32;
-    const bool bi128 = a.Cin % 128 == 0, bj128 = a.Cout % 128 == 0;
-    const int BI = bi128 ? 128 : 64, BJ = bj128 ? 128 : 64;
-    dim3 grid((a.Cin / BI) * (a.Cout / BJ), 7, S);
-    const size_t lds = (size_t)2 * 32 * (BI + BJ) * 4;
-#define ICN_WG(I, J)                                                                                              \
-    hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.M, a.Ps, a.Pd, a.Cin, \
-                       a.Cout, a.ns, rows)
-    prof_mark_begin(bi128 ? (bj128 ? PROF_WG_128x128 : PROF_WG_128x64) : (bj128 ? PROF_WG_64x128 : PROF_WG_64x64),
-                    a.algo_flops, s);
-    if (bi128 && bj128) ICN_WG(128, 128);
-    else if (bi128) ICN_WG(128, 64);
-    else if (bj128) ICN_WG(64, 128);
-    else ICN_WG(64, 64);
-    prof_mark_end(s);
+    if (wgrad_supported(a.Cin, a.Cout)) {
+        int rows = (a.M + S - 1) / S;
+        rows = (rows + 31) / 32 * 32;
+        const bool bi128 = a.Cin % 128 == 0, bj128 = a.Cout % 128 == 0;
+        const int BI = bi128 ? 128 : 64, BJ = bj128 ? 128 : 64;
+        dim3 grid((a.Cin / BI) * (a.Cout / BJ), 7, S);
+        const size_t lds = (size_t)2 * 32 * (BI + BJ) * 4;
+#define ICN_WG(I, J)                                                                                                   \
+    hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M, a.Ps, \
+                       a.Pd, a.Cin, a.Cout, a.ns, rows)
+        prof_mark_begin(bi128 ? (bj128 ? PROF_WG_128x128 : PROF_WG_128x64) : (bj128 ? PROF_WG_64x128 : PROF_WG_64x64),
+                        a.algo_flops, s);
+        if (bi128 && bj128) ICN_WG(128, 128);
+        else if (bi128) ICN_WG(128, 64);
+        else if (bj128) ICN_WG(64, 128);
+        else ICN_WG(64, 64);
+        prof_mark_end(s);
 #undef ICN_WG
-    const int total = 7 * a.Cin * a.Cout;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, s, a.partial, a.dw, S, a.Cin, a.Cout);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// column sums (bias gradient): partial[chunk][C] then reduce
-// ---------------------------------------------------------------------------------------------------------
-__global__ void k_colsum_partial(const float* __restrict__ dy, float* __restrict__ partial, int M, int C, int rows_per_block) {
-    const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s = 0.f;
-        for (int m = m0; m < m1; ++m) s += dy[(size_t)m * C + c];
-        partial[(size_t)blockIdx.x * C + c] = s;
+    } else if (stem_supported(a.Cin, a.Cout)) {
+        const int rows = (a.M + S - 1) / S;
+        const size_t lds = ((size_t)STEM_PIX * 7 * a.Cin + (size_t)(256 / a.Cout) * (7 * a.Cin + 1) * a.Cout) * 4;
+#define ICN_SW(C)                                                                                                    \
+    hipLaunchKernelGGL((k_stem_wgrad<C>), dim3(S), dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M, \
+                       a.Ps, a.Pd, a.Cout, a.ns, rows)
+        switch (a.Cin) { case 1: ICN_SW(1); break; case 2: ICN_SW(2); break; case 3: ICN_SW(3); break; default: ICN_SW(4); }
+#undef ICN_SW
+    } else {
+        const int rows = (a.M + S - 1) / S;
+        const int total = 7 * a.Cin * a.Cout;
+        dim3 grid(std::min(64, (total + 255) / 256), S);
+        hipLaunchKernelGGL(k_wgrad_generic, grid, dim3(256), 0, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M, a.Ps,
+                           a.Pd, a.Cin, a.Cout, a.ns, rows);
     }
-}
-__global__ void k_reduce_rows(const float* __restrict__ partial, float* __restrict__ out, int S, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += partial[(size_t)k * C + c];
-    out[c] = s;
-}
-
-int colsum_chunks(int M) { return std::min(1024, (M + 63) / 64); }
-
-void launch_colsum(const float* dy, float* partial, float* out, int M, int C, hipStream_t s) {
-    const int chunks = colsum_chunks(M);
-    const int rows = (M + chunks - 1) / chunks;
-    hipLaunchKernelGGL(k_colsum_partial, dim3(chunks), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)), 0, s, dy, partial, M,
-                       C, rows);
-    hipLaunchKernelGGL(k_reduce_rows, dim3((C + 63) / 64), dim3(64), 0, s, partial, out, chunks, C);
+    const int total = 7 * a.Cin * a.Cout + a.Cout;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, s, a.partial, a.dw, a.bias_partial, a.dbias,
+                       S, a.Cin, a.Cout);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -503,16 +684,6 @@ void launch_spmm_ell(const float* in, float* out, const int32_t* idx, const floa
 // ---------------------------------------------------------------------------------------------------------
 // scalar fall-backs (any Cin / Cout)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gather1(const float* src, int32_t code, int b, int Ps, int ns, int K, int ch) {
-    if (code >= 0) return src[((size_t)b * Ps + code) * K + ch];
-    if (code <= -2) {
-        float s = 0.f;
-        for (int c = 0; c < 5; ++c) s += src[((size_t)b * Ps + corner_pixel(ns, -2 - code, c)) * K + ch];
-        return s * 0.2f;
-    }
-    return 0.f;
-}
-
 // dst[b,p,n] = bias[n] + sum_t sum_e sum_k gather(src, idx[t][e][p])[k] * w(n,k,t)
 // w is the parameter tensor [Cout][Cin][7]; transpose = 0: n = co, k = ci (forward); 1: n = ci, k = co (bwd-data)
 __global__ void k_conv_generic(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias,
@@ -543,37 +714,6 @@ void launch_conv_generic(const float* src, const float* w, const float* bias, fl
     const int blocks = (int)std::min((size_t)16384, (total + 255) / 256);
     hipLaunchKernelGGL(k_conv_generic, dim3(blocks), dim3(256), 0, s, src, w, bias, dst, idx, B, Ps, Pd, K, N, E, ns,
                        transpose);
-}
-
-// partial[chunk][t][ci][co] over row chunks; reduced by k_wgrad_reduce
-__global__ void k_wgrad_generic(const float* __restrict__ x, const float* __restrict__ dy, const int32_t* __restrict__ idx,
-                                float* __restrict__ partial, int M, int Ps, int Pd, int Cin, int Cout, int ns,
-                                int rows_per_split) {
-    const int total = 7 * Cin * Cout;
-    const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cin * Cout);
-        float s = 0.f;
-        for (int m = m0; m < m1; ++m) {
-            const int b = m / Pd, p = m % Pd;
-            const int32_t code = idx[(size_t)t * Pd + p];
-            if (code == -1) continue;
-            s += gather1(x, code, b, Ps, ns, Cin, ci) * dy[(size_t)m * Cout + co];
-        }
-        partial[(size_t)blockIdx.y * total + i] = s;
-    }
-}
-
-int wgrad_generic_splits(int M) { return std::min(512, (M + 127) / 128); }
-
-void launch_wgrad_generic(const WgradArgs& a, hipStream_t s) {
-    const int S = wgrad_generic_splits(a.M);
-    const int rows = (a.M + S - 1) / S;
-    const int total = 7 * a.Cin * a.Cout;
-    dim3 grid(std::min(64, (total + 255) / 256), S);
-    hipLaunchKernelGGL(k_wgrad_generic, grid, dim3(256), 0, s, a.x, a.dy, a.idx, a.partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout,
-                       a.ns, rows);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, s, a.partial, a.dw, S, a.Cin, a.Cout);
 }
 
 void launch_pack_weights(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t s) {

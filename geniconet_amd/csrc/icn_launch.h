@@ -22,7 +22,9 @@ struct WgradArgs {
     const float* dy;        // (B, Pd, Cout)
     const int32_t* idx;     // forward table [7][Pd]
     float* partial;         // [S][7][Cin][Cout]
+    float* bias_partial;    // [S][Cout] (null when dbias is null)
     float* dw;              // [Cout][Cin][7]
+    float* dbias;           // [Cout] or null
     int M, Ps, Pd, Cin, Cout, ns;
     double algo_flops;
 };
@@ -33,11 +35,9 @@ void launch_gather_gemm_auto(const GatherGemmArgs& a, hipStream_t s);
 bool wgrad_supported(int Cin, int Cout);
 int wgrad_splits(int M, int Cin, int Cout);
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
-int wgrad_generic_splits(int M);
-void launch_wgrad_generic(const WgradArgs& a, hipStream_t s);
-
-int colsum_chunks(int M);
-void launch_colsum(const float* dy, float* partial, float* out, int M, int C, hipStream_t s);
+bool stem_supported(int Cin, int Cout);
+void launch_stem_fwd(const float* x, const float* w, const float* bias, float* y, const int32_t* idx, int M, int Ps, int Pd,
+                     int Cin, int Cout, int ns, hipStream_t s);
 
 void launch_spmm_ell(const float* in, float* out, const int32_t* idx, const float* coef, int B, int Pin, int Pout, int C,
                      int W, hipStream_t s);
@@ -48,7 +48,7 @@ void launch_conv_generic(const float* src, const float* w, const float* bias, fl
 void launch_pack_weights(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t s);
 
 // ---- optional per-launch HIP-event timing of the MFMA kernels (bench.py's live roofline measurement) ----------
-enum ProfKind { PROF_GG_128x128 = 0, PROF_GG_128x64, PROF_GG_64x64, PROF_WG_128x128, PROF_WG_128x64, PROF_WG_64x128,
+enum ProfKind { PROF_GG_128x128 = 0, PROF_GG_128x64, PROF_GG_64x128, PROF_GG_64x64, PROF_WG_128x128, PROF_WG_128x64, PROF_WG_64x128,
                 PROF_WG_64x64, PROF_KINDS };
 extern const char* const PROF_NAMES[PROF_KINDS];
 void prof_mark_begin(int kind, double flops, hipStream_t s);   // no-ops unless profiling is on

@@ -25,7 +25,8 @@ def grid_to_vertices(x, subdivisions):
 
 def compute_vertex_normals(v, faces, eps=1e-10):
     """v (B, N, 3), faces (F, 3) int64 -> unit vertex normals (B, N, 3), face-area weighted (generate.py:20-43)."""
-    v0, v1, v2 = v[:, faces[:, 0]], v[:, faces[:, 1]], v[:, faces[:, 2]]
+    # index_select (backward = index_add) instead of advanced indexing (backward = sort-based scatter)
+    v0, v1, v2 = (torch.index_select(v, 1, faces[:, k]) for k in range(3))
     fn = torch.cross(v1 - v0, v2 - v0, dim=2)
     vn = torch.zeros_like(v)
     for k in range(3):
@@ -36,7 +37,7 @@ def compute_vertex_normals(v, faces, eps=1e-10):
 def compute_laplacian_batch(v, nbr_idx, nbr_w):
     """Uniform Laplacian: mean of the 1-ring minus the vertex.  nbr_idx (N, 6) int64 (padding entries point at
     vertex 0 with weight 0), nbr_w (N, 6) = 1/valence or 0."""
-    ring = v[:, nbr_idx]                       # (B, N, 6, 3)
+    ring = torch.index_select(v, 1, nbr_idx.reshape(-1)).view(v.shape[0], nbr_idx.shape[0], 6, 3)
     return (ring * nbr_w[None, :, :, None]).sum(2) - v
 
 

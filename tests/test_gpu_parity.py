@@ -117,9 +117,17 @@ def test_autoencoder_forward_and_gradients(R, B):
     yg = net(x.cuda())
     ((yg - tgt.cuda()) ** 2).mean().backward()
     assert rel_l2(yg.detach().cpu().numpy(), yr.detach().numpy()) < TOL
+    # A conv bias in front of a train-mode BatchNorm has an exactly-zero true gradient (BN removes the mean), so both
+    # sides hold rounding noise there: errors are measured against max(||g_ref||, 1e-3 * largest gradient norm).
     gr = dict(ref.named_parameters())
-    worst = max(rel_l2(p.grad.cpu().numpy(), gr[k].grad.numpy()) for k, p in net.named_parameters())
-    assert worst < 2e-3, worst
+    floor = 1e-3 * max(float(q.grad.norm()) for q in gr.values())
+    errs = {k: float((p.grad.cpu() - gr[k].grad).norm()) / max(float(gr[k].grad.norm()), floor)
+            for k, p in net.named_parameters()}
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 2e-3, (worst, errs[worst], float(gr[worst].grad.norm()), floor)
+    for k, q in gr.items():          # ... and those biases really are (numerically) zero on both sides
+        if k.endswith('.bias') and ('conv0' in k or 'conv1' in k or k == 'encoder.0.bias'):
+            assert float(q.grad.norm()) < floor and float(dict(net.named_parameters())[k].grad.norm()) < floor, k
     # BatchNorm running statistics were updated identically
     sr = ref.state_dict()
     for k, v in net.state_dict().items():
@@ -167,7 +175,10 @@ def test_full_size_linearity_and_chart_equivariance(name, r, B, cin, cout, strid
     lin = 1.5 * (y1 - y0) + (y2 - y0) + y0
     assert float((y12 - lin).norm() / lin.norm()) < 1e-5
     ys = f(torch.roll(x1, n, dims=2))
-    assert float((ys - torch.roll(y1, n // stride, dims=2)).abs().max()) == 0.0   # same arithmetic, other chart
+    # same arithmetic on another chart; only the pole mean sums its 5 corners in a rotated order (1-ulp effects)
+    d = (ys - torch.roll(y1, n // stride, dims=2)).abs()
+    assert float(d.max()) < 1e-5
+    assert int((d > 0).sum()) <= B * cout * 10 * 3
 
 
 def test_full_size_backward_is_the_adjoint():
@@ -180,15 +191,15 @@ def test_full_size_backward_is_the_adjoint():
         y = ico_conv(x, w, None, 5, stride, 'average')
         gy = torch.randn(y.shape, device='cuda', generator=g)
         dx, dw = torch.autograd.grad(y, (x, w), gy)
-        lhs = float((y.double() * gy.double()).sum())
-        assert abs(lhs - float((x.double() * dx.double()).sum())) < 1e-6 * abs(lhs) + 1e-3
-        assert abs(lhs - float((w.double() * dw.double()).sum())) < 1e-5 * abs(lhs) + 1e-3   # y is linear in w too
+        lhs = float((y.detach().double() * gy.double()).sum())
+        assert abs(lhs - float((x.detach().double() * dx.double()).sum())) < 1e-6 * abs(lhs) + 1e-3
+        assert abs(lhs - float((w.detach().double() * dw.double()).sum())) < 1e-5 * abs(lhs) + 1e-3   # y is linear in w too
     x = torch.randn(36, 128, 80, 32, device='cuda', generator=g, requires_grad=True)
     u = ico_upsample(x, 4, 'average')
     gu = torch.randn(u.shape, device='cuda', generator=g)
     (dx,) = torch.autograd.grad(u, x, gu)
-    lhs = float((u.double() * gu.double()).sum())
-    assert abs(lhs - float((x.double() * dx.double()).sum())) < 1e-6 * abs(lhs) + 1e-3
+    lhs = float((u.detach().double() * gu.double()).sum())
+    assert abs(lhs - float((x.detach().double() * dx.double()).sum())) < 1e-6 * abs(lhs) + 1e-3
 
 
 def test_training_step_runs_and_decreases_loss():
