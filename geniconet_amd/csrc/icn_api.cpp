@@ -41,6 +41,14 @@ struct ConvTables {
     int Pin = 0, Pout = 0, n_in = 0, n_out = 0, E = 1;
     int32_t* fwd = nullptr;    // [7][Pout]
     int32_t* bwd = nullptr;    // [7][E][Pin]
+    uint8_t* fwd_slow = nullptr;  // [Pout] taps of each output row that need the slow gather (pole means)
+    uint8_t* bwd_slow = nullptr;  // [Pin] same for the full transposed table (extra entries / pole means)
+    int32_t* bwd1 = nullptr;      // [7][Pin] primary (single plain pixel) entries of the transposed table
+    uint8_t* bwd1_slow = nullptr; // [Pin] all zero: the primary table has no slow rows
+    int nv = 0;                   // virtual rows: extra transposed entries, run as a second small GEMM
+    int32_t* vidx = nullptr;      // [7][nv]
+    uint8_t* vslow = nullptr;     // [nv] taps of each virtual row that are pole means
+    int32_t* vq = nullptr;        // [nv] target input pixel (sorted)
     int32_t* perm = nullptr;   // [Pin] (stride 2 only)
     uint8_t* mask32 = nullptr; // [Pin/32] (stride 2 only)
 };
@@ -72,6 +80,24 @@ const ConvTables& conv_tables(int r_in, int stride, int mode) {
     t.E = icn::build_conv_bwd(r_in, stride, mode, bwd);
     t.fwd = upload(fwd);
     t.bwd = upload(bwd);
+    std::vector<uint8_t> slow;
+    icn::build_slow_mask(fwd, 1, t.Pout, slow);
+    t.fwd_slow = upload(slow);
+    icn::build_slow_mask(bwd, t.E, t.Pin, slow);
+    t.bwd_slow = upload(slow);
+    std::vector<int32_t> primary;
+    icn::VirtualRows vr;
+    icn::split_conv_bwd(r_in, stride, bwd, t.E, primary, vr);
+    t.bwd1 = upload(primary);
+    slow.assign(t.Pin, 0);
+    t.bwd1_slow = upload(slow);
+    t.nv = vr.nv;
+    if (vr.nv > 0) {
+        t.vidx = upload(vr.vidx);
+        icn::build_slow_mask(vr.vidx, 1, vr.nv, slow);
+        t.vslow = upload(slow);
+        t.vq = upload(vr.vq);
+    }
     if (stride == 2) {
         icn::build_bwd_row_order(r_in, stride, bwd, t.E, perm, mask);
         t.perm = upload(perm);
@@ -116,6 +142,21 @@ void check_conv(const void* a, const void* b, const void* c, int B, int Cin, int
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// number of virtual rows of the stride-1 transposed gather, per (r, corner_mode); host-only, cached
+int virtual_rows(int r_in, int mode) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_pair(r_in, mode);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    std::vector<int32_t> bwd, primary;
+    icn::VirtualRows vr;
+    const int E = icn::build_conv_bwd(r_in, 1, mode, bwd);
+    icn::split_conv_bwd(r_in, 1, bwd, E, primary, vr);
+    return cache[key] = vr.nv;
+}
 
 // workspace layout of bwd-weight: [wgrad partial slabs S x 7 x Cin x Cout][bias partials S x Cout]
 size_t wgrad_partial_bytes(int M, int Cin, int Cout) {
@@ -214,7 +255,10 @@ size_t icn_conv_workspace_bytes(int op, int B, int Cin, int Cout, int r_in, int 
     const size_t wbytes = align256((size_t)7 * Cin * Cout * sizeof(float));
     switch (op) {
         case ICN_OP_CONV_FWD: return icn::gather_gemm_supported(Cin, Cout) ? wbytes : 0;
-        case ICN_OP_CONV_BWD_DATA: return icn::gather_gemm_supported(Cout, Cin) ? wbytes : 0;
+        case ICN_OP_CONV_BWD_DATA:
+            if (!icn::gather_gemm_supported(Cout, Cin)) return 0;
+            // packed weights + (stride 1) the virtual-row GEMM result (B, nv, Cin); 'average' bounds 'zeros'
+            return wbytes + (stride == 1 ? align256((size_t)B * virtual_rows(r_in, ICN_CORNER_AVERAGE) * Cin * sizeof(float)) : 0);
         case ICN_OP_CONV_BWD_WEIGHT:
             return wgrad_partial_bytes(M, Cin, Cout) + align256((size_t)icn::wgrad_splits(M, Cin, Cout) * Cout * sizeof(float));
         default: return 0;
@@ -232,7 +276,7 @@ int icn_conv_fwd(const float* x, const float* w, const float* bias, float* y, in
                 throw std::invalid_argument("icn_conv_fwd: workspace too small");
             float* wf = static_cast<float*>(ws);
             icn::launch_pack_weights(w, wf, Cout, Cin, 0, s);
-            icn::GatherGemmArgs a{x, wf, bias, y, t.fwd, nullptr, nullptr, B * t.Pout, t.Pin, t.Pout, Cin, Cout, 1, t.n_in,
+            icn::GatherGemmArgs a{x, wf, bias, y, t.fwd, t.fwd_slow, nullptr, nullptr, B * t.Pout, t.Pin, t.Pout, Cin, Cout, 1, t.n_in,
                                   2.0 * 7 * Cin * Cout * (double)B * t.Pout};
             icn::launch_gather_gemm_auto(a, s);
         } else if (icn::stem_supported(Cin, Cout)) {
@@ -259,9 +303,23 @@ int icn_conv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin
             float* wb = static_cast<float*>(ws);
             icn::launch_pack_weights(w, wb, Cout, Cin, 1, s);
             // source = dy at the output level (pole corners of THAT level), rows = input pixels
-            icn::GatherGemmArgs a{dy, wb, nullptr, dx, t.bwd, t.perm, t.mask32, B * t.Pin, t.Pout, t.Pin, Cout, Cin, t.E, t.n_out,
+            // Stride 1: the transposed gather has extra entries (duplicates / pole means) along the chart seams.
+            // Where they are few (fine levels) the main GEMM gathers only the primary entries and a second, small GEMM
+            // over "virtual rows" adds the rest; where they are many (coarse levels: 23 % of the rows at r = 3) the
+            // kernel's in-line multi-entry path is cheaper than a second launch.
+            const bool split = stride == 1 && t.nv > 0 && t.nv * 8 < t.Pin;
+            icn::GatherGemmArgs a{dy, wb, nullptr, dx, split ? t.bwd1 : t.bwd, split ? t.bwd1_slow : t.bwd_slow,
+                                  t.perm, t.mask32, B * t.Pin, t.Pout, t.Pin, Cout, Cin, split ? 1 : t.E, t.n_out,
                                   2.0 * 7 * Cin * Cout * (double)B * t.Pout};
             icn::launch_gather_gemm_auto(a, s);
+            if (split) {
+                // second, small GEMM over the virtual rows, then dx[b, vq[v], :] += result[b, v, :]
+                float* vout = reinterpret_cast<float*>(static_cast<char*>(ws) + align256((size_t)7 * Cin * Cout * sizeof(float)));
+                icn::GatherGemmArgs v{dy, wb, nullptr, vout, t.vidx, t.vslow, nullptr, nullptr, B * t.nv, t.Pout, t.nv, Cout, Cin, 1,
+                                      t.n_out, 2.0 * 7 * Cin * Cout * (double)B * t.nv};
+                icn::launch_gather_gemm_auto(v, s);
+                icn::launch_row_scatter_add(vout, dx, t.vq, B, t.nv, t.Pin, Cin, s);
+            }
         } else {
             icn::launch_conv_generic(dy, w, nullptr, dx, t.bwd, B, t.Pout, t.Pin, Cout, Cin, t.E, t.n_out, 1, s);
         }

@@ -135,6 +135,54 @@ int build_conv_bwd(int r_in, int stride, int corner_mode, std::vector<int32_t>& 
     return (int)E;
 }
 
+void split_conv_bwd(int r_in, int stride, const std::vector<int32_t>& bwd_idx, int E, std::vector<int32_t>& primary,
+                    VirtualRows& vr) {
+    const int n = 1 << r_in, Pin = 10 * n * n;
+    (void)stride;
+    primary.assign((size_t)NTAPS * Pin, IDX_ZERO);
+    std::vector<std::array<int32_t, NTAPS>> rows;        // virtual rows in creation order (sorted by q)
+    vr = VirtualRows{};
+    for (int q = 0; q < Pin; ++q) {
+        // leftover[t] = entries of (t, q) that are not the primary plain pixel
+        std::array<std::vector<int32_t>, NTAPS> leftover;
+        size_t levels = 0;
+        for (int t = 0; t < NTAPS; ++t) {
+            bool have_primary = false;
+            for (int e = 0; e < E; ++e) {
+                const int32_t v = bwd_idx[((size_t)t * E + e) * Pin + q];
+                if (v == IDX_ZERO) continue;
+                if (v >= 0 && !have_primary) {
+                    primary[(size_t)t * Pin + q] = v;
+                    have_primary = true;
+                } else {
+                    leftover[t].push_back(v);
+                }
+            }
+            levels = std::max(levels, leftover[t].size());
+        }
+        for (size_t l = 0; l < levels; ++l) {
+            std::array<int32_t, NTAPS> row;
+            for (int t = 0; t < NTAPS; ++t) row[t] = l < leftover[t].size() ? leftover[t][l] : IDX_ZERO;
+            rows.push_back(row);
+            vr.vq.push_back(q);
+        }
+    }
+    vr.nv = (int)rows.size();
+    vr.vidx.assign((size_t)NTAPS * std::max(vr.nv, 1), IDX_ZERO);
+    for (int v = 0; v < vr.nv; ++v)
+        for (int t = 0; t < NTAPS; ++t) vr.vidx[(size_t)t * vr.nv + v] = rows[v][t];
+}
+
+void build_slow_mask(const std::vector<int32_t>& idx, int E, int P, std::vector<uint8_t>& mask) {
+    mask.assign(P, 0);
+    for (int t = 0; t < NTAPS; ++t)
+        for (int p = 0; p < P; ++p) {
+            bool slow = idx[((size_t)t * E) * P + p] <= IDX_POLE;
+            for (int e = 1; e < E; ++e) slow |= idx[((size_t)t * E + e) * P + p] != IDX_ZERO;
+            if (slow) mask[p] |= (uint8_t)(1u << t);
+        }
+}
+
 void build_upsample(int r_in, int corner_mode, Ell& fwd, Ell& bwd) {
     check_args(r_in, 1, corner_mode);
     const int n = 1 << r_in, nf = 2 * n;

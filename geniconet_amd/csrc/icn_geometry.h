@@ -33,6 +33,22 @@ void build_conv_fwd(int r_in, int stride, int corner_mode, std::vector<int32_t>&
 // r_in - log2(stride)); E is the max multiplicity (returned).
 int build_conv_bwd(int r_in, int stride, int corner_mode, std::vector<int32_t>& out);
 
+// Split of the transposed table for the fast dgrad path.  `primary` [7][P_in] keeps at most one plain pixel per
+// (tap, row).  Every other contribution (second / third entries, pole means) becomes an entry of a "virtual row":
+// virtual row v (one per affected input pixel and level) has at most one code per tap, vidx [7][nv], and its GEMM
+// result is added to input pixel vq[v].  vq is sorted, so the virtual rows of one pixel are adjacent.
+struct VirtualRows {
+    int nv = 0;
+    std::vector<int32_t> vidx;   // [7][nv]: pixel of dy, IDX_ZERO, or IDX_POLE - k
+    std::vector<int32_t> vq;     // [nv] target input pixel
+};
+void split_conv_bwd(int r_in, int stride, const std::vector<int32_t>& bwd_idx, int E, std::vector<int32_t>& primary,
+                    VirtualRows& vr);
+
+// Per-row bit mask (bit t set) of the taps whose gather is not a single plain pixel: a pole mean, or more than
+// one entry (transposed tables).  idx is [7][E][P].
+void build_slow_mask(const std::vector<int32_t>& idx, int E, int P, std::vector<uint8_t>& mask);
+
 // ELL sparse matrices of the r -> r+1 upsample and of its transpose.
 struct Ell {
     int rows = 0, width = 0;

@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "icn_launch.h"
 
@@ -280,32 +282,369 @@ static void launch_gather_gemm(const GatherGemmArgs& a, hipStream_t s) {
 
 bool gather_gemm_supported(int K, int N) { return K % BK == 0 && N % 64 == 0 && K >= BK; }
 
-// Tile choice.  All co-resident blocks of a CU share its 4 MFMA pipes, so a launch takes about
-//   rounds * occ * BM * BN / eff,   rounds = ceil(tiles / (256 CUs * occ)),
-// where occ = blocks resident per CU (LDS / register bound) and eff = relative MFMA efficiency of the tile
-// shape.  The last, partly filled round costs as much as a full one (the dispatcher packs the leftover blocks
-// `occ` to a CU), so the tile count should land just below a multiple of 256 * occ.
-struct TileCfg { int bm, bn, occ; double eff; };
-static const TileCfg kTiles[] = {{128, 128, 2, 1.00}, {128, 64, 3, 0.96}, {64, 128, 3, 0.96}, {64, 64, 4, 0.88}};
+// ---------------------------------------------------------------------------------------------------------
+// k_conv_dma: the production gather-GEMM (same math as k_gather_gemm), persistent and staged by LDS-DMA.
+//   * staging: each lane owns BM/32 A rows and BN/32 B rows of a tile; its 16-byte chunk of every row is DMA'd
+//     (buffer_load ... lds) straight into the swizzled LDS image -- the swizzle lives in the per-lane SOURCE
+//     offset because the LDS side of a DMA is lane-linear -- so the steady state has no VGPR staging and no
+//     ds_write.  Rows that contribute nothing (corner_mode 'zeros', rows past M) carry an out-of-range offset
+//     and the buffer range check writes zeros for them.
+//   * the 7 x BM/32 source byte offsets of a tile live in registers (taps are unrolled);
+//   * rows that need more than one source (pole mean, duplicated transposed entries; a per-row bit mask
+//     marks them) are summed in registers and overwrite their LDS chunk before the stage is published;
+//   * persistent blocks walk tiles b, b+G, ...: the next tile's gather codes are fetched two K-steps before
+//     the current tile ends and its first stage is DMA'd during the last K-step, so the MFMA pipe does not
+//     drain at tile boundaries and launches are not rounded up to whole dispatch waves.
+// Requires every tap in use (no row permutation / tap masks) and source tensors below 2 GiB.
+// ---------------------------------------------------------------------------------------------------------
+using lds_ptr_t = __attribute__((address_space(3))) void*;
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(integral_constant<int, N-1>{})
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+constexpr unsigned OOB_OFFSET = 0x80000000u;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv_dma(
+    const float* __restrict__ src,      // (B, Ps, K)
+    const float* __restrict__ wt,       // [7][N][K]
+    const float* __restrict__ bias,     // [N] or null
+    float* __restrict__ dst,            // (B, Pd, N)
+    const int32_t* __restrict__ idx,    // [7][E][Pd]
+    const uint8_t* __restrict__ slowtab,// [Pd]
+    int M, int Ps, int Pd, int K, int N, int E, int ns, unsigned src_bytes, int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int RA = BM / 32, RB = BN / 32;          // rows per lane (one 16-byte chunk of each)
+    constexpr int NDMA = RA + RB;                      // DMA instructions per wave per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);        // [3][BM*32]   3-stage ring
+    float* Bs = As + 3 * BM * BK;                      // [3][BN*32]
+    unsigned* otab = reinterpret_cast<unsigned*>(Bs + 3 * BN * BK);   // [2][7][BM] source byte offset of each row
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int rsub = lane >> 3, pc = lane & 7;         // DMA: row within its 8-row group, physical 16-byte chunk
+    const int ntn = N / BN, nk = K / BK;
+    const int S = 7 * nk;                              // K-steps per tile
+
+    const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, 7 * N * K * 4, 0x00020000);
+
+    // XCD-aware tile order: tiles with equal index mod 8 (one persistent block's residue class, hence one XCD
+    // and one L2) form a contiguous run of (m, n) tiles.
+    auto tile_origin = [&](int tile, int& m0, int& n0) __attribute__((always_inline)) {
+        const int q = ntiles / 8, rem = ntiles % 8, x = tile % 8;
+        const int sw = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + tile / 8;
+        m0 = (sw / ntn) * BM;
+        n0 = (sw % ntn) * BN;
+    };
+    // lane-constant parts of the DMA source offsets (bytes)
+    unsigned achunk[RA], bconst[RB];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) achunk[i] = 16u * (pc ^ swz(8 * (wave + 4 * i) + rsub));
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int row = 8 * (wave + 4 * i) + rsub;
+        bconst[i] = (unsigned)row * (unsigned)K * 4u + 16u * (pc ^ swz(row));
+    }
+    // Row-offset table of one tile (built cooperatively, one tile ahead): byte offset of the row's source pixel, or
+    // an out-of-range offset (the DMA's range check then writes zeros) for rows that gather nothing.
+    auto build_table = [&](int slot, int m0) {
+        for (int e = tid; e < 7 * BM; e += 256) {
+            const int t = e / BM, row = e % BM, m = m0 + row;
+            unsigned base = OOB_OFFSET;
+            if (m < M) {
+                const int b = m / Pd, p = m % Pd;
+                const int32_t c = idx[(size_t)(t * E) * Pd + p];
+                if (c >= 0) base = (unsigned)(b * Ps + c) * (unsigned)K * 4u;
+            }
+            otab[slot * 7 * BM + e] = base;
+        }
+    };
+    auto load_slow = [&](int m0) {                       // bit 7*i + t: row i of this lane is slow for tap t
+        unsigned sl = 0;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = m0 + 8 * (wave + 4 * i) + rsub;
+            if (m < M) sl |= (unsigned)(slowtab[m % Pd] & 0x7f) << (7 * i);
+        }
+        return sl;
+    };
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    const int fl = swz(l31);
+    f32x4 fa[2][TM], fb[2][TN];
+    auto frag0 = [&](int ring) {                          // first fragments of a stage (issued before the DMA)
+        const float* a_base = As + ring * BM * BK + (wr * (BM / 2) + l31) * BK;
+        const float* b_base = Bs + ring * BN * BK + (wc * (BN / 2) + l31) * BK;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + 4 * (h ^ fl));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BK + 4 * (h ^ fl));
+    };
+    auto compute = [&](int ring) {
+        const float* a_base = As + ring * BM * BK + (wr * (BM / 2) + l31) * BK;
+        const float* b_base = Bs + ring * BN * BK + (wc * (BN / 2) + l31) * BK;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                const int off = 4 * ((2 * (kk + 1) + h) ^ fl);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[(kk + 1) & 1][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + off);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[(kk + 1) & 1][j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BK + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);     // keep the next group's LDS reads ahead of this group's MFMAs
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i][sidx], fb[kk & 1][j][sidx], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- 3-stage LDS ring: while step s computes from stage s, stages s+1 and s+2 are landed / in flight.
+    //   top of step s : issue stage s+2 into ring slot (s+2)%3 -- last read in step s-1, and every wave has passed
+    //                   the barrier that ended step s-1.  Rows of this lane that gather a single pixel are DMA'd;
+    //                   "slow" rows (pole mean / several transposed entries) are masked out of the DMA and summed in
+    //                   registers from ordinary loads issued BEFORE the DMA, so that ...
+    //   end of step s : ... waiting until only the youngest NDMA operations (stage s+2's DMA) are outstanding means
+    //                   stage s+1 has landed AND stage s+2's slow-row sums are in registers; those are written into
+    //                   stage s+2's slot; a raw barrier publishes stage s+1.  (__syncthreads() would drain vmcnt
+    //                   to 0 and serialise the ring.)
+    // The DMA pointer (i_*) runs two steps ahead of the compute pointer and crosses into the next tile, so the MFMA
+    // pipe does not drain at tile boundaries; the first two iterations (c_step < 0) only fill the ring.
+    // All loop state is kept in plain ints and passed through readfirstlane: hipcc must see the DMA's LDS base
+    // and scalar offset as wave-uniform or it wraps every DMA in a waterfall loop.
+    int tile = blockIdx.x, m0, n0;
+    tile_origin(tile, m0, n0);
+    build_table(0, m0);
+    unsigned slow_c = load_slow(m0), slow_n = 0;
+    __syncthreads();
+    int slot = 0;                                         // offset-table slot of the compute tile
+    int next_tile = tile + gridDim.x;
+    int has_next = next_tile < ntiles;
+    int nm0 = m0, nn0 = n0;
+    if (has_next) tile_origin(next_tile, nm0, nn0);
+    int i_t = 0, i_kc = 0, i_ring = 0, i_own = 1, i_live = 1;   // DMA pointer; i_own: still inside the compute tile
+    f32x4 ex[RA];
+    unsigned pbase[RA];                                   // row offsets of the next stage to be issued (prefetched)
+#pragma unroll
+    for (int i = 0; i < RA; ++i) pbase[i] = otab[8 * (wave + 4 * i) + rsub];
+    unsigned p_slow = 0;                                  // slow rows (bit 7*i) of the stage issued this step
+    int p_ring = 0, issued = 0;
+    // Issue the stage under the DMA pointer (slow-row loads first, then the DMA with those lanes masked off),
+    // advance the pointer, prefetch the next stage's row offsets.  One level of forced inlining, int state only.
+    // (macros, not lambdas: hipcc spilled the captured loop state of a lambda to scratch, and a scratch load is a
+    // VMEM op whose vmcnt(0) wait drains the DMA ring)
+#define ICN_ISSUE_STAGE() do { \
+        p_slow = 0; \
+        p_ring = i_ring; \
+        issued = i_live; \
+        if (i_live) { \
+            const int t = i_t, kc = i_kc; \
+            const int tm0 = __builtin_amdgcn_readfirstlane(i_own ? m0 : nm0); \
+            const int tn0 = __builtin_amdgcn_readfirstlane(i_own ? n0 : nn0); \
+            p_slow = ((i_own ? slow_c : slow_n) >> t) & 0x10204081u; \
+            if (p_slow) { \
+_Pragma("unroll") \
+                for (int i = 0; i < RA; ++i) { \
+                    if (!((p_slow >> (i * 7)) & 1)) continue; \
+                    const int row = 8 * (wave + 4 * i) + rsub, m = tm0 + row; \
+                    const int b = m / Pd, p = m % Pd, ch = kc * BK + 4 * (pc ^ swz(row)); \
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f}; \
+                    for (int e = 0; e < E; ++e) { \
+                        const int32_t c = idx[(size_t)(t * E + e) * Pd + p]; \
+                        if (c >= 0) v += ld4(src + ((size_t)b * Ps + c) * K + ch); \
+                        else if (c <= -2) v += pole_mean4(src, b, Ps, ns, -2 - c, K, ch); \
+                    } \
+                    ex[i] = v; \
+                } \
+            } \
+            const int a_soff = __builtin_amdgcn_readfirstlane(kc * (BK * 4)); \
+            const int b_soff = __builtin_amdgcn_readfirstlane(((t * N + tn0) * K + kc * BK) * 4); \
+_Pragma("unroll") \
+            for (int i = 0; i < RA; ++i) { \
+                float* lds_dst = As + __builtin_amdgcn_readfirstlane(p_ring * BM * BK + 8 * (wave + 4 * i) * BK); \
+                if (!((p_slow >> (i * 7)) & 1)) \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)lds_dst, 16, pbase[i] + achunk[i], a_soff, 0, 0); \
+            } \
+_Pragma("unroll") \
+            for (int i = 0; i < RB; ++i) { \
+                float* lds_dst = Bs + __builtin_amdgcn_readfirstlane(p_ring * BN * BK + 8 * (wave + 4 * i) * BK); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)lds_dst, 16, bconst[i], b_soff, 0, 0); \
+            } \
+            i_ring = i_ring == 2 ? 0 : i_ring + 1; \
+            if (++i_t == 7) { \
+                i_t = 0; \
+                if (++i_kc == nk) { \
+                    i_kc = 0; \
+                    if (i_own && has_next) i_own = 0; \
+                    else i_live = 0; \
+                } \
+            } \
+            if (i_live) { \
+                const int tb = __builtin_amdgcn_readfirstlane(((i_own ? slot : slot ^ 1) * 7 + i_t) * BM); \
+_Pragma("unroll") \
+                for (int i = 0; i < RA; ++i) pbase[i] = otab[tb + 8 * (wave + 4 * i) + rsub]; \
+            } \
+        } \
+    } while (0)
+    // End of a K-step: retire the previous stage (and this step's slow-row loads), write the slow-row sums into the
+    // slot of the stage issued this step, publish.
+#define ICN_RETIRE_AND_PUBLISH() do { \
+        if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        if (p_slow) { \
+_Pragma("unroll") \
+            for (int i = 0; i < RA; ++i) \
+                if ((p_slow >> (i * 7)) & 1) \
+                    *reinterpret_cast<f32x4*>(As + p_ring * BM * BK + (8 * (wave + 4 * i) + rsub) * BK + 4 * pc) = ex[i]; \
+        } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier(); \
+    } while (0)
+    ICN_ISSUE_STAGE();                                    // ring fill: stages 0 and 1 (K >= 32 => >= 7 steps per tile)
+    ICN_RETIRE_AND_PUBLISH();
+    ICN_ISSUE_STAGE();
+    ICN_RETIRE_AND_PUBLISH();
+    zero_acc();
+    int c_ring = 0;
+    for (;;) {
+        if (has_next) {                                   // next tile's row offsets: consumed >= 5 K-steps from now
+            build_table(slot ^ 1, nm0);
+            slow_n = load_slow(nm0);
+        }
+        for (int step = 0; step < S; ++step) {
+            frag0(c_ring);
+            ICN_ISSUE_STAGE();                            // stage s+2
+            compute(c_ring);
+            ICN_RETIRE_AND_PUBLISH();                     // stage s+1 landed and visible
+            c_ring = c_ring == 2 ? 0 : c_ring + 1;
+        }
+        // ---- tile epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wc * (BN / 2) + j * 32 + l31;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < M) dst[(size_t)m * N + col] = acc[i][j][r] + bv;
+                }
+        }
+        if (!has_next) break;
+        zero_acc();
+        tile = next_tile;
+        m0 = nm0;
+        n0 = nn0;
+        slow_c = slow_n;
+        slot ^= 1;
+        i_own = 1;                                        // the DMA pointer is already inside this tile
+        next_tile = tile + gridDim.x;
+        has_next = next_tile < ntiles;
+        if (has_next) tile_origin(next_tile, nm0, nn0);
+    }
+#undef ICN_ISSUE_STAGE
+#undef ICN_RETIRE_AND_PUBLISH
+#endif
+}
+
+template <int BM, int BN>
+static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
+    const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+    int grid = std::min(ntiles, 256 * occ);
+    if (grid >= 8) grid -= grid % 8;                     // keep a block's tiles in one residue class mod 8 (one XCD)
+    const size_t lds = (size_t)3 * (BM + BN) * BK * 4 + (size_t)2 * 7 * BM * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_dma<BM, BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const unsigned src_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.Ps * a.K * 4);
+    prof_mark_begin(BM == 64 ? (BN == 128 ? PROF_GG_64x128 : PROF_GG_64x64) : (BN == 128 ? PROF_GG_128x128 : PROF_GG_128x64),
+                    a.algo_flops, s);
+    hipLaunchKernelGGL((k_conv_dma<BM, BN>), dim3(grid), dim3(256), lds, s, a.src, a.wt, a.bias, a.dst, a.idx, a.slow, a.M,
+                       a.Ps, a.Pd, a.K, a.N, a.E, a.ns, src_bytes, ntiles);
+    prof_mark_end(s);
+}
+
+static bool conv_dma_usable(const GatherGemmArgs& a) {
+    if (dbg_flags() & 16) return false;
+    const size_t src_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.K * 4, wt_bytes = (size_t)7 * a.N * a.K * 4;
+    return a.perm == nullptr && a.mask32 == nullptr && a.slow != nullptr && src_bytes < ((size_t)1 << 31) &&
+           wt_bytes < ((size_t)1 << 31);
+}
+
+// Tile shape of the persistent kernel.  `occ` blocks share a CU's MFMA pipes and a block runs ceil(tiles / grid) tiles
+// back to back, so a launch takes about ceil(tiles / (256 * occ)) * occ * BM * BN / eff.  eff is the measured relative
+// throughput of the shapes on I5 / batch 36 layers (tools/bench_layers.py with ICN_TILE=0..3): 64-row tiles at two to
+// three blocks per CU hide the per-step barrier best; the 128x128 tile only fits one block per CU (3-stage ring).
+struct DmaCfg { int bm, bn, occ; double eff; };
+static const DmaCfg kDma[] = {{128, 128, 1, 0.80}, {128, 64, 2, 0.92}, {64, 128, 2, 1.00}, {64, 64, 3, 0.95}};
+
+static void launch_conv_dma_auto(const GatherGemmArgs& a, hipStream_t s) {
+    int best = -1;
+    double best_cost = 0;
+    const char* force = getenv("ICN_TILE");          // developer override: 0..3 = index into kDma
+    for (int i = 0; i < 4; ++i) {
+        const DmaCfg& c = kDma[i];
+        if (a.N % c.bn != 0) continue;
+        const long tiles = (long)((a.M + c.bm - 1) / c.bm) * (a.N / c.bn);
+        const long slots = 256L * c.occ;
+        double cost = (double)((tiles + slots - 1) / slots) * c.occ * c.bm * c.bn / c.eff;
+        if (force && atoi(force) == i) cost = -1;
+        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+    }
+    switch (best) {
+        case 0: return launch_conv_dma<128, 128>(a, kDma[0].occ, s);
+        case 1: return launch_conv_dma<128, 64>(a, kDma[1].occ, s);
+        case 2: return launch_conv_dma<64, 128>(a, kDma[2].occ, s);
+        default: return launch_conv_dma<64, 64>(a, kDma[3].occ, s);
+    }
+}
+
+// tile of the fall-back kernel (k_gather_gemm: row permutation / tap masks, or tensors beyond the DMA's 2 GiB range)
 static int pick_tile(int M, int N, int E) {
+    static const struct { int bm, bn, occ; double eff; } cfg[] = {{128, 128, 2, 1.00}, {128, 64, 3, 0.96}, {64, 128, 3, 0.96}, {64, 64, 4, 0.88}};
     int best = -1;
     double best_cost = 0;
     for (int i = 0; i < 4; ++i) {
-        const TileCfg& c = kTiles[i];
-        if (N % c.bn != 0) continue;
-        int occ = c.occ;
-        if (E > 1 && c.bm == 128 && c.bn != 128) occ = 2;   // the transposed tables' code array costs LDS
-        const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
-        const long slots = 256L * occ;
-        const long rounds = (tiles + slots - 1) / slots;
-        const double cost = (double)rounds * occ * c.bm * c.bn / c.eff;
+        if (N % cfg[i].bn != 0) continue;
+        const int occ = (E > 1 && cfg[i].bm == 128 && cfg[i].bn != 128) ? 2 : cfg[i].occ;   // the code table costs LDS
+        const long tiles = (long)((M + cfg[i].bm - 1) / cfg[i].bm) * (N / cfg[i].bn), slots = 256L * occ;
+        const double cost = (double)((tiles + slots - 1) / slots) * occ * cfg[i].bm * cfg[i].bn / cfg[i].eff;
         if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
     }
     return best;
 }
 
 void launch_gather_gemm_auto(const GatherGemmArgs& a, hipStream_t s) {
+    if (conv_dma_usable(a)) return launch_conv_dma_auto(a, s);
     switch (pick_tile(a.M, a.N, a.E)) {
         case 0: return launch_gather_gemm<128, 128>(a, s);
         case 1: return launch_gather_gemm<128, 64>(a, s);
@@ -714,6 +1053,33 @@ void launch_conv_generic(const float* src, const float* w, const float* bias, fl
     const int blocks = (int)std::min((size_t)16384, (total + 255) / 256);
     hipLaunchKernelGGL(k_conv_generic, dim3(blocks), dim3(256), 0, s, src, w, bias, dst, idx, B, Ps, Pd, K, N, E, ns,
                        transpose);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dst[b, q[v], :] += src[b, v, :]: folds the virtual-row GEMM of dgrad (extra transposed entries along chart seams)
+// back into dx.  q is sorted, so the thread that owns the first virtual row of a pixel adds all of them in order.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_row_scatter_add(const float* __restrict__ src, float* __restrict__ dst, const int32_t* __restrict__ q, int B,
+                                  int nv, int P, int C) {
+    const int c4n = C / 4;
+    const size_t total = (size_t)B * nv * c4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const size_t bv = i / c4n;
+        const int v = (int)(bv % nv), b = (int)(bv / nv);
+        const int32_t qv = q[v];
+        if (v > 0 && q[v - 1] == qv) continue;            // not the first virtual row of this pixel
+        float* d = dst + ((size_t)b * P + qv) * C + c;
+        f32x4 acc = ld4(d);
+        for (int k = v; k < nv && q[k] == qv; ++k) acc += ld4(src + ((size_t)b * nv + k) * C + c);
+        *reinterpret_cast<f32x4*>(d) = acc;
+    }
+}
+
+void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int B, int nv, int P, int C, hipStream_t s) {
+    const size_t total = (size_t)B * nv * (C / 4);
+    hipLaunchKernelGGL(k_row_scatter_add, dim3((unsigned)std::min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s, src, dst, q, B,
+                       nv, P, C);
 }
 
 void launch_pack_weights(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t s) {

@@ -11,6 +11,7 @@ struct GatherGemmArgs {
     const float* bias;      // [N] or null
     float* dst;             // (B, Pd, N)
     const int32_t* idx;     // [7][E][Pd]
+    const uint8_t* slow;    // [Pd] per-row mask of taps needing the slow gather
     const int32_t* perm;    // [Pd] or null
     const uint8_t* mask32;  // [Pd/32] or null
     int M, Ps, Pd, K, N, E, ns;
@@ -44,6 +45,9 @@ void launch_spmm_ell(const float* in, float* out, const int32_t* idx, const floa
 
 void launch_conv_generic(const float* src, const float* w, const float* bias, float* dst, const int32_t* idx, int B, int Ps,
                          int Pd, int K, int N, int E, int ns, int transpose, hipStream_t s);
+
+// dst[b, q[v], :] += src[b, v, :]   (q sorted; rows of one q are summed in order by one thread => deterministic)
+void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int B, int nv, int P, int C, hipStream_t s);
 
 void launch_pack_weights(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t s);
 

@@ -43,6 +43,8 @@ def main():
     ap.add_argument('--R', type=int, default=5)
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--only', default='')
+    ap.add_argument('--mode', default='all', choices=['all', 'fwd'])
+    ap.add_argument('--data', default='randn', choices=['randn', 'zeros', 'ones'])
     a = ap.parse_args()
     tot = {'fwd': 0.0, 'bwd_data': 0.0, 'bwd_weight': 0.0}
     print('%-22s %9s | %8s %7s | %8s %7s | %8s %7s' % ('layer', 'GFLOP', 'fwd us', 'TF/s', 'dgrad us', 'TF/s', 'wgrad us', 'TF/s'))
@@ -54,8 +56,14 @@ def main():
         x = torch.randn(a.batch, cin, 5 * n, 2 * n, device='cuda').contiguous(memory_format=torch.channels_last)
         w = (torch.randn(cout, cin, 7, device='cuda') / (7 * cin) ** 0.5)
         b = torch.randn(cout, device='cuda')
+        if a.data != 'randn':
+            fill = 0.0 if a.data == 'zeros' else 1.0
+            x.fill_(fill); w.fill_(fill)
         gflop = 2 * 7 * cin * cout * a.batch * 10 * (n // stride) ** 2 / 1e9
         t_f = timed(lambda: ico_conv(x, w, b, r, stride, 'average'), a.iters)
+        if a.mode == 'fwd':
+            print('%-22s %9.2f | %8.1f %7.1f' % (name, gflop, t_f * 1e6, gflop / t_f / 1e3))
+            continue
         xg = x.clone().requires_grad_()
         y = ico_conv(xg, w, b, r, stride, 'average')
         gy = torch.randn_like(y)
