@@ -142,12 +142,21 @@ def main():
         roofline = None
         if prof:
             dom = max(prof, key=lambda e: e['total_ms'])
+            # HBM bytes per launch of that kernel from the latest committed PMC passes (tools/profile_round.sh:
+            # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH doubled per the gfx950 note)
+            traffic = None
+            try:
+                import glob
+                latest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel.json')))[-1]
+                traffic = json.load(open(latest)).get('icn::' + dom['kernel'], {}).get('hbm_bytes_per_launch')
+            except (IndexError, OSError, ValueError):
+                pass
             per_launch_ms = dom['total_ms'] / dom['launches']
             achieved = dom['total_flops'] / (dom['total_ms'] * 1e-3) / 1e12
             mfma_ms = sum(e['total_ms'] for e in prof)
             roofline = {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
                 'kernel': dom['kernel'], 'launches_per_step': dom['launches'] / args.steps,
                 'avg_launch_us': round(per_launch_ms * 1e3, 2),
                 'algorithmic_gflop_per_launch': round(dom['total_flops'] / dom['launches'] / 1e9, 3),

@@ -143,8 +143,8 @@ def profile_start(max_launches=100000):
 
 def profile_stop():
     """-> list of dicts(kernel, launches, total_ms, total_flops) for the MFMA kernels launched since profile_start."""
-    buf = (ProfileEntry * 16)()
-    n = lib().icn_profile_stop(buf, 16)
+    buf = (ProfileEntry * 32)()
+    n = lib().icn_profile_stop(buf, 32)
     if n < 0:
         check(-1, 'icn_profile_stop')
     return [dict(kernel=buf[i].kernel.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms,

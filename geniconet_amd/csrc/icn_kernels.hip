@@ -586,7 +586,7 @@ static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
         attr_set = true;
     }
     const unsigned src_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.Ps * a.K * 4);
-    prof_mark_begin(BM == 64 ? (BN == 128 ? PROF_GG_64x128 : PROF_GG_64x64) : (BN == 128 ? PROF_GG_128x128 : PROF_GG_128x64),
+    prof_mark_begin(BM == 64 ? (BN == 128 ? PROF_DMA_64x128 : PROF_DMA_64x64) : (BN == 128 ? PROF_DMA_128x128 : PROF_DMA_128x64),
                     a.algo_flops, s);
     hipLaunchKernelGGL((k_conv_dma<BM, BN>), dim3(grid), dim3(256), lds, s, a.src, a.wt, a.bias, a.dst, a.idx, a.slow, a.M,
                        a.Ps, a.Pd, a.K, a.N, a.E, a.ns, src_bytes, ntiles);
@@ -675,9 +675,15 @@ __global__ __launch_bounds__(256) void k_wgrad(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
+    // XCD-aware block order: the `group` = (ci tile, co tile, tap) blocks of one row split all read the same x / dy
+    // rows.  Blocks b and b + 8 share an XCD (and its L2), so walk each XCD through one split at a time; dispatched
+    // round-robin instead, the 7 taps of a split land on 7 different L2s and every row is fetched from HBM 7 times.
     const int ntj = Cout / BJ;
-    const int ci0 = (blockIdx.x / ntj) * BI, co0 = (blockIdx.x % ntj) * BJ;
-    const int t = blockIdx.y, split = blockIdx.z;
+    const int group = (Cin / BI) * ntj * 7;              // blocks per row split
+    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+    const int split = (j / group) * 8 + xcd, g = j % group;
+    const int t = g % 7, tile = g / 7;
+    const int ci0 = (tile / ntj) * BI, co0 = (tile % ntj) * BJ;
     const int m_begin = split * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
     const bool do_bias = bias_partial != nullptr && t == 0 && ci0 == 0;   // block-uniform
@@ -929,7 +935,8 @@ int wgrad_splits(int M, int Cin, int Cout) {
         long s = (1024 + tiles - 1) / tiles;                   // ~4 blocks per CU in flight
         const long max_s = (M + 255) / 256;                    // >= 8 stages of 32 rows per block
         if (s > max_s) s = max_s;
-        return (int)(s < 1 ? 1 : s);
+        if (s < 1) s = 1;
+        return (int)((s + 7) / 8 * 8);                         // whole number of splits per XCD (k_wgrad's block order)
     }
     if (stem_supported(Cin, Cout)) return std::min(2048, (M + 255) / 256);
     return std::min(512, (M + 127) / 128);
@@ -942,7 +949,7 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         rows = (rows + 31) / 32 * 32;
         const bool bi128 = a.Cin % 128 == 0, bj128 = a.Cout % 128 == 0;
         const int BI = bi128 ? 128 : 64, BJ = bj128 ? 128 : 64;
-        dim3 grid((a.Cin / BI) * (a.Cout / BJ), 7, S);
+        dim3 grid((a.Cin / BI) * (a.Cout / BJ) * 7 * S);        // S is a multiple of 8 (see wgrad_splits)
         const size_t lds = (size_t)2 * 32 * (BI + BJ) * 4;
 #define ICN_WG(I, J)                                                                                                   \
     hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M, a.Ps, \

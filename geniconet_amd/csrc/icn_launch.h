@@ -52,8 +52,8 @@ void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int 
 void launch_pack_weights(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t s);
 
 // ---- optional per-launch HIP-event timing of the MFMA kernels (bench.py's live roofline measurement) ----------
-enum ProfKind { PROF_GG_128x128 = 0, PROF_GG_128x64, PROF_GG_64x128, PROF_GG_64x64, PROF_WG_128x128, PROF_WG_128x64, PROF_WG_64x128,
-                PROF_WG_64x64, PROF_KINDS };
+enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA_64x64, PROF_GG_128x128, PROF_GG_128x64,
+                PROF_GG_64x128, PROF_GG_64x64, PROF_WG_128x128, PROF_WG_128x64, PROF_WG_64x128, PROF_WG_64x64, PROF_KINDS };
 extern const char* const PROF_NAMES[PROF_KINDS];
 void prof_mark_begin(int kind, double flops, hipStream_t s);   // no-ops unless profiling is on
 void prof_mark_end(hipStream_t s);

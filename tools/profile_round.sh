@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round evidence for profiles/: run on the GPU box (via gpurun).  usage: tools/profile_round.sh rNN
+#   1. rocprofv3 --kernel-trace --stats of the default bench command (no PMC)
+#   2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, GRBM/TCC) of the same command with fewer steps
+# Raw output goes to gpurun_out/prof_<round>/; tools/profile_summary.py condenses it into profiles/.
+set -e
+ROUND="${1:-r01}"
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_$ROUND; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_stats.json 2> $OUT/bench_stats.err
+for c in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
+  tag=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$tag -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err
+done
+cd $R && python3 tools/profile_summary.py $ROUND

@@ -1,0 +1,70 @@
+"""Condense gpurun_out/prof_<round>/ (rocprofv3 csv) into the tracked profiles/<round>_* files."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, 'gpurun_out', 'prof_' + rnd)
+dst = os.path.join(root, 'profiles')
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    return name.split('(')[0].replace('void ', '')[:70]
+
+
+# ---- 1. kernel stats of the bench command
+stats = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)
+bench = json.loads(open(os.path.join(src, 'bench_stats.json')).read().strip().splitlines()[-1])
+steps_total = bench['steps'] + bench['warmup']
+rows = list(csv.DictReader(open(stats[0])))
+with open(os.path.join(dst, rnd + '_bench_kernel_stats.csv'), 'w') as f:
+    f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup %d --no-cpu-baseline  (%d steps traced; '
+            'bench line under the profiler: %.1f meshes/s, %.3f ms/step)\n' % (bench['steps'], bench['warmup'], steps_total,
+                                                                           bench['value'], bench['ms_per_step']))
+    f.write('kernel,calls,calls_per_step,total_ms,avg_us,min_us,max_us,percent\n')
+    for r in rows:
+        f.write('%s,%s,%.2f,%.3f,%.2f,%.2f,%.2f,%s\n' % (short(r['Name']).replace(',', ';'), r['Calls'], int(r['Calls']) / steps_total,
+                                                       float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3,
+                                                       float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
+
+# ---- 2. PMC passes: per-kernel mean counter value per dispatch
+pmc = collections.defaultdict(dict)
+dur = collections.defaultdict(list)
+for d in sorted(glob.glob(os.path.join(src, 'pmc_*/'))):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(d + '**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    for f in glob.glob(d + '**/*kernel_trace.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    for k, cs in agg.items():
+        for c, v in cs.items():
+            pmc[k][c] = sum(v) / len(v)
+            pmc[k]['dispatches_' + c] = len(v)
+out = {}
+for k, cs in pmc.items():
+    if 'icn::' not in k:
+        continue
+    e = {'avg_us_under_pmc': round(sum(dur[k]) / len(dur[k]), 2)}
+    e.update({c: v for c, v in cs.items()})
+    # gfx950: FETCH_SIZE (KiB) under-reports wide coalesced reads by exactly 2x; WRITE_SIZE (KiB) is exact
+    if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
+        e['hbm_read_bytes_per_launch'] = cs['FETCH_SIZE'] * 1024 * 2
+        e['hbm_write_bytes_per_launch'] = cs['WRITE_SIZE'] * 1024
+        e['hbm_bytes_per_launch'] = e['hbm_read_bytes_per_launch'] + e['hbm_write_bytes_per_launch']
+    if 'GRBM_GUI_ACTIVE' in cs:
+        e['clock_ghz_estimate'] = round(cs['GRBM_GUI_ACTIVE'] / 8 / (e['avg_us_under_pmc'] * 1e-6) / 1e9, 3)
+    if 'TCC_HIT_sum' in cs:
+        e['l2_hit_rate'] = round(cs['TCC_HIT_sum'] / (cs['TCC_HIT_sum'] + cs['TCC_MISS_sum']), 4)
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in cs and 'GRBM_GUI_ACTIVE' in cs:
+        e['mfma_pipe_busy_frac'] = round(cs['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (cs['GRBM_GUI_ACTIVE'] / 8), 4)
+    out[k] = e
+json.dump(out, open(os.path.join(dst, rnd + '_pmc_per_kernel.json'), 'w'), indent=1, sort_keys=True)
+json.dump(bench, open(os.path.join(dst, rnd + '_bench_under_rocprof.json'), 'w'), indent=1)
+print('wrote', sorted(os.listdir(dst)))
