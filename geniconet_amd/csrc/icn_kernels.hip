@@ -780,6 +780,207 @@ __global__ __launch_bounds__(256) void k_wgrad(
     if (do_bias && tid < BJ) bias_partial[(size_t)split * Cout + co0 + tid] = bsum;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_wgrad_dma: same math as k_wgrad, staged by LDS-DMA through a 3-stage ring of 16-row stages.
+//   A stage = 16 consecutive output rows m: X[16][BI] (gathered input rows of tap t, channels ci0..) and Y[16][BJ]
+//   (dy rows, channels co0..).  A lane's gather code for stage s+3 is fetched (plain load) at step s, turned into a
+//   byte offset at step s+1 and used by the DMA of stage s+3 issued there; rows whose tap reads a pole are masked out
+//   of the DMA and patched from registers (pole mean), exactly as in k_conv_dma.  Plain loads are always issued BEFORE
+//   the step's DMA, so the single counted vmcnt at the end of a step retires the previous stage and those loads.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int WG_RS = 16;   // rows per stage
+
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void k_wgrad_dma(
+    const float* __restrict__ x,        // (B, Ps, Cin)
+    const float* __restrict__ dy,       // (B, Pd, Cout)
+    const int32_t* __restrict__ idx,    // forward table [7][Pd]
+    float* __restrict__ partial,        // [S][7][Cin][Cout]
+    float* __restrict__ bias_partial,   // [S][Cout] or null
+    int M, int Ps, int Pd, int Cin, int Cout, int ns, int rows_per_split, unsigned x_bytes, unsigned dy_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TI = BI / 64, TJ = BJ / 64;
+    constexpr int LA = BI / 4, LB = BJ / 4;            // lanes (16-byte chunks) per row
+    constexpr int RPA = 64 / LA, RPB = 64 / LB;        // rows per DMA instruction
+    constexpr int NA = WG_RS / RPA / 4, NB = WG_RS / RPB / 4;   // DMA instructions per wave per stage (BI,BJ >= 64)
+    constexpr int NDMA = NA + NB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Xs = reinterpret_cast<float*>(smem);        // [3][WG_RS][BI]
+    float* Ys = Xs + 3 * WG_RS * BI;                   // [3][WG_RS][BJ]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    // XCD-aware block order (see k_wgrad)
+    const int ntj = Cout / BJ;
+    const int group = (Cin / BI) * ntj * 7;
+    const int xcd = blockIdx.x % 8, jb = blockIdx.x / 8;
+    const int split = (jb / group) * 8 + xcd, g = jb % group;
+    const int t = g % 7, tile = g / 7;
+    const int ci0 = (tile / ntj) * BI, co0 = (tile % ntj) * BJ;
+    const int m_begin = split * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+    const int nsteps = (m_end - m_begin + WG_RS - 1) / WG_RS;
+    const bool do_bias = bias_partial != nullptr && t == 0 && ci0 == 0;   // block-uniform
+
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+    const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, dy_bytes, 0x00020000);
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum = 0.f;
+
+    // lane-constant pieces
+    const int arow = lane / LA, achunk = lane % LA;    // row within its DMA instruction, 16-byte chunk
+    const int brow = lane / LB, bchunk = lane % LB;
+    // per-lane row state of the CODE pointer (3 stages ahead of compute): row (wave + 4*i)*RPA + arow of that stage
+    int c_b[NA], c_p[NA];                              // sample / pixel of the lane's rows at the code pointer
+    int c_m0 = m_begin;                                // first row of the stage under the code pointer
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m_begin + (wave + 4 * i) * RPA + arow;
+        c_b[i] = m / Pd;
+        c_p[i] = m % Pd;
+    }
+    int32_t code[NA];                                  // codes of the stage the DMA pointer will issue next
+    unsigned aoff[NA];
+    f32x4 ex[NA];
+    unsigned p_slow = 0;
+    int d_ring = 0, d_step = 0;                        // DMA pointer: ring slot and stage index
+    int p_ring = 0, issued = 0;
+
+    // fetch the gather codes of the stage under the code pointer, advance the pointer by one stage
+#define ICN_WG_FETCH_CODES() do { \
+        _Pragma("unroll") \
+        for (int i = 0; i < NA; ++i) { \
+            const int m = c_m0 + (wave + 4 * i) * RPA + arow; \
+            code[i] = m < m_end ? idx[(size_t)t * Pd + c_p[i]] : -1; \
+        } \
+    } while (0)
+#define ICN_WG_ADVANCE_CODE_PTR() do { \
+        c_m0 += WG_RS; \
+        _Pragma("unroll") \
+        for (int i = 0; i < NA; ++i) { c_p[i] += WG_RS; while (c_p[i] >= Pd) { c_p[i] -= Pd; c_b[i] += 1; } } \
+    } while (0)
+    // codes -> byte offsets (uses the row state BEFORE it is advanced); pole codes become slow rows
+#define ICN_WG_MAKE_OFFSETS() do { \
+        p_slow = 0; \
+        _Pragma("unroll") \
+        for (int i = 0; i < NA; ++i) { \
+            const int32_t c = code[i]; \
+            aoff[i] = c >= 0 ? ((unsigned)(c_b[i] * Ps + c) * (unsigned)Cin + (unsigned)(ci0 + 4 * achunk)) * 4u : OOB_OFFSET; \
+            if (c <= -2) { \
+                p_slow |= 1u << i; \
+                ex[i] = pole_mean4(x, c_b[i], Ps, ns, -2 - c, Cin, ci0 + 4 * achunk); \
+            } \
+        } \
+    } while (0)
+    // issue the DMA of stage d_step into ring slot d_ring (offsets prepared by ICN_WG_MAKE_OFFSETS)
+#define ICN_WG_ISSUE() do { \
+        p_ring = d_ring; \
+        issued = d_step < nsteps; \
+        if (issued) { \
+            _Pragma("unroll") \
+            for (int i = 0; i < NA; ++i) { \
+                float* dst_ = Xs + __builtin_amdgcn_readfirstlane(p_ring * WG_RS * BI + (wave + 4 * i) * RPA * BI); \
+                if (!((p_slow >> i) & 1)) \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst_, 16, aoff[i], 0, 0, 0); \
+            } \
+            const int y_soff = __builtin_amdgcn_readfirstlane((m_begin + d_step * WG_RS) * Cout * 4); \
+            _Pragma("unroll") \
+            for (int i = 0; i < NB; ++i) { \
+                float* dst_ = Ys + __builtin_amdgcn_readfirstlane(p_ring * WG_RS * BJ + (wave + 4 * i) * RPB * BJ); \
+                const int row_ = (wave + 4 * i) * RPB + brow; \
+                const unsigned voff_ = (m_begin + d_step * WG_RS + row_ < m_end) \
+                                           ? ((unsigned)row_ * (unsigned)Cout + (unsigned)(co0 + 4 * bchunk)) * 4u : OOB_OFFSET; \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)dst_, 16, voff_, y_soff, 0, 0); \
+            } \
+            d_ring = d_ring == 2 ? 0 : d_ring + 1; \
+            d_step += 1; \
+        } \
+    } while (0)
+#define ICN_WG_RETIRE_AND_PUBLISH() do { \
+        if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        if (p_slow && issued) { \
+            _Pragma("unroll") \
+            for (int i = 0; i < NA; ++i) \
+                if ((p_slow >> i) & 1) \
+                    *reinterpret_cast<f32x4*>(Xs + p_ring * WG_RS * BI + ((wave + 4 * i) * RPA + arow) * BI + 4 * achunk) = ex[i]; \
+        } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier(); \
+    } while (0)
+
+    // ring fill: stages 0 and 1; codes for stage 2 in flight
+    ICN_WG_FETCH_CODES();
+    ICN_WG_MAKE_OFFSETS();
+    ICN_WG_ADVANCE_CODE_PTR();
+    ICN_WG_ISSUE();
+    ICN_WG_RETIRE_AND_PUBLISH();
+    ICN_WG_FETCH_CODES();
+    ICN_WG_MAKE_OFFSETS();
+    ICN_WG_ADVANCE_CODE_PTR();
+    ICN_WG_ISSUE();
+    ICN_WG_RETIRE_AND_PUBLISH();
+    ICN_WG_FETCH_CODES();                               // codes of stage 2, consumed at the top of step 0
+    int c_ring = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        // stage step+2: offsets from the codes fetched one step ago, slow-row loads, next codes, then the DMA
+        ICN_WG_MAKE_OFFSETS();
+        ICN_WG_ADVANCE_CODE_PTR();
+        ICN_WG_FETCH_CODES();                           // stage step+3 (plain loads, issued before the DMA)
+        ICN_WG_ISSUE();
+        const float* xa = Xs + c_ring * WG_RS * BI + wr * (BI / 2) + l31;
+        const float* yb = Ys + c_ring * WG_RS * BJ + wc * (BJ / 2) + l31;
+#pragma unroll
+        for (int k2 = 0; k2 < WG_RS / 2; ++k2) {
+            const int k = 2 * k2 + h;
+            float a[TI], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = xa[k * BI + i * 32];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[j] = yb[k * BJ + j * 32];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (do_bias && tid < BJ) {
+#pragma unroll
+            for (int k = 0; k < WG_RS; ++k) bsum += Ys[c_ring * WG_RS * BJ + k * BJ + tid];
+        }
+        ICN_WG_RETIRE_AND_PUBLISH();
+        c_ring = c_ring == 2 ? 0 : c_ring + 1;
+    }
+#undef ICN_WG_FETCH_CODES
+#undef ICN_WG_ADVANCE_CODE_PTR
+#undef ICN_WG_MAKE_OFFSETS
+#undef ICN_WG_ISSUE
+#undef ICN_WG_RETIRE_AND_PUBLISH
+
+    float* out = partial + ((size_t)split * 7 + t) * Cin * Cout;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wr * (BI / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int co = co0 + wc * (BJ / 2) + j * 32 + l31;
+                out[(size_t)ci * Cout + co] = acc[i][j][r];
+            }
+    if (do_bias && tid < BJ) bias_partial[(size_t)split * Cout + co0 + tid] = bsum;
+#endif
+}
+
 // dw[co][ci][t] = sum_s partial[s][t][ci][co];   dbias[co] = sum_s bias_partial[s][co]
 __global__ void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
                                const float* __restrict__ bias_partial, float* __restrict__ dbias, int S, int Cin, int Cout) {
@@ -951,9 +1152,18 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         const int BI = bi128 ? 128 : 64, BJ = bj128 ? 128 : 64;
         dim3 grid((a.Cin / BI) * (a.Cout / BJ) * 7 * S);        // S is a multiple of 8 (see wgrad_splits)
         const size_t lds = (size_t)2 * 32 * (BI + BJ) * 4;
-#define ICN_WG(I, J)                                                                                                   \
-    hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M, a.Ps, \
-                       a.Pd, a.Cin, a.Cout, a.ns, rows)
+        const size_t x_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.Cin * 4, dy_bytes = (size_t)a.M * a.Cout * 4;
+        const bool dma = !(dbg_flags() & 32) && x_bytes < ((size_t)1 << 31) && dy_bytes < ((size_t)1 << 31);
+        const size_t lds_dma = (size_t)3 * WG_RS * (BI + BJ) * 4;
+#define ICN_WG(I, J)                                                                                                       \
+    do {                                                                                                                   \
+        if (dma)                                                                                                           \
+            hipLaunchKernelGGL((k_wgrad_dma<I, J>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, \
+                               a.M, a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows, (unsigned)x_bytes, (unsigned)dy_bytes);         \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M,   \
+                               a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows);                                                     \
+    } while (0)
         prof_mark_begin(bi128 ? (bj128 ? PROF_WG_128x128 : PROF_WG_128x64) : (bj128 ? PROF_WG_64x128 : PROF_WG_64x64),
                         a.algo_flops, s);
         if (bi128 && bj128) ICN_WG(128, 128);
