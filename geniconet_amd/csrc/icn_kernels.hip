@@ -317,7 +317,9 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     const float* __restrict__ bias,     // [N] or null
     float* __restrict__ dst,            // (B, Pd, N)
     const int32_t* __restrict__ idx,    // [7][E][Pd]
-    const uint8_t* __restrict__ slowtab,// [Pd]
+    const uint8_t* __restrict__ slowtab,// [Pd] or null (no slow rows)
+    const int32_t* __restrict__ perm,   // [Pd] row -> dst pixel, or null (identity)
+    const uint8_t* __restrict__ mask32, // [Pd/32] taps in use per 32 rows, or null (all 7)
     int M, int Ps, int Pd, int K, int N, int E, int ns, unsigned src_bytes, int ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -334,7 +336,6 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     const int l31 = lane & 31, h = lane >> 5;
     const int rsub = lane >> 3, pc = lane & 7;         // DMA: row within its 8-row group, physical 16-byte chunk
     const int ntn = N / BN, nk = K / BK;
-    const int S = 7 * nk;                              // K-steps per tile
 
     const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
     const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, 7 * N * K * 4, 0x00020000);
@@ -363,19 +364,33 @@ __global__ __launch_bounds__(256) void k_conv_dma(
             const int t = e / BM, row = e % BM, m = m0 + row;
             unsigned base = OOB_OFFSET;
             if (m < M) {
-                const int b = m / Pd, p = m % Pd;
+                const int b = m / Pd, p = perm ? perm[m % Pd] : m % Pd;
                 const int32_t c = idx[(size_t)(t * E) * Pd + p];
                 if (c >= 0) base = (unsigned)(b * Ps + c) * (unsigned)K * 4u;
             }
             otab[slot * 7 * BM + e] = base;
         }
     };
+    // taps in use by a tile (stride-2 dgrad: rows are grouped by lattice parity class, a class uses 1-2 taps)
+    auto tile_taps = [&](int m0) __attribute__((always_inline)) {
+        unsigned mk = 0x7f;
+        if (mask32) {
+            mk = 0;
+#pragma unroll
+            for (int g2 = 0; g2 < BM / 32; ++g2)
+                if (m0 + 32 * g2 < M) mk |= mask32[((m0 + 32 * g2) % Pd) >> 5];
+            if (mk == 0) mk = 1;                         // never an empty step list
+        }
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)mk);
+    };
     auto load_slow = [&](int m0) {                       // bit 7*i + t: row i of this lane is slow for tap t
         unsigned sl = 0;
+        if (slowtab) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int m = m0 + 8 * (wave + 4 * i) + rsub;
-            if (m < M) sl |= (unsigned)(slowtab[m % Pd] & 0x7f) << (7 * i);
+            for (int i = 0; i < RA; ++i) {
+                const int m = m0 + 8 * (wave + 4 * i) + rsub;
+                if (m < M) sl |= (unsigned)(slowtab[perm ? perm[m % Pd] : m % Pd] & 0x7f) << (7 * i);
+            }
         }
         return sl;
     };
@@ -447,11 +462,12 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     int has_next = next_tile < ntiles;
     int nm0 = m0, nn0 = n0;
     if (has_next) tile_origin(next_tile, nm0, nn0);
-    int i_t = 0, i_kc = 0, i_ring = 0, i_own = 1, i_live = 1;   // DMA pointer; i_own: still inside the compute tile
+    unsigned mask_c = tile_taps(m0), mask_n = has_next ? tile_taps(nm0) : 0x7fu;   // taps of the compute / next tile
+    int i_t = __ffs(mask_c) - 1, i_kc = 0, i_ring = 0, i_own = 1, i_live = 1;       // DMA pointer; i_own: inside compute tile
     f32x4 ex[RA];
     unsigned pbase[RA];                                   // row offsets of the next stage to be issued (prefetched)
 #pragma unroll
-    for (int i = 0; i < RA; ++i) pbase[i] = otab[8 * (wave + 4 * i) + rsub];
+    for (int i = 0; i < RA; ++i) pbase[i] = otab[i_t * BM + 8 * (wave + 4 * i) + rsub];
     unsigned p_slow = 0;                                  // slow rows (bit 7*i) of the stage issued this step
     int p_ring = 0, issued = 0;
     // Issue the stage under the DMA pointer (slow-row loads first, then the DMA with those lanes masked off),
@@ -472,7 +488,7 @@ _Pragma("unroll") \
                 for (int i = 0; i < RA; ++i) { \
                     if (!((p_slow >> (i * 7)) & 1)) continue; \
                     const int row = 8 * (wave + 4 * i) + rsub, m = tm0 + row; \
-                    const int b = m / Pd, p = m % Pd, ch = kc * BK + 4 * (pc ^ swz(row)); \
+                    const int b = m / Pd, p = perm ? perm[m % Pd] : m % Pd, ch = kc * BK + 4 * (pc ^ swz(row)); \
                     f32x4 v = {0.f, 0.f, 0.f, 0.f}; \
                     for (int e = 0; e < E; ++e) { \
                         const int32_t c = idx[(size_t)(t * E + e) * Pd + p]; \
@@ -496,12 +512,18 @@ _Pragma("unroll") \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)lds_dst, 16, bconst[i], b_soff, 0, 0); \
             } \
             i_ring = i_ring == 2 ? 0 : i_ring + 1; \
-            if (++i_t == 7) { \
-                i_t = 0; \
-                if (++i_kc == nk) { \
-                    i_kc = 0; \
-                    if (i_own && has_next) i_own = 0; \
-                    else i_live = 0; \
+            { \
+                unsigned mk_ = i_own ? mask_c : mask_n; \
+                const unsigned higher_ = mk_ & ~((2u << i_t) - 1u); \
+                if (higher_) { \
+                    i_t = __ffs(higher_) - 1; \
+                } else { \
+                    if (++i_kc == nk) { \
+                        i_kc = 0; \
+                        if (i_own && has_next) { i_own = 0; mk_ = mask_n; } \
+                        else i_live = 0; \
+                    } \
+                    i_t = __ffs(mk_) - 1; \
                 } \
             } \
             if (i_live) { \
@@ -536,6 +558,7 @@ _Pragma("unroll") \
             build_table(slot ^ 1, nm0);
             slow_n = load_slow(nm0);
         }
+        const int S = __popc(mask_c) * nk;                // K-steps of this tile
         for (int step = 0; step < S; ++step) {
             frag0(c_ring);
             ICN_ISSUE_STAGE();                            // stage s+2
@@ -553,7 +576,10 @@ _Pragma("unroll") \
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < M) dst[(size_t)m * N + col] = acc[i][j][r] + bv;
+                    if (m < M) {
+                        const size_t drow = perm ? (size_t)(m / Pd) * Pd + perm[m % Pd] : (size_t)m;
+                        dst[drow * N + col] = acc[i][j][r] + bv;
+                    }
                 }
         }
         if (!has_next) break;
@@ -562,11 +588,15 @@ _Pragma("unroll") \
         m0 = nm0;
         n0 = nn0;
         slow_c = slow_n;
+        mask_c = mask_n;
         slot ^= 1;
         i_own = 1;                                        // the DMA pointer is already inside this tile
         next_tile = tile + gridDim.x;
         has_next = next_tile < ntiles;
-        if (has_next) tile_origin(next_tile, nm0, nn0);
+        if (has_next) {
+            tile_origin(next_tile, nm0, nn0);
+            mask_n = tile_taps(nm0);
+        }
     }
 #undef ICN_ISSUE_STAGE
 #undef ICN_RETIRE_AND_PUBLISH
@@ -588,7 +618,8 @@ static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
     const unsigned src_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.Ps * a.K * 4);
     prof_mark_begin(BM == 64 ? (BN == 128 ? PROF_DMA_64x128 : PROF_DMA_64x64) : (BN == 128 ? PROF_DMA_128x128 : PROF_DMA_128x64),
                     a.algo_flops, s);
-    hipLaunchKernelGGL((k_conv_dma<BM, BN>), dim3(grid), dim3(256), lds, s, a.src, a.wt, a.bias, a.dst, a.idx, a.slow, a.M,
+    hipLaunchKernelGGL((k_conv_dma<BM, BN>), dim3(grid), dim3(256), lds, s, a.src, a.wt, a.bias, a.dst, a.idx, a.slow, a.perm,
+                       a.mask32, a.M,
                        a.Ps, a.Pd, a.K, a.N, a.E, a.ns, src_bytes, ntiles);
     prof_mark_end(s);
 }
@@ -596,8 +627,8 @@ static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
 static bool conv_dma_usable(const GatherGemmArgs& a) {
     if (dbg_flags() & 16) return false;
     const size_t src_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.K * 4, wt_bytes = (size_t)7 * a.N * a.K * 4;
-    return a.perm == nullptr && a.mask32 == nullptr && a.slow != nullptr && src_bytes < ((size_t)1 << 31) &&
-           wt_bytes < ((size_t)1 << 31);
+    if (a.E != 1 && a.slow == nullptr) return false;      // multi-entry tables need their slow-row mask
+    return src_bytes < ((size_t)1 << 31) && wt_bytes < ((size_t)1 << 31);
 }
 
 // Tile shape of the persistent kernel.  `occ` blocks share a CU's MFMA pipes and a block runs ceil(tiles / grid) tiles
@@ -982,20 +1013,40 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
 }
 
 // dw[co][ci][t] = sum_s partial[s][t][ci][co];   dbias[co] = sum_s bias_partial[s][co]
-__global__ void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
-                               const float* __restrict__ bias_partial, float* __restrict__ dbias, int S, int Cin, int Cout) {
+// A block owns 64 consecutive elements of the [t][ci][co] slab layout (plus, past the weights, of the bias row); its
+// four waves each sum a quarter of the S slabs (256-byte coalesced reads, independent loads), the quarters are
+// combined in a fixed order through LDS (deterministic), and wave 0 stores into the (Cout, Cin, 7) parameter layout.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
+                                                       const float* __restrict__ bias_partial, float* __restrict__ dbias, int S,
+                                                       int Cin, int Cout) {
+    __shared__ float red[4][64];
     const int total = 7 * Cin * Cout;
-    const int total2 = total + (dbias ? Cout : 0);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        if (i < total) {
-            for (int k = 0; k < S; ++k) s += partial[(size_t)k * total + i];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;                  // element of [weights | bias]
+    const bool is_w = i < total, is_b = !is_w && dbias != nullptr && i - total < Cout;
+    const float* src = is_w ? partial + i : bias_partial + (i - total);
+    const size_t stride = is_w ? (size_t)total : (size_t)Cout;
+    const int k0 = (S * q) / 4, k1 = (S * (q + 1)) / 4;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (is_w || is_b) {
+        int k = k0;
+        for (; k + 3 < k1; k += 4) {
+            s0 += src[(size_t)k * stride];
+            s1 += src[(size_t)(k + 1) * stride];
+            s2 += src[(size_t)(k + 2) * stride];
+            s3 += src[(size_t)(k + 3) * stride];
+        }
+        for (; k < k1; ++k) s0 += src[(size_t)k * stride];
+    }
+    red[q][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (is_w) {
             const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cin * Cout);
-            dw[((size_t)co * Cin + ci) * 7 + t] = s;
-        } else {
-            const int c = i - total;
-            for (int k = 0; k < S; ++k) s += bias_partial[(size_t)k * Cout + c];
-            dbias[c] = s;
+            dw[((size_t)co * Cin + ci) * 7 + t] = v;
+        } else if (is_b) {
+            dbias[i - total] = v;
         }
     }
 }
@@ -1187,9 +1238,9 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k_wgrad_generic, grid, dim3(256), 0, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M, a.Ps,
                            a.Pd, a.Cin, a.Cout, a.ns, rows);
     }
-    const int total = 7 * a.Cin * a.Cout + a.Cout;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, s, a.partial, a.dw, a.bias_partial, a.dbias,
-                       S, a.Cin, a.Cout);
+    const int elems = 7 * a.Cin * a.Cout + a.Cout;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems + 63) / 64), dim3(256), 0, s, a.partial, a.dw, a.bias_partial, a.dbias, S,
+                       a.Cin, a.Cout);
 }
 
 // ---------------------------------------------------------------------------------------------------------

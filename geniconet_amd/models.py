@@ -58,8 +58,13 @@ class BasicIcoS2SUpBlock(nn.Module):
         self.icobn10 = nn.BatchNorm2d(out_features)
 
     def forward(self, x):
-        main = self.icobn01(self.conv01(F.relu(self.icobn00(self.conv00(self.upsample00(x))))))
-        skip = self.icobn10(self.conv10(self.upsample10(x)))
+        # upsample00 and upsample10 are parameter-free and see the same input (reference models.py:59-60): compute the
+        # r -> r+1 upsample once and let autograd sum the two gradients, unless someone hooked upsample10 itself.
+        up = self.upsample00(x)
+        hooked = self.upsample10._forward_hooks or self.upsample10._forward_pre_hooks
+        up_skip = self.upsample10(x) if hooked else up
+        main = self.icobn01(self.conv01(F.relu(self.icobn00(self.conv00(up)))))
+        skip = self.icobn10(self.conv10(up_skip))
         return F.relu(main + skip)
 
 
