@@ -102,10 +102,18 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py: no GPU visible; the HIP path has no CPU fallback')
+    # Rehearsal switch for a 1-GPU box (never set by the driver): all ranks share device 0 and talk over gloo, which
+    # exercises the same DDP wiring (bucketing, hooks on the custom autograd ops) without RCCL.
+    rehearsal = os.environ.get('ICN_BENCH_REHEARSAL', '') == '1'
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)      # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)      # RCCL over xGMI
 
     _lib.lib()
     p = models.default_params(cfg['model'], subdivisions=cfg['R'])
@@ -115,7 +123,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local])
+            if rehearsal:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

@@ -50,6 +50,7 @@ struct ConvTables {
     uint8_t* vslow = nullptr;     // [nv] taps of each virtual row that are pole means
     int32_t* vq = nullptr;        // [nv] target input pixel (sorted)
     int32_t* perm = nullptr;   // [Pin] (stride 2 only)
+    int32_t* bwd_perm = nullptr;  // [7][E][Pin] transposed table in permuted row order (stride 2 only)
     uint8_t* mask32 = nullptr; // [Pin/32] (stride 2 only)
 };
 struct UpTables {
@@ -102,6 +103,11 @@ const ConvTables& conv_tables(int r_in, int stride, int mode) {
         icn::build_bwd_row_order(r_in, stride, bwd, t.E, perm, mask);
         t.perm = upload(perm);
         t.mask32 = upload(mask);
+        // the same table in permuted row order (row k of a sample = pixel perm[k]): one load level in the kernels
+        std::vector<int32_t> bwd_p(bwd.size());
+        for (int te = 0; te < icn::NTAPS * t.E; ++te)
+            for (int k = 0; k < t.Pin; ++k) bwd_p[(size_t)te * t.Pin + k] = bwd[(size_t)te * t.Pin + perm[k]];
+        t.bwd_perm = upload(bwd_p);
     }
     return g_conv.emplace(key, t).first->second;
 }
@@ -310,7 +316,8 @@ int icn_conv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin
             // over "virtual rows" adds the rest; where they are many (coarse levels: 23 % of the rows at r = 3) the
             // kernel's in-line multi-entry path is cheaper than a second launch.
             const bool split = stride == 1 && t.nv > 0 && t.nv * 8 < t.Pin;
-            icn::GatherGemmArgs a{dy, wb, nullptr, dx, split ? t.bwd1 : t.bwd, split ? t.bwd1_slow : t.bwd_slow,
+            icn::GatherGemmArgs a{dy, wb, nullptr, dx, split ? t.bwd1 : (stride == 2 ? t.bwd_perm : t.bwd),
+                                  split ? t.bwd1_slow : (stride == 2 ? nullptr : t.bwd_slow),
                                   t.perm, t.mask32, B * t.Pin, t.Pout, t.Pin, Cout, Cin, split ? 1 : t.E, t.n_out,
                                   2.0 * 7 * Cin * Cout * (double)B * t.Pout};
             icn::launch_gather_gemm_auto(a, s);

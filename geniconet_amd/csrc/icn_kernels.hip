@@ -123,9 +123,8 @@ __global__ __launch_bounds__(256) void k_gather_gemm(
         const int m = m0 + row;
         int32_t code = -1;
         if (m < M) {
-            const int b = m / Pd, kk = m % Pd;
-            const int q = perm ? perm[kk] : kk;
-            const int32_t v = idx[(size_t)te * Pd + q];
+            const int b = m / Pd, kk = m % Pd;         // idx is in row order (pre-permuted when perm != null)
+            const int32_t v = idx[(size_t)te * Pd + kk];
             code = v >= 0 ? b * Ps + v : v;
         }
         s_code[i] = code;
@@ -364,7 +363,7 @@ __global__ __launch_bounds__(256) void k_conv_dma(
             const int t = e / BM, row = e % BM, m = m0 + row;
             unsigned base = OOB_OFFSET;
             if (m < M) {
-                const int b = m / Pd, p = perm ? perm[m % Pd] : m % Pd;
+                const int b = m / Pd, p = m % Pd;        // idx / slowtab are in ROW order (pre-permuted when perm != null)
                 const int32_t c = idx[(size_t)(t * E) * Pd + p];
                 if (c >= 0) base = (unsigned)(b * Ps + c) * (unsigned)K * 4u;
             }
@@ -389,7 +388,7 @@ __global__ __launch_bounds__(256) void k_conv_dma(
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 const int m = m0 + 8 * (wave + 4 * i) + rsub;
-                if (m < M) sl |= (unsigned)(slowtab[perm ? perm[m % Pd] : m % Pd] & 0x7f) << (7 * i);
+                if (m < M) sl |= (unsigned)(slowtab[m % Pd] & 0x7f) << (7 * i);
             }
         }
         return sl;
@@ -488,7 +487,7 @@ _Pragma("unroll") \
                 for (int i = 0; i < RA; ++i) { \
                     if (!((p_slow >> (i * 7)) & 1)) continue; \
                     const int row = 8 * (wave + 4 * i) + rsub, m = tm0 + row; \
-                    const int b = m / Pd, p = perm ? perm[m % Pd] : m % Pd, ch = kc * BK + 4 * (pc ^ swz(row)); \
+                    const int b = m / Pd, p = m % Pd, ch = kc * BK + 4 * (pc ^ swz(row)); \
                     f32x4 v = {0.f, 0.f, 0.f, 0.f}; \
                     for (int e = 0; e < E; ++e) { \
                         const int32_t c = idx[(size_t)(t * E + e) * Pd + p]; \
@@ -628,6 +627,9 @@ static bool conv_dma_usable(const GatherGemmArgs& a) {
     if (dbg_flags() & 16) return false;
     const size_t src_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.K * 4, wt_bytes = (size_t)7 * a.N * a.K * 4;
     if (a.E != 1 && a.slow == nullptr) return false;      // multi-entry tables need their slow-row mask
+    // The cross-tile pipeline needs >= 3 K-steps per tile: the DMA pointer runs 2 steps ahead and the next tile's
+    // offset table is published by the barrier of the tile's first step.  With tap masks a tile may use a single tap.
+    if ((a.mask32 ? 1 : 7) * (a.K / BK) < 3) return false;
     return src_bytes < ((size_t)1 << 31) && wt_bytes < ((size_t)1 << 31);
 }
 

@@ -86,7 +86,7 @@ class KLD_Loss(torch.nn.Module):
         return self.loss
 
     def get_last_losses(self):
-        return 0, 0, 0, 0, -float(self.loss)
+        return 0, 0, 0, 0, -float(self.loss.detach())
 
     def get_factor(self):
         return self.factor_kl
@@ -118,4 +118,4 @@ class P2PKLD_Loss(P2P_Loss, KLD_Loss):
         return self.loss
 
     def get_last_losses(self):
-        return float(self.recons_loss), 0, 0, -float(self.kld_loss), float(self.loss)
+        return float(self.recons_loss.detach()), 0, 0, -float(self.kld_loss.detach()), float(self.loss.detach())

@@ -44,13 +44,20 @@ MFMA_CASES = [
     (4, 2, 64, 128, 1, 'zeros'), (2, 1, 96, 192, 2, 'average'), (1, 1, 64, 64, 1, 'average'),
     (5, 1, 128, 128, 1, 'average'),
 ]
+# odd-but-legal shapes: K = 32 / 64 (short tiles; stride-2 dgrad with Cout = 64 must take the register-staged kernel),
+# N = 192 / 320, single sample, coarsest levels, 'zeros' corners with multi-entry transposed taps
+EDGE_CASES = [
+    (3, 2, 64, 64, 2, 'average'), (4, 2, 128, 64, 1, 'average'), (2, 1, 32, 64, 2, 'average'), (3, 1, 64, 192, 1, 'zeros'),
+    (1, 1, 128, 128, 3, 'average'), (0, 1, 64, 64, 5, 'average'), (1, 2, 64, 128, 4, 'zeros'), (3, 2, 96, 160, 2, 'average'),
+    (4, 1, 64, 320, 1, 'average'), (5, 2, 64, 128, 2, 'zeros'),
+]
 SCALAR_CASES = [
     (2, 1, 3, 64, 2, 'average'), (1, 1, 5, 7, 2, 'average'), (2, 2, 3, 8, 2, 'zeros'), (0, 1, 4, 4, 2, 'average'),
     (3, 1, 3, 64, 2, 'zeros'), (2, 1, 64, 3, 2, 'average'), (1, 2, 33, 65, 1, 'average'),
 ]
 
 
-@pytest.mark.parametrize('case', MFMA_CASES + SCALAR_CASES, ids=lambda c: 'r%d_s%d_%dx%d_b%d_%s' % c)
+@pytest.mark.parametrize('case', MFMA_CASES + EDGE_CASES + SCALAR_CASES, ids=lambda c: 'r%d_s%d_%dx%d_b%d_%s' % c)
 def test_conv_forward_backward(case):
     for k, (got, want) in conv_both(*case, seed=11).items():
         assert got.shape == want.shape, k
@@ -200,6 +207,24 @@ def test_full_size_backward_is_the_adjoint():
     (dx,) = torch.autograd.grad(u, x, gu)
     lhs = float((u.detach().double() * gu.double()).sum())
     assert abs(lhs - float((x.detach().double() * dx.double()).sum())) < 1e-6 * abs(lhs) + 1e-3
+
+
+def test_vae_training_step_and_i6_forward():
+    """BASELINE configs 4 and 5 in miniature: a VAE step with the P2P+KLD loss, and the AE built at subdivisions=6."""
+    from geniconet_amd import data, models
+    from geniconet_amd.train import Trainer
+    p = models.default_params('ico2ico_vae', subdivisions=4)
+    tr = Trainer(p, 'cuda', seed=0)
+    x, t = data.synthetic_batch(3, 4, seed=2, device='cuda')
+    l0 = float(tr.step(x, t))
+    assert np.isfinite(l0)
+    rec, kld = tr.criterion.get_last_losses()[0], tr.criterion.get_last_losses()[3]
+    assert np.isfinite(rec) and np.isfinite(kld)
+    net6 = models.ico2ico(models.default_params('ico2ico', subdivisions=6)).cuda()
+    x6, _ = data.synthetic_batch(1, 6, seed=3, device='cuda')
+    with torch.no_grad():
+        y6 = net6(x6)
+    assert y6.shape == (1, 3, 320, 128) and bool(torch.isfinite(y6).all())
 
 
 def test_training_step_runs_and_decreases_loss():
