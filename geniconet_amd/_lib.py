@@ -32,6 +32,10 @@ SIGNATURES = {
     'icn_conv_bwd_weight': (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'icn_upsample_fwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'icn_upsample_bwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    'icn_bn_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),
+    'icn_bn_stats': (ctypes.c_int, [_c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float] + [_c_float_p] * 4 + [ctypes.c_void_p]),
+    'icn_bn_relu_fwd': (ctypes.c_int, [_c_float_p] * 9 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
+    'icn_bn_relu_bwd': (ctypes.c_int, [_c_float_p] * 12 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     'icn_table_conv_fwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t]),
     'icn_table_conv_bwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t, _intp]),
     'icn_table_upsample': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, _f32p, ctypes.c_size_t, _intp]),

@@ -384,6 +384,52 @@ int icn_upsample_bwd(const float* dy, float* dx, int B, int C, int r_in, int cor
     }
 }
 
+// ---- fused BatchNorm + ReLU ---------------------------------------------------------------------------------
+size_t icn_bn_workspace_floats(int M, int C) { return (M < 1 || C < 1) ? 0 : (size_t)icn::bn_chunks(M) * 3 * C; }
+
+int icn_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
+                 float* ws, void* stream) {
+    try {
+        if (!x || !stat || !ws || M < 1) throw std::invalid_argument("icn_bn_stats: bad arguments");
+        if (!icn::bn_supported(C)) throw std::invalid_argument("icn_bn_stats: unsupported channel count");
+        icn::launch_bn_stats(x, M, C, eps, momentum, running_mean, running_var, stat, ws, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* gamma_a,
+                    const float* beta_a, const float* gamma_b, const float* beta_b, float* y, int M, int C, void* stream) {
+    try {
+        if (!a || !stat_a || !gamma_a || !beta_a || !y || M < 1) throw std::invalid_argument("icn_bn_relu_fwd: bad arguments");
+        if (b && (!stat_b || !gamma_b || !beta_b)) throw std::invalid_argument("icn_bn_relu_fwd: second input needs its stats");
+        if (!icn::bn_supported(C)) throw std::invalid_argument("icn_bn_relu_fwd: unsupported channel count");
+        icn::launch_bn_relu_fwd(a, b, stat_a, stat_b, gamma_a, beta_a, gamma_b, beta_b, y, M, C, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_bn_relu_bwd(const float* dy, const float* y, const float* a, const float* b, const float* stat_a, const float* stat_b,
+                    const float* gamma_a, const float* gamma_b, float* da, float* db, float* sums, float* ws, int M, int C,
+                    void* stream) {
+    try {
+        if (!dy || !y || !a || !stat_a || !gamma_a || !da || !sums || !ws || M < 1)
+            throw std::invalid_argument("icn_bn_relu_bwd: bad arguments");
+        if (b && (!stat_b || !gamma_b || !db)) throw std::invalid_argument("icn_bn_relu_bwd: second input needs its buffers");
+        if (!icn::bn_supported(C)) throw std::invalid_argument("icn_bn_relu_bwd: unsupported channel count");
+        icn::launch_bn_relu_bwd(dy, y, a, b, stat_a, stat_b, gamma_a, gamma_b, da, db, sums, ws, M, C, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
 // ---- host-side introspection ----------------------------------------------------------------------------
 long icn_table_conv_fwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap) {
     try {

@@ -1,0 +1,201 @@
+// Fused BatchNorm (+ residual) + ReLU of the residual blocks, training mode, channels-last rows (M = B*P, C).
+//
+// Replaces the torch builtins the reference strings together inside BasicIcoS2SDownBlock / UpBlock
+// (models.py:36-40,58-62):   relu(bn(x))   and   relu(bn_a(a) + bn_b(b)).
+// All kernels are HBM-bound streaming passes; sums are reduced in two deterministic stages (row chunks -> finalize).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "icn_launch.h"
+
+namespace icn {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ f32x4 ldv(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void stv(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+
+constexpr int BN_MAX_CHUNKS = 512;
+
+// partial[chunk][k][C], k < NS: per-channel sums of NS quantities over the chunk's rows.
+//   MODE 0 (forward stats of x):                 k0 = sum x,        k1 = sum x^2
+//   MODE 1 (backward of relu(bn(x))):            k0 = sum g,        k1 = sum g * xhat         g = dy * (y > 0)
+//   MODE 2 (backward of relu(bn_a(a)+bn_b(b))):  k0 = sum g,        k1 = sum g * ahat,  k2 = sum g * bhat
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                     const float* __restrict__ p2, const float* __restrict__ p3,
+                                                     const float* __restrict__ stat_a, const float* __restrict__ stat_b,
+                                                     float* __restrict__ partial, int M, int C, int rows_per_chunk) {
+    constexpr int NS = MODE == 2 ? 3 : 2;
+    __shared__ f32x4 red[NS][256];
+    const int c4n = C / 4, stripes = 256 / c4n;
+    const int cq = threadIdx.x % c4n, stripe = threadIdx.x / c4n, c = cq * 4;
+    const int r0 = blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    f32x4 s[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 mean_a{}, inv_a{}, mean_b{}, inv_b{};
+    if (MODE >= 1) { mean_a = ldv(stat_a + c); inv_a = ldv(stat_a + C + c); }
+    if (MODE == 2) { mean_b = ldv(stat_b + c); inv_b = ldv(stat_b + C + c); }
+    if (stripe < stripes) {
+        for (int r = r0 + stripe; r < r1; r += stripes) {
+            const size_t o = (size_t)r * C + c;
+            if (MODE == 0) {
+                const f32x4 x = ldv(p0 + o);
+                s[0] += x;
+                s[1] += x * x;
+            } else {
+                // p0 = dy, p1 = y (output of the fused op), p2 = x / a, p3 = b
+                const f32x4 dy = ldv(p0 + o), y = ldv(p1 + o);
+                f32x4 g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = y[j] > 0.f ? dy[j] : 0.f;
+                s[0] += g;
+                s[1] += g * ((ldv(p2 + o) - mean_a) * inv_a);
+                if (MODE == 2) s[2] += g * ((ldv(p3 + o) - mean_b) * inv_b);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) red[k][threadIdx.x] = s[k];
+    __syncthreads();
+    if (stripe == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            f32x4 t = red[k][cq];
+            for (int q = 1; q < stripes; ++q) t += red[k][q * c4n + cq];
+            stv(partial + ((size_t)blockIdx.x * NS + k) * C + c, t);
+        }
+    }
+}
+
+// sum over chunks of partial[chunk][k][C] for 16 channels per block: 16 slices of the chunk range per channel, combined
+// through LDS in a fixed order (deterministic).  Returns the total in every thread with slice == 0.
+__device__ __forceinline__ double chunk_sum(const float* __restrict__ partial, int chunks, int NS, int k, int C, int c,
+                                            int slice, double (*red)[16]) {
+    // 16 slices x 4 independent float chains per thread (the loads pipeline), combined in double
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        const float* p = partial + (size_t)k * C + c;
+        const size_t st = (size_t)NS * C;
+        int j = slice;
+        for (; j + 48 < chunks; j += 64) {
+            s0 += p[(size_t)j * st];
+            s1 += p[(size_t)(j + 16) * st];
+            s2 += p[(size_t)(j + 32) * st];
+            s3 += p[(size_t)(j + 48) * st];
+        }
+        for (; j < chunks; j += 16) s0 += p[(size_t)j * st];
+    }
+    red[slice][threadIdx.x % 16] = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+    __syncthreads();
+    double t = 0.0;
+    if (slice == 0)
+        for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x % 16];
+    __syncthreads();
+    return t;
+}
+
+// forward finalize: mean / invstd of the batch, running statistics (momentum, unbiased variance); 16 channels per block
+__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ partial, int chunks, int M, int C, float eps,
+                                                          float momentum, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ stat) {
+    __shared__ double red[16][16];
+    const int c = blockIdx.x * 16 + threadIdx.x % 16, slice = threadIdx.x / 16;
+    const double s = chunk_sum(partial, chunks, 2, 0, C, c, slice, red);
+    const double s2 = chunk_sum(partial, chunks, 2, 1, C, c, slice, red);
+    if (slice != 0 || c >= C) return;
+    const double mean = s / M;
+    double var = s2 / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[c] = (float)mean;
+    stat[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * M / (M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// backward finalize: sums[k][C] = sum over chunks (k < NS); blockIdx.y = k
+__global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict__ partial, int chunks, int C, int NS,
+                                                          float* __restrict__ sums) {
+    __shared__ double red[16][16];
+    const int c = blockIdx.x * 16 + threadIdx.x % 16, slice = threadIdx.x / 16, k = blockIdx.y;
+    const double s = chunk_sum(partial, chunks, NS, k, C, c, slice, red);
+    if (slice == 0 && c < C) sums[k * C + c] = (float)s;
+}
+
+// y = relu(bn_a(a) [+ bn_b(b)])
+template <int DUAL>
+__global__ void k_bn_relu_fwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ stat_a,
+                              const float* __restrict__ stat_b, const float* __restrict__ ga, const float* __restrict__ ba,
+                              const float* __restrict__ gb, const float* __restrict__ bb, float* __restrict__ y, size_t total4,
+                              int C) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        f32x4 v = (ldv(a + i * 4) - ldv(stat_a + c)) * (ldv(stat_a + C + c) * ldv(ga + c)) + ldv(ba + c);
+        if (DUAL) v += (ldv(b + i * 4) - ldv(stat_b + c)) * (ldv(stat_b + C + c) * ldv(gb + c)) + ldv(bb + c);
+        stv(y + i * 4, relu4(v));
+    }
+}
+
+// dx = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M),   g = dy * (y > 0)      (and the same for b when DUAL)
+template <int DUAL>
+__global__ void k_bn_relu_bwd(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ a,
+                              const float* __restrict__ b, const float* __restrict__ stat_a, const float* __restrict__ stat_b,
+                              const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ sums,
+                              float* __restrict__ da, float* __restrict__ db, size_t total4, int C, float inv_m) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 d = ldv(dy + i * 4), yy = ldv(y + i * 4);
+        f32x4 g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = yy[j] > 0.f ? d[j] : 0.f;
+        const f32x4 sg = ldv(sums + c) * inv_m;
+        {
+            const f32x4 inv = ldv(stat_a + C + c), xh = (ldv(a + i * 4) - ldv(stat_a + c)) * inv;
+            stv(da + i * 4, ldv(ga + c) * inv * (g - sg - xh * (ldv(sums + C + c) * inv_m)));
+        }
+        if (DUAL) {
+            const f32x4 inv = ldv(stat_b + C + c), xh = (ldv(b + i * 4) - ldv(stat_b + c)) * inv;
+            stv(db + i * 4, ldv(gb + c) * inv * (g - sg - xh * (ldv(sums + 2 * C + c) * inv_m)));
+        }
+    }
+}
+
+bool bn_supported(int C) { return C >= 4 && C <= 1024 && C % 4 == 0 && 256 % (C / 4) == 0; }
+int bn_chunks(int M) { return std::min(BN_MAX_CHUNKS, (M + 63) / 64); }
+
+static int stream_blocks(size_t total4) { return (int)std::min((size_t)8192, (total4 + 255) / 256); }
+
+void launch_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
+                     float* ws, hipStream_t s) {
+    const int chunks = bn_chunks(M), rows = (M + chunks - 1) / chunks;
+    hipLaunchKernelGGL(k_bn_partial<0>, dim3(chunks), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, rows);
+    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 15) / 16), dim3(256), 0, s, ws, chunks, M, C, eps, momentum, running_mean,
+                       running_var, stat);
+}
+
+void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga, const float* ba,
+                        const float* gb, const float* bb, float* y, int M, int C, hipStream_t s) {
+    const size_t total4 = (size_t)M * C / 4;
+    if (b) hipLaunchKernelGGL(k_bn_relu_fwd<1>, dim3(stream_blocks(total4)), dim3(256), 0, s, a, b, stat_a, stat_b, ga, ba, gb, bb, y, total4, C);
+    else hipLaunchKernelGGL(k_bn_relu_fwd<0>, dim3(stream_blocks(total4)), dim3(256), 0, s, a, b, stat_a, stat_b, ga, ba, gb, bb, y, total4, C);
+}
+
+void launch_bn_relu_bwd(const float* dy, const float* y, const float* a, const float* b, const float* stat_a, const float* stat_b,
+                        const float* ga, const float* gb, float* da, float* db, float* sums, float* ws, int M, int C, hipStream_t s) {
+    const int chunks = bn_chunks(M), rows = (M + chunks - 1) / chunks;
+    const int NS = b ? 3 : 2;
+    if (b) hipLaunchKernelGGL(k_bn_partial<2>, dim3(chunks), dim3(256), 0, s, dy, y, a, b, stat_a, stat_b, ws, M, C, rows);
+    else hipLaunchKernelGGL(k_bn_partial<1>, dim3(chunks), dim3(256), 0, s, dy, y, a, b, stat_a, stat_b, ws, M, C, rows);
+    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((C + 15) / 16, NS), dim3(256), 0, s, ws, chunks, C, NS, sums);
+    const size_t total4 = (size_t)M * C / 4;
+    if (b) hipLaunchKernelGGL(k_bn_relu_bwd<1>, dim3(stream_blocks(total4)), dim3(256), 0, s, dy, y, a, b, stat_a, stat_b, ga, gb, sums, da, db, total4, C, 1.f / M);
+    else hipLaunchKernelGGL(k_bn_relu_bwd<0>, dim3(stream_blocks(total4)), dim3(256), 0, s, dy, y, a, b, stat_a, stat_b, ga, gb, sums, da, db, total4, C, 1.f / M);
+}
+
+}  // namespace icn

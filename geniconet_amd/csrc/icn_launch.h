@@ -51,6 +51,16 @@ void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int 
 
 void launch_pack_weights(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t s);
 
+// ---- fused BatchNorm (+ residual) + ReLU (icn_bn.hip); stat = [mean | invstd] (2*C), sums = NS*C, ws = chunks*NS*C floats
+bool bn_supported(int C);
+int bn_chunks(int M);
+void launch_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
+                     float* ws, hipStream_t s);
+void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga, const float* ba,
+                        const float* gb, const float* bb, float* y, int M, int C, hipStream_t s);
+void launch_bn_relu_bwd(const float* dy, const float* y, const float* a, const float* b, const float* stat_a, const float* stat_b,
+                        const float* ga, const float* gb, float* da, float* db, float* sums, float* ws, int M, int C, hipStream_t s);
+
 // ---- optional per-launch HIP-event timing of the MFMA kernels (bench.py's live roofline measurement) ----------
 enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA_64x64, PROF_GG_128x128, PROF_GG_128x64,
                 PROF_GG_64x128, PROF_GG_64x64, PROF_WG_128x128, PROF_WG_128x64, PROF_WG_64x128, PROF_WG_64x64, PROF_KINDS };

@@ -1,0 +1,106 @@
+"""Fused BatchNorm (+ residual) + ReLU of the residual blocks on the HIP path.
+
+The reference strings torch builtins together (models.py:36-40,58-62):
+    relu(icobn00(conv00(.)))                      -> bn_relu(a, icobn00)
+    relu(icobn01(conv01(.)) + icobn10(conv10(.))) -> bn_add_relu(a, icobn01, b, icobn10)
+Here each is one autograd Function over libicn's icn_bn_* kernels (two streaming passes forward, two backward, instead
+of 4-7 separate elementwise passes).  The `nn.BatchNorm2d` modules stay in the module tree (state_dict keys, running
+statistics, `num_batches_tracked` are updated exactly as torch does in training mode); the fused path is only taken in
+training mode on ROCm tensors when nobody hooked those modules -- otherwise the modules are called as usual.
+"""
+import os
+
+import torch
+
+from . import _lib
+from .ico_conv import _nhwc, _stream
+
+_DISABLED = os.environ.get('ICN_NO_FUSED_BN', '') == '1'
+
+
+def can_fuse(x, *bns):
+    if _DISABLED or not x.is_cuda or x.dtype != torch.float32 or not torch.is_grad_enabled():
+        return False
+    for bn in bns:
+        if not (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None):
+            return False
+        if bn._forward_hooks or bn._forward_pre_hooks or bn._backward_hooks:
+            return False
+        c = bn.num_features
+        if c % 4 or c > 1024 or 256 % (c // 4):
+            return False
+    return True
+
+
+class _BnReluFn(torch.autograd.Function):
+    """y = relu(bn_a(a) [+ bn_b(b)]) with batch statistics; updates the running statistics in place."""
+
+    @staticmethod
+    def forward(ctx, a, ga, ba, rm_a, rv_a, eps_a, mom_a, b, gb, bb, rm_b, rv_b, eps_b, mom_b):
+        L = _lib.lib()
+        ap = _nhwc(a)
+        Bn, H, W, C = ap.shape
+        M = Bn * H * W
+        dual = b is not None
+        bp = _nhwc(b) if dual else None
+        dev = a.device
+        ws = torch.empty(L.icn_bn_workspace_floats(M, C), dtype=torch.float32, device=dev)
+        stat_a = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        stat_b = torch.empty(2 * C, dtype=torch.float32, device=dev) if dual else None
+        y = torch.empty_like(ap)
+        with torch.cuda.device(dev):
+            st = _stream()
+            _lib.check(L.icn_bn_stats(ap.data_ptr(), M, C, eps_a, mom_a, rm_a.data_ptr(), rv_a.data_ptr(), stat_a.data_ptr(),
+                                      ws.data_ptr(), st), 'icn_bn_stats')
+            if dual:
+                _lib.check(L.icn_bn_stats(bp.data_ptr(), M, C, eps_b, mom_b, rm_b.data_ptr(), rv_b.data_ptr(),
+                                          stat_b.data_ptr(), ws.data_ptr(), st), 'icn_bn_stats')
+            _lib.check(L.icn_bn_relu_fwd(ap.data_ptr(), bp.data_ptr() if dual else None, stat_a.data_ptr(),
+                                         stat_b.data_ptr() if dual else None, ga.data_ptr(), ba.data_ptr(),
+                                         gb.data_ptr() if dual else None, bb.data_ptr() if dual else None, y.data_ptr(), M, C,
+                                         st), 'icn_bn_relu_fwd')
+        ctx.save_for_backward(ap, bp, y, stat_a, stat_b, ga, gb)
+        ctx.dims = (M, C, dual)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        L = _lib.lib()
+        ap, bp, y, stat_a, stat_b, ga, gb = ctx.saved_tensors
+        M, C, dual = ctx.dims
+        gyp = _nhwc(gy)
+        dev = gyp.device
+        da = torch.empty_like(ap)
+        db = torch.empty_like(bp) if dual else None
+        sums = torch.empty(3 * C, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.icn_bn_workspace_floats(M, C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.icn_bn_relu_bwd(gyp.data_ptr(), y.data_ptr(), ap.data_ptr(), bp.data_ptr() if dual else None,
+                                         stat_a.data_ptr(), stat_b.data_ptr() if dual else None, ga.data_ptr(),
+                                         gb.data_ptr() if dual else None, da.data_ptr(), db.data_ptr() if dual else None,
+                                         sums.data_ptr(), ws.data_ptr(), M, C, _stream()), 'icn_bn_relu_bwd')
+        dbeta, dga = sums[:C], sums[C:2 * C]
+        out = [da.permute(0, 3, 1, 2), dga, dbeta, None, None, None, None]
+        if dual:
+            out += [db.permute(0, 3, 1, 2), sums[2 * C:3 * C], dbeta, None, None, None, None]
+        else:
+            out += [None] * 7
+        return tuple(out)
+
+
+def _args(bn):
+    return bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum)
+
+
+def bn_relu(a, bn):
+    """relu(bn(a)) -- training-mode BatchNorm2d `bn` (its running statistics are updated)."""
+    bn.num_batches_tracked.add_(1)
+    return _BnReluFn.apply(a, *_args(bn), None, None, None, None, None, 0.0, 0.0)
+
+
+def bn_add_relu(a, bn_a, b, bn_b):
+    """relu(bn_a(a) + bn_b(b))."""
+    bn_a.num_batches_tracked.add_(1)
+    bn_b.num_batches_tracked.add_(1)
+    return _BnReluFn.apply(a, *_args(bn_a), b, *_args(bn_b))

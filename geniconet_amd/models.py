@@ -13,6 +13,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from . import fused
 from .ico_conv import IcoConvS2S, IcoUpsampleS2S
 
 # channels after the stem and after each Down block (AE: 3 blocks -> R-3; VAE encoder: 2 blocks -> R-2)
@@ -36,6 +37,9 @@ class BasicIcoS2SDownBlock(nn.Module):
         self.icobn10 = nn.BatchNorm2d(out_features)
 
     def forward(self, x):
+        if fused.can_fuse(x, self.icobn00, self.icobn01, self.icobn10):    # same math, fused HIP BN / ReLU passes
+            h = fused.bn_relu(self.conv00(x), self.icobn00)
+            return fused.bn_add_relu(self.conv01(h), self.icobn01, self.conv10(x), self.icobn10)
         main = self.icobn01(self.conv01(F.relu(self.icobn00(self.conv00(x)))))
         skip = self.icobn10(self.conv10(x))
         return F.relu(main + skip)
@@ -63,6 +67,9 @@ class BasicIcoS2SUpBlock(nn.Module):
         up = self.upsample00(x)
         hooked = self.upsample10._forward_hooks or self.upsample10._forward_pre_hooks
         up_skip = self.upsample10(x) if hooked else up
+        if fused.can_fuse(x, self.icobn00, self.icobn01, self.icobn10):
+            h = fused.bn_relu(self.conv00(up), self.icobn00)
+            return fused.bn_add_relu(self.conv01(h), self.icobn01, self.conv10(up_skip), self.icobn10)
         main = self.icobn01(self.conv01(F.relu(self.icobn00(self.conv00(up)))))
         skip = self.icobn10(self.conv10(up_skip))
         return F.relu(main + skip)

@@ -71,6 +71,22 @@ int icn_conv_bwd_weight(const float* x, const float* dy, float* dw, float* dbias
 int icn_upsample_fwd(const float* x, float* y, int B, int C, int r_in, int corner_mode, void* stream);
 int icn_upsample_bwd(const float* dy, float* dx, int B, int C, int r_in, int corner_mode, void* stream);
 
+/* Fused BatchNorm + ReLU of the residual blocks (training mode; replaces the torch builtins at models.py:36-40,58-62).
+ * Tensors are channels-last rows (M = B * pixels, C), C in {64, 128, 256, 512, ...: C % 4 == 0 and 256 % (C/4) == 0}.
+ *   stat   [2*C]  batch mean | 1/sqrt(var + eps), written by icn_bn_stats and read by the other two
+ *   ws     at least icn_bn_workspace_floats(M, C) floats
+ * icn_bn_stats also updates running_mean / running_var (momentum, unbiased variance) when they are not NULL.
+ * icn_bn_relu_fwd : y = relu(bn_a(a) [+ bn_b(b)])            (b == NULL: single input)
+ * icn_bn_relu_bwd : da [, db], and sums[k*C + c]: k = 0 -> d(beta), 1 -> d(gamma_a), 2 -> d(gamma_b)           */
+size_t icn_bn_workspace_floats(int M, int C);
+int icn_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
+                 float* ws, void* stream);
+int icn_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* gamma_a,
+                    const float* beta_a, const float* gamma_b, const float* beta_b, float* y, int M, int C, void* stream);
+int icn_bn_relu_bwd(const float* dy, const float* y, const float* a, const float* b, const float* stat_a, const float* stat_b,
+                    const float* gamma_a, const float* gamma_b, float* da, float* db, float* sums, float* ws, int M, int C,
+                    void* stream);
+
 /* Host-side introspection (no device needed).  Each writes at most `cap` elements and returns the element
  * count required (negative on error). */
 long icn_table_conv_fwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap);      /* [7][P_out]     */

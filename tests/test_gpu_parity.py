@@ -209,6 +209,38 @@ def test_full_size_backward_is_the_adjoint():
     assert abs(lhs - float((x.detach().double() * dx.double()).sum())) < 1e-6 * abs(lhs) + 1e-3
 
 
+@pytest.mark.parametrize('C,dual', [(64, False), (128, True), (256, True), (512, False)])
+def test_fused_bn_relu_matches_torch_builtins(C, dual):
+    """icn_bn_* vs the chain of torch builtins it replaces (models.py:36-40): outputs, input/affine gradients,
+    running statistics and num_batches_tracked."""
+    from geniconet_amd import fused
+    torch.manual_seed(C)
+    mk = lambda: torch.nn.BatchNorm2d(C).cuda().train()
+    bn_a, bn_b, rf_a, rf_b = mk(), mk(), mk(), mk()
+    for m, r in ((bn_a, rf_a), (bn_b, rf_b)):
+        with torch.no_grad():
+            m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.5, 0.5)
+        r.load_state_dict(m.state_dict())
+    a = (torch.randn(3, C, 40, 16, device='cuda') * 2 + 0.3).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(3, C, 40, 16, device='cuda').contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(3, C, 40, 16, device='cuda')
+    a1, b1, a2, b2 = (t.clone().requires_grad_() for t in (a, b, a, b))
+    assert fused.can_fuse(a1, bn_a, bn_b)
+    y1 = fused.bn_add_relu(a1, bn_a, b1, bn_b) if dual else fused.bn_relu(a1, bn_a)
+    y2 = torch.relu(rf_a(a2) + rf_b(b2)) if dual else torch.relu(rf_a(a2))
+    y1.backward(gy); y2.backward(gy)
+    pairs = [(y1, y2), (a1.grad, a2.grad), (bn_a.weight.grad, rf_a.weight.grad), (bn_a.bias.grad, rf_a.bias.grad),
+             (bn_a.running_mean, rf_a.running_mean), (bn_a.running_var, rf_a.running_var)]
+    if dual:
+        pairs += [(b1.grad, b2.grad), (bn_b.weight.grad, rf_b.weight.grad), (bn_b.bias.grad, rf_b.bias.grad),
+                  (bn_b.running_var, rf_b.running_var)]
+    for got, want in pairs:
+        assert rel_l2(got.detach().cpu().numpy(), want.detach().cpu().numpy()) < 2e-5
+    assert int(bn_a.num_batches_tracked) == int(rf_a.num_batches_tracked) == 1
+    bn_a.eval()
+    assert not fused.can_fuse(a1, bn_a)
+
+
 def test_vae_training_step_and_i6_forward():
     """BASELINE configs 4 and 5 in miniature: a VAE step with the P2P+KLD loss, and the AE built at subdivisions=6."""
     from geniconet_amd import data, models
