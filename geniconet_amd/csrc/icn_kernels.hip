@@ -627,9 +627,10 @@ static bool conv_dma_usable(const GatherGemmArgs& a) {
     if (dbg_flags() & 16) return false;
     const size_t src_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.K * 4, wt_bytes = (size_t)7 * a.N * a.K * 4;
     if (a.E != 1 && a.slow == nullptr) return false;      // multi-entry tables need their slow-row mask
-    // The cross-tile pipeline needs >= 3 K-steps per tile: the DMA pointer runs 2 steps ahead and the next tile's
-    // offset table is published by the barrier of the tile's first step.  With tap masks a tile may use a single tap.
-    if ((a.mask32 ? 1 : 7) * (a.K / BK) < 3) return false;
+    // The cross-tile pipeline needs >= 4 K-steps per tile: the next tile's offset table is built in the tile's first
+    // step and published by that step's barrier, and the DMA pointer (2 steps ahead) prefetches the next stage's row
+    // offsets one step earlier still, i.e. in step S-3 >= 1.  With tap masks a tile may use a single tap.
+    if ((a.mask32 ? 1 : 7) * (a.K / BK) < 4) return false;
     return src_bytes < ((size_t)1 << 31) && wt_bytes < ((size_t)1 << 31);
 }
 
