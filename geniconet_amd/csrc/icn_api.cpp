@@ -430,6 +430,34 @@ int icn_bn_relu_bwd(const float* dy, const float* y, const float* a, const float
     }
 }
 
+// ---- fused 1x1 head + tanh ------------------------------------------------------------------------------------
+size_t icn_head_workspace_floats(int M, int Cin) { return (M < 1 || Cin < 1) ? 0 : (size_t)icn::head_chunks(M) * 4 * (Cin + 4); }
+
+int icn_head_fwd(const float* x, const float* w, const float* bias, float* y, int M, int Cin, int Cout, void* stream) {
+    try {
+        if (!x || !w || !bias || !y || M < 1) throw std::invalid_argument("icn_head_fwd: bad arguments");
+        if (!icn::head_supported(Cin, Cout)) throw std::invalid_argument("icn_head_fwd: unsupported channel counts");
+        icn::launch_head_fwd(x, w, bias, y, M, Cin, Cout, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_head_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
+                 int M, int Cin, int Cout, void* stream) {
+    try {
+        if (!dy || !y || !x || !w || !dw || !db || !ws || M < 1) throw std::invalid_argument("icn_head_bwd: bad arguments");
+        if (!icn::head_supported(Cin, Cout)) throw std::invalid_argument("icn_head_bwd: unsupported channel counts");
+        icn::launch_head_bwd(dy, y, x, w, dx, dw, db, ws, M, Cin, Cout, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
 // ---- host-side introspection ----------------------------------------------------------------------------
 long icn_table_conv_fwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap) {
     try {

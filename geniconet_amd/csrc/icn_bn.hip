@@ -199,3 +199,131 @@ void launch_bn_relu_bwd(const float* dy, const float* y, const float* a, const f
 }
 
 }  // namespace icn
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused head:  y = tanh(x @ W^T + b),  x (M, Cin) channels-last rows, W (Cout, Cin), Cout <= 4
+// (reference models.py:151-154: Conv2d(64, 3, kernel_size=1) + Tanh).  HBM-bound: Cin/4 lanes share a row
+// (one float4 each, coalesced), partial dot products are combined with wave shuffles.
+// ---------------------------------------------------------------------------------------------------------
+namespace icn {
+
+constexpr int HEAD_MAX_OUT = 4;
+
+template <int LPR>   // lanes per row = Cin / 4 (power of two, <= 64)
+__global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ y, int M, int Cout) {
+    constexpr int Cin = LPR * 4, RPB = 256 / LPR;         // rows per block pass
+    const int sub = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
+    f32x4 wv[HEAD_MAX_OUT];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_OUT; ++o) wv[o] = o < Cout ? ldv(w + o * Cin + 4 * sub) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = blockIdx.x * RPB + rloc; r < M; r += gridDim.x * RPB) {
+        const f32x4 xv = ldv(x + (size_t)r * Cin + 4 * sub);
+        float acc[HEAD_MAX_OUT];
+#pragma unroll
+        for (int o = 0; o < HEAD_MAX_OUT; ++o) acc[o] = xv[0] * wv[o][0] + xv[1] * wv[o][1] + xv[2] * wv[o][2] + xv[3] * wv[o][3];
+#pragma unroll
+        for (int d = LPR / 2; d >= 1; d >>= 1)
+#pragma unroll
+            for (int o = 0; o < HEAD_MAX_OUT; ++o) acc[o] += __shfl_xor(acc[o], d, 64);
+        if (sub < Cout) {
+            float v = acc[0];
+#pragma unroll
+            for (int o = 1; o < HEAD_MAX_OUT; ++o) v = sub == o ? acc[o] : v;
+            y[(size_t)r * Cout + sub] = tanhf(v + bias[sub]);
+        }
+    }
+}
+
+// g = dy * (1 - y^2);  dx = g @ W;  partial[chunk][o][Cin] = sum_rows g[o] * x,  partial_b[chunk][o] = sum_rows g[o]
+template <int LPR>
+__global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dy, const float* __restrict__ y,
+                                                   const float* __restrict__ x, const float* __restrict__ w,
+                                                   float* __restrict__ dx, float* __restrict__ partial, int M, int Cout,
+                                                   int rows_per_block) {
+    constexpr int Cin = LPR * 4, RPB = 256 / LPR;
+    __shared__ f32x4 red[HEAD_MAX_OUT][256];
+    __shared__ float redb[HEAD_MAX_OUT][256];
+    const int sub = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
+    f32x4 wv[HEAD_MAX_OUT], dwv[HEAD_MAX_OUT];
+    float dbv[HEAD_MAX_OUT];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_OUT; ++o) {
+        wv[o] = o < Cout ? ldv(w + o * Cin + 4 * sub) : f32x4{0.f, 0.f, 0.f, 0.f};
+        dwv[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dbv[o] = 0.f;
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int r = r0 + rloc; r < r1; r += RPB) {
+        const f32x4 xv = ldv(x + (size_t)r * Cin + 4 * sub);
+        f32x4 dxa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < HEAD_MAX_OUT; ++o) {
+            if (o < Cout) {
+                const float yy = y[(size_t)r * Cout + o];
+                const float g = dy[(size_t)r * Cout + o] * (1.f - yy * yy);
+                dxa += g * wv[o];
+                dwv[o] += g * xv;
+                dbv[o] += g;
+            }
+        }
+        if (dx) stv(dx + (size_t)r * Cin + 4 * sub, dxa);
+    }
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_OUT; ++o) { red[o][threadIdx.x] = dwv[o]; redb[o][threadIdx.x] = dbv[o]; }
+    __syncthreads();
+    if (rloc == 0) {
+        for (int o = 0; o < Cout; ++o) {
+            f32x4 t = red[o][sub];
+            for (int q = 1; q < RPB; ++q) t += red[o][q * LPR + sub];
+            stv(partial + ((size_t)blockIdx.x * HEAD_MAX_OUT + o) * (Cin + 4) + 4 * sub, t);
+            if (sub == 0) {
+                float tb = 0.f;
+                for (int q = 0; q < RPB; ++q) tb += redb[o][q * LPR];
+                partial[((size_t)blockIdx.x * HEAD_MAX_OUT + o) * (Cin + 4) + Cin] = tb;
+            }
+        }
+    }
+}
+
+// dw[o][c] = sum_chunks partial[chunk][o][c];  db[o] = sum_chunks partial[chunk][o][Cin]     (row stride Cin + 4)
+__global__ void k_head_reduce(const float* __restrict__ partial, int chunks, int Cin, int Cout, float* __restrict__ dw,
+                              float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * (Cin + 1)) return;
+    const int o = i / (Cin + 1), c = i % (Cin + 1);
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += partial[((size_t)k * HEAD_MAX_OUT + o) * (Cin + 4) + c];
+    if (c < Cin) dw[o * Cin + c] = (float)s;
+    else db[o] = (float)s;
+}
+
+bool head_supported(int Cin, int Cout) {
+    return Cout >= 1 && Cout <= HEAD_MAX_OUT && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128 || Cin == 256);
+}
+int head_chunks(int M) { return std::min(256, (M + 255) / 256); }
+
+#define ICN_HEAD_DISPATCH(KERNEL, ...)                                                  \
+    switch (Cin) {                                                                      \
+        case 16: hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__); break;                   \
+        case 32: hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__); break;                   \
+        case 64: hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__); break;                  \
+        case 128: hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__); break;                 \
+        default: hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__); break;                  \
+    }
+
+void launch_head_fwd(const float* x, const float* w, const float* bias, float* y, int M, int Cin, int Cout, hipStream_t s) {
+    const int rpb = 256 / (Cin / 4);
+    const int blocks = std::min(4096, (M + rpb - 1) / rpb);
+    ICN_HEAD_DISPATCH(k_head_fwd, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, Cout)
+}
+
+void launch_head_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
+                     int M, int Cin, int Cout, hipStream_t s) {
+    const int chunks = head_chunks(M), rows = (M + chunks - 1) / chunks;
+    ICN_HEAD_DISPATCH(k_head_bwd, dim3(chunks), dim3(256), 0, s, dy, y, x, w, dx, ws, M, Cout, rows)
+    hipLaunchKernelGGL(k_head_reduce, dim3((Cout * (Cin + 1) + 63) / 64), dim3(64), 0, s, ws, chunks, Cin, Cout, dw, db);
+}
+#undef ICN_HEAD_DISPATCH
+
+}  // namespace icn

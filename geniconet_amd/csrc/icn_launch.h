@@ -61,6 +61,13 @@ void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, con
 void launch_bn_relu_bwd(const float* dy, const float* y, const float* a, const float* b, const float* stat_a, const float* stat_b,
                         const float* ga, const float* gb, float* da, float* db, float* sums, float* ws, int M, int C, hipStream_t s);
 
+// ---- fused 1x1 head + tanh (icn_bn.hip); ws = head_chunks(M) * 4 * (Cin + 4) floats
+bool head_supported(int Cin, int Cout);
+int head_chunks(int M);
+void launch_head_fwd(const float* x, const float* w, const float* bias, float* y, int M, int Cin, int Cout, hipStream_t s);
+void launch_head_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
+                     int M, int Cin, int Cout, hipStream_t s);
+
 // ---- optional per-launch HIP-event timing of the MFMA kernels (bench.py's live roofline measurement) ----------
 enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA_64x64, PROF_GG_128x128, PROF_GG_128x64,
                 PROF_GG_64x128, PROF_GG_64x64, PROF_WG_128x128, PROF_WG_128x64, PROF_WG_64x128, PROF_WG_64x64, PROF_KINDS };

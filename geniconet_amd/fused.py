@@ -104,3 +104,65 @@ def bn_add_relu(a, bn_a, b, bn_b):
     bn_a.num_batches_tracked.add_(1)
     bn_b.num_batches_tracked.add_(1)
     return _BnReluFn.apply(a, *_args(bn_a), b, *_args(bn_b))
+
+
+class _HeadFn(torch.autograd.Function):
+    """y = tanh(conv1x1(x)) : the output head `Conv2d(C, 3, 1) + Tanh` (reference models.py:151-154)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        L = _lib.lib()
+        xp = _nhwc(x)
+        Bn, H, W, Cin = xp.shape
+        Cout, M = weight.shape[0], Bn * H * W
+        w2 = weight.reshape(Cout, Cin).contiguous()
+        y = torch.empty(Bn, H, W, Cout, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.icn_head_fwd(xp.data_ptr(), w2.data_ptr(), bias.contiguous().data_ptr(), y.data_ptr(), M, Cin, Cout,
+                                      _stream()), 'icn_head_fwd')
+        ctx.save_for_backward(xp, w2, y)
+        ctx.wshape = weight.shape
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        L = _lib.lib()
+        xp, w2, y = ctx.saved_tensors
+        Bn, H, W, Cin = xp.shape
+        Cout, M = w2.shape[0], Bn * H * W
+        gyp = _nhwc(gy)
+        dev = gyp.device
+        dx = torch.empty_like(xp) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w2)
+        db = torch.empty(Cout, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.icn_head_workspace_floats(M, Cin), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.icn_head_bwd(gyp.data_ptr(), y.data_ptr(), xp.data_ptr(), w2.data_ptr(),
+                                      dx.data_ptr() if dx is not None else None, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), M,
+                                      Cin, Cout, _stream()), 'icn_head_bwd')
+        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dw.reshape(ctx.wshape), db
+
+
+def can_fuse_head(x, seq):
+    """seq = nn.Sequential(Conv2d(C, <=4, kernel_size=1), Tanh()) on a ROCm fp32 tensor, nobody hooked it."""
+    if _DISABLED or not x.is_cuda or x.dtype != torch.float32 or len(seq) != 2:
+        return False
+    conv, act = seq[0], seq[1]
+    if not isinstance(conv, torch.nn.Conv2d) or not isinstance(act, torch.nn.Tanh):
+        return False
+    if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.padding != (0, 0) or conv.groups != 1 or conv.bias is None:
+        return False
+    if conv.in_channels not in (16, 32, 64, 128, 256) or conv.out_channels > 4:
+        return False
+    for m in (seq, conv, act):
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks:
+            return False
+    return True
+
+
+def head(x, seq):
+    """seq(x) through the fused kernel when possible."""
+    if can_fuse_head(x, seq):
+        return _HeadFn.apply(x, seq[0].weight, seq[0].bias)
+    return seq(x)

@@ -151,7 +151,7 @@ class ico2ico(nn.Module):
         self.decoder, self.enc2icoConv = createenc2ico(mode, kind, R)
 
     def forward(self, x):
-        return self.enc2icoConv(self.decoder(self.enc(self.encoder(x))))
+        return fused.head(self.decoder(self.enc(self.encoder(x))), self.enc2icoConv)
 
 
 class ico2enc(nn.Module):
@@ -175,7 +175,7 @@ class enc2ico(nn.Module):
                                                        self.subdivisions)
 
     def forward(self, x):
-        return self.enc2icoConv(self.decoder(x))
+        return fused.head(self.decoder(x), self.enc2icoConv)
 
 
 class VAE(nn.Module):
@@ -234,7 +234,7 @@ class ico2ico_vae(VAE):
         return self.mu_hook(self.mu(h)), self.logvar_hook(self.logvar(h))
 
     def decode(self, z):
-        return self.final_layer(self.decoder(self.reparameterize_hook(z)))
+        return fused.head(self.decoder(self.reparameterize_hook(z)), self.final_layer)
 
 
 class ico2enc_vae(VAE):
@@ -271,7 +271,7 @@ class enc2ico_vae(VAE):
         return torch.add(mean, logvar * torch.randn(logvar.shape))
 
     def decode(self, z):
-        return self.final_layer(self.decoder(z))
+        return fused.head(self.decoder(z), self.final_layer)
 
     def forward(self, x):
         return self.decode(x), torch.tensor([]), torch.tensor([])

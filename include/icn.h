@@ -87,6 +87,14 @@ int icn_bn_relu_bwd(const float* dy, const float* y, const float* a, const float
                     const float* gamma_a, const float* gamma_b, float* da, float* db, float* sums, float* ws, int M, int C,
                     void* stream);
 
+/* Fused output head  y = tanh(x W^T + b)  (reference models.py:151-154: Conv2d(64, 3, 1x1) + Tanh).
+ * x (M, Cin) channels-last rows, w (Cout, Cin), Cin in {16,32,64,128,256}, Cout <= 4; y (M, Cout).
+ * icn_head_bwd: dx (may be NULL), dw (Cout, Cin), db (Cout); ws >= icn_head_workspace_floats(M, Cin) floats. */
+size_t icn_head_workspace_floats(int M, int Cin);
+int icn_head_fwd(const float* x, const float* w, const float* bias, float* y, int M, int Cin, int Cout, void* stream);
+int icn_head_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
+                 int M, int Cin, int Cout, void* stream);
+
 /* Host-side introspection (no device needed).  Each writes at most `cap` elements and returns the element
  * count required (negative on error). */
 long icn_table_conv_fwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap);      /* [7][P_out]     */

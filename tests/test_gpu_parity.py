@@ -241,6 +241,25 @@ def test_fused_bn_relu_matches_torch_builtins(C, dual):
     assert not fused.can_fuse(a1, bn_a)
 
 
+def test_fused_head_matches_conv1x1_tanh():
+    from geniconet_amd import fused
+    torch.manual_seed(4)
+    seq = torch.nn.Sequential(torch.nn.Conv2d(64, 3, kernel_size=(1, 1)), torch.nn.Tanh()).cuda()
+    ref = torch.nn.Sequential(torch.nn.Conv2d(64, 3, kernel_size=(1, 1)), torch.nn.Tanh()).cuda()
+    ref.load_state_dict(seq.state_dict())
+    x = torch.randn(5, 64, 40, 16, device='cuda').contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(5, 3, 40, 16, device='cuda')
+    x1, x2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    assert fused.can_fuse_head(x1, seq)
+    y1, y2 = fused.head(x1, seq), ref(x2)
+    y1.backward(gy); y2.backward(gy)
+    for got, want in ((y1, y2), (x1.grad, x2.grad), (seq[0].weight.grad, ref[0].weight.grad), (seq[0].bias.grad, ref[0].bias.grad)):
+        assert got.shape == want.shape
+        assert rel_l2(got.detach().cpu().numpy(), want.detach().cpu().numpy()) < 2e-5
+    seq.register_forward_hook(lambda *a: None)
+    assert not fused.can_fuse_head(x1, seq)
+
+
 def test_vae_training_step_and_i6_forward():
     """BASELINE configs 4 and 5 in miniature: a VAE step with the P2P+KLD loss, and the AE built at subdivisions=6."""
     from geniconet_amd import data, models

@@ -27,6 +27,12 @@ __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_b
     unsigned aoff[RA], boff[RB];
     for (int i = 0; i < RA; ++i) aoff[i] = (unsigned)(((blockIdx.x * BM + 8 * (wave + 4 * i) + rsub) % rows_total) * 1024 + 16 * pc);
     for (int i = 0; i < RB; ++i) boff[i] = (unsigned)(((8 * (wave + 4 * i) + rsub) % rows_total) * 1024 + 16 * pc + 512);
+    // LEVEL 4: the conv's real traffic -- A = 92160 rows x 1 KiB (K = 256 fp32), 7 taps = the tile's rows shifted by
+    // {0, +64, +1, -63, -64, -1, +63} (a 64-wide chart), 8 channel chunks of 128 B; B = weight panel [7][128][1 KiB]
+    // behind the activations; 56 K-steps per 64-row tile, tiles b, b + grid, ...
+    const int a_rows = 92160;
+    const unsigned b_base = (unsigned)a_rows * 1024u;
+    const int shift[7] = {0, 64, 1, -63, -64, -1, 63};
     f32x16 acc[TM][TN];
     for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int fl = swz(l31);
@@ -35,6 +41,23 @@ __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_b
     for (int j = 0; j < TN; ++j) fb[0][j] = fb[1][j] = f32x4{-1e-3f, 1e-3f * (lane & 7), 3e-3f, 1e-3f};
     int ring = 0, iring = 2;
     auto dma = [&](int slot, int step) {
+        if (LEVEL >= 4) {
+            const int tile = (blockIdx.x + (step / 56) * gridDim.x) % (a_rows / BM);
+            const int t = step % 7, kc = (step / 7) % 8;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                int row = tile * BM + 8 * (wave + 4 * i) + rsub + shift[t];
+                row = row < 0 ? row + a_rows : (row >= a_rows ? row - a_rows : row);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(As + slot * BM * BK + 8 * (wave + 4 * i) * BK), 16,
+                                                         (unsigned)row * 1024u + 16u * pc, kc * 128, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(Bs + slot * BN * BK + 8 * (wave + 4 * i) * BK), 16,
+                                                         b_base + (unsigned)(t * BN + 8 * (wave + 4 * i) + rsub) * 1024u + 16u * pc,
+                                                         kc * 128, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(As + slot * BM * BK + 8 * (wave + 4 * i) * BK), 16, aoff[i],
@@ -103,7 +126,7 @@ void run(int blocks_per_cu, const float* src, unsigned src_bytes, float* out) {
 }
 
 int main(int argc, char** argv) {
-    const unsigned src_bytes = 64u << 20;
+    const unsigned src_bytes = 96u << 20;   // >= 92160 KiB of activations + 0.9 MB of weights
     float *src, *out;
     hipMalloc(&src, src_bytes); hipMalloc(&out, 1024 * 256 * 4);
     {   // random normal-ish operands: zero / trivial data lets the chip hold a higher clock than real activations do
@@ -115,7 +138,8 @@ int main(int argc, char** argv) {
         printf("source data: %s\n", (argc > 1 && argv[1][0] == 'z') ? "zeros" : "random");
     }
 #define LADDER(BM, BN, OCC) run<BM, BN, 0>(OCC, src, src_bytes, out); run<BM, BN, 1>(OCC, src, src_bytes, out); \
-                            run<BM, BN, 2>(OCC, src, src_bytes, out); run<BM, BN, 3>(OCC, src, src_bytes, out);
+                            run<BM, BN, 2>(OCC, src, src_bytes, out); run<BM, BN, 3>(OCC, src, src_bytes, out); \
+                            run<BM, BN, 4>(OCC, src, src_bytes, out);
     LADDER(128, 128, 1)
     LADDER(128, 64, 2)
     LADDER(64, 128, 2)
