@@ -58,12 +58,17 @@ class Point2Point_Loss(torch.nn.Module):
 
     def forward(self, inputs, target):
         v = grid_to_vertices(inputs, self.subdivisions)
-        normals = compute_vertex_normals(v, self.ico_faces)       # evaluated even when their factor is 0,
-        lap = compute_laplacian_batch(v, self.nbr_idx, self.nbr_w)  # as the reference does (losses.py:54,57)
         tgt = target.transpose(1, 2)
         l_pos = torch.nn.functional.mse_loss(v, tgt[:, :, :3])
-        l_nor = torch.mean(1 - torch.nn.functional.cosine_similarity(normals, tgt[:, :, 3:6], dim=2))
-        l_lap = torch.nn.functional.mse_loss(lap, tgt[:, :, 6:9])
+        # The normal and Laplacian terms are evaluated (and reported) even when their factor is 0, as the reference
+        # does (losses.py:54,57,74-80); a zero-weighted term contributes exactly zero gradient, so it is evaluated
+        # without recording a backward graph.
+        with torch.set_grad_enabled(torch.is_grad_enabled() and self.factor_nor != 0):
+            normals = compute_vertex_normals(v, self.ico_faces)
+            l_nor = torch.mean(1 - torch.nn.functional.cosine_similarity(normals, tgt[:, :, 3:6], dim=2))
+        with torch.set_grad_enabled(torch.is_grad_enabled() and self.factor_lap != 0):
+            lap = compute_laplacian_batch(v, self.nbr_idx, self.nbr_w)
+            l_lap = torch.nn.functional.mse_loss(lap, tgt[:, :, 6:9])
         loss = self.factor_pos * l_pos + self.factor_nor * l_nor + self.factor_lap * l_lap
         self.last_loss_mse, self.last_loss_cos, self.last_loss_lap = l_pos.detach(), l_nor.detach(), l_lap.detach()
         self.last_loss_total = loss.detach()

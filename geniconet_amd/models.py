@@ -92,6 +92,24 @@ def _check_model(model):
         raise ValueError("only model='residualS2S' is built (reference models.py:102,135); got %r" % (model,))
 
 
+class _Encoder(nn.Sequential):
+    """nn.Sequential (same child names '0', '1', ... as the reference's encoder, models.py:103-127) whose stem
+    conv -> BatchNorm2d -> ReLU runs BN + ReLU through the fused HIP kernel when possible."""
+
+    def forward(self, x):
+        mods = list(self)
+        x = mods[0](x)
+        relu = mods[2]
+        hooked = relu._forward_hooks or relu._forward_pre_hooks or relu._backward_hooks
+        if isinstance(relu, nn.ReLU) and not hooked and fused.can_fuse(x, mods[1]):
+            x = fused.bn_relu(x, mods[1])
+        else:
+            x = relu(mods[1](x))
+        for m in mods[3:]:
+            x = m(x)
+        return x
+
+
 def _encoder(corner_mode, subdivisions, n_down):
     layers = [IcoConvS2S(3, STEM_CHANNELS, 1, True, subdivisions, corner_mode),
               nn.BatchNorm2d(STEM_CHANNELS), nn.ReLU(inplace=False)]
@@ -99,7 +117,7 @@ def _encoder(corner_mode, subdivisions, n_down):
     for k in range(n_down):
         layers.append(BasicIcoS2SDownBlock(cin, DOWN_CHANNELS[k], True, subdivisions - k, corner_mode))
         cin = DOWN_CHANNELS[k]
-    return nn.Sequential(*layers)
+    return _Encoder(*layers)
 
 
 def _decoder(corner_mode, subdivisions, latent_channels):
