@@ -1218,7 +1218,8 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M,   \
                                a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows);                                                     \
     } while (0)
-        prof_mark_begin(bi128 ? (bj128 ? PROF_WG_128x128 : PROF_WG_128x64) : (bj128 ? PROF_WG_64x128 : PROF_WG_64x64),
+        prof_mark_begin((bi128 ? (bj128 ? PROF_WG_128x128 : PROF_WG_128x64) : (bj128 ? PROF_WG_64x128 : PROF_WG_64x64)) -
+                            (dma ? PROF_WG_128x128 - PROF_WGD_128x128 : 0),
                         a.algo_flops, s);
         if (bi128 && bj128) ICN_WG(128, 128);
         else if (bi128) ICN_WG(128, 64);
