@@ -37,21 +37,34 @@ T* upload(const std::vector<T>& v) {
     return d;
 }
 
+// device copy of an icn::DmaTable (the form the LDS-DMA kernels consume)
+struct DevDma {
+    int32_t* code = nullptr;   // [7][P]
+    int32_t* slots = nullptr;  // [n_slots][E]
+    int n_slots = 0, E = 1;
+};
+DevDma upload_dma(const std::vector<int32_t>& idx, int E, int P) {
+    icn::DmaTable h;
+    icn::build_dma_table(idx, E, P, h);
+    DevDma d;
+    d.code = upload(h.code);
+    d.slots = upload(h.slots);
+    d.n_slots = h.n_slots;
+    d.E = E;
+    return d;
+}
 struct ConvTables {
     int Pin = 0, Pout = 0, n_in = 0, n_out = 0, E = 1;
     int32_t* fwd = nullptr;    // [7][Pout]
     int32_t* bwd = nullptr;    // [7][E][Pin]
-    uint8_t* fwd_slow = nullptr;  // [Pout] taps of each output row that need the slow gather (pole means)
-    uint8_t* bwd_slow = nullptr;  // [Pin] same for the full transposed table (extra entries / pole means)
     int32_t* bwd1 = nullptr;      // [7][Pin] primary (single plain pixel) entries of the transposed table
-    uint8_t* bwd1_slow = nullptr; // [Pin] all zero: the primary table has no slow rows
     int nv = 0;                   // virtual rows: extra transposed entries, run as a second small GEMM
     int32_t* vidx = nullptr;      // [7][nv]
-    uint8_t* vslow = nullptr;     // [nv] taps of each virtual row that are pole means
     int32_t* vq = nullptr;        // [nv] target input pixel (sorted)
     int32_t* perm = nullptr;   // [Pin] (stride 2 only)
     int32_t* bwd_perm = nullptr;  // [7][E][Pin] transposed table in permuted row order (stride 2 only)
     uint8_t* mask32 = nullptr; // [Pin/32] (stride 2 only)
+    DevDma d_fwd, d_bwd, d_bwd1, d_virt, d_bwdp;   // DmaTable forms of fwd, bwd, bwd1, vidx, bwd_perm
 };
 struct UpTables {
     int Pc = 0, Pf = 0, Wf = 0, Wb = 0;
@@ -81,22 +94,17 @@ const ConvTables& conv_tables(int r_in, int stride, int mode) {
     t.E = icn::build_conv_bwd(r_in, stride, mode, bwd);
     t.fwd = upload(fwd);
     t.bwd = upload(bwd);
-    std::vector<uint8_t> slow;
-    icn::build_slow_mask(fwd, 1, t.Pout, slow);
-    t.fwd_slow = upload(slow);
-    icn::build_slow_mask(bwd, t.E, t.Pin, slow);
-    t.bwd_slow = upload(slow);
+    t.d_fwd = upload_dma(fwd, 1, t.Pout);
+    t.d_bwd = upload_dma(bwd, t.E, t.Pin);
     std::vector<int32_t> primary;
     icn::VirtualRows vr;
     icn::split_conv_bwd(r_in, stride, bwd, t.E, primary, vr);
     t.bwd1 = upload(primary);
-    slow.assign(t.Pin, 0);
-    t.bwd1_slow = upload(slow);
+    t.d_bwd1 = upload_dma(primary, 1, t.Pin);
     t.nv = vr.nv;
     if (vr.nv > 0) {
         t.vidx = upload(vr.vidx);
-        icn::build_slow_mask(vr.vidx, 1, vr.nv, slow);
-        t.vslow = upload(slow);
+        t.d_virt = upload_dma(vr.vidx, 1, vr.nv);
         t.vq = upload(vr.vq);
     }
     if (stride == 2) {
@@ -108,6 +116,7 @@ const ConvTables& conv_tables(int r_in, int stride, int mode) {
         for (int te = 0; te < icn::NTAPS * t.E; ++te)
             for (int k = 0; k < t.Pin; ++k) bwd_p[(size_t)te * t.Pin + k] = bwd[(size_t)te * t.Pin + perm[k]];
         t.bwd_perm = upload(bwd_p);
+        t.d_bwdp = upload_dma(bwd_p, t.E, t.Pin);
     }
     return g_conv.emplace(key, t).first->second;
 }
@@ -149,19 +158,38 @@ void check_conv(const void* a, const void* b, const void* c, int B, int Cin, int
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// number of virtual rows of the stride-1 transposed gather, per (r, corner_mode); host-only, cached
-int virtual_rows(int r_in, int mode) {
+// Table sizes the workspace query needs, per (r, stride): virtual rows of the stride-1 transposed gather and side-buffer
+// slots of each DmaTable, the larger of the two corner modes.  Host-only, cached.
+struct TableCounts { int nv = 0, slots_fwd = 0, slots_bwd = 0; };
+TableCounts table_counts(int r_in, int stride) {
     static std::mutex mu;
-    static std::map<std::pair<int, int>, int> cache;
+    static std::map<std::pair<int, int>, TableCounts> cache;
     std::lock_guard<std::mutex> lk(mu);
-    auto key = std::make_pair(r_in, mode);
+    auto key = std::make_pair(r_in, stride);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    std::vector<int32_t> bwd, primary;
-    icn::VirtualRows vr;
-    const int E = icn::build_conv_bwd(r_in, 1, mode, bwd);
-    icn::split_conv_bwd(r_in, 1, bwd, E, primary, vr);
-    return cache[key] = vr.nv;
+    TableCounts c;
+    const int Pin = icn::pixels(r_in), Pout = Pin / (stride * stride);
+    for (int mode = 0; mode < 2; ++mode) {
+        std::vector<int32_t> fwd, bwd, primary;
+        icn::DmaTable d;
+        icn::build_conv_fwd(r_in, stride, mode, fwd);
+        icn::build_dma_table(fwd, 1, Pout, d);
+        c.slots_fwd = std::max(c.slots_fwd, d.n_slots);
+        const int E = icn::build_conv_bwd(r_in, stride, mode, bwd);
+        icn::build_dma_table(bwd, E, Pin, d);              // (a row permutation does not change the slots)
+        c.slots_bwd = std::max(c.slots_bwd, d.n_slots);
+        if (stride == 1) {
+            icn::VirtualRows vr;
+            icn::split_conv_bwd(r_in, 1, bwd, E, primary, vr);
+            c.nv = std::max(c.nv, vr.nv);
+            if (vr.nv > 0) {
+                icn::build_dma_table(vr.vidx, 1, vr.nv, d);
+                c.slots_bwd = std::max(c.slots_bwd, d.n_slots);
+            }
+        }
+    }
+    return cache[key] = c;
 }
 
 // workspace layout of bwd-weight: [wgrad partial slabs S x 7 x Cin x Cout][bias partials S x Cout]
@@ -257,20 +285,33 @@ int icn_prepare_upsample(int r_in, int corner_mode) {
     }
 }
 
+// Workspace layouts (each piece 256-byte aligned):
+//   fwd        [packed weights][side buffer (B, slots_fwd, Cin)]
+//   bwd-data   [packed weights][stride 1: virtual-row GEMM result (B, nv, Cin)][side buffer (B, slots_bwd, Cout)]
+//   bwd-weight [partial slabs S x 7 x Cin x Cout][bias partials S x Cout][side buffer (B, slots_fwd, Cin)]
 size_t icn_conv_workspace_bytes(int op, int B, int Cin, int Cout, int r_in, int stride) {
     if (B < 1 || Cin < 1 || Cout < 1 || r_in < 0 || r_in > 10 || (stride != 1 && stride != 2)) return 0;
     const int n_out = (1 << r_in) / stride;
     const int M = B * 10 * n_out * n_out;
     const size_t wbytes = align256((size_t)7 * Cin * Cout * sizeof(float));
-    switch (op) {
-        case ICN_OP_CONV_FWD: return icn::gather_gemm_supported(Cin, Cout) ? wbytes : 0;
-        case ICN_OP_CONV_BWD_DATA:
-            if (!icn::gather_gemm_supported(Cout, Cin)) return 0;
-            // packed weights + (stride 1) the virtual-row GEMM result (B, nv, Cin); 'average' bounds 'zeros'
-            return wbytes + (stride == 1 ? align256((size_t)B * virtual_rows(r_in, ICN_CORNER_AVERAGE) * Cin * sizeof(float)) : 0);
-        case ICN_OP_CONV_BWD_WEIGHT:
-            return wgrad_partial_bytes(M, Cin, Cout) + align256((size_t)icn::wgrad_splits(M, Cin, Cout) * Cout * sizeof(float));
-        default: return 0;
+    try {
+        switch (op) {
+            case ICN_OP_CONV_FWD:
+                if (!icn::gather_gemm_supported(Cin, Cout)) return 0;
+                return wbytes + align256((size_t)B * table_counts(r_in, stride).slots_fwd * Cin * sizeof(float));
+            case ICN_OP_CONV_BWD_DATA: {
+                if (!icn::gather_gemm_supported(Cout, Cin)) return 0;
+                const TableCounts c = table_counts(r_in, stride);
+                return wbytes + align256((size_t)B * c.nv * Cin * sizeof(float)) +
+                       align256((size_t)B * c.slots_bwd * Cout * sizeof(float));
+            }
+            case ICN_OP_CONV_BWD_WEIGHT:
+                return wgrad_partial_bytes(M, Cin, Cout) + align256((size_t)icn::wgrad_splits(M, Cin, Cout) * Cout * sizeof(float)) +
+                       align256((size_t)B * table_counts(r_in, stride).slots_fwd * Cin * sizeof(float));
+            default: return 0;
+        }
+    } catch (const std::exception&) {
+        return 0;
     }
 }
 
@@ -284,9 +325,10 @@ int icn_conv_fwd(const float* x, const float* w, const float* bias, float* y, in
             if (!ws || ws_bytes < icn_conv_workspace_bytes(ICN_OP_CONV_FWD, B, Cin, Cout, r_in, stride))
                 throw std::invalid_argument("icn_conv_fwd: workspace too small");
             float* wf = static_cast<float*>(ws);
-            icn::launch_pack_weights(w, wf, Cout, Cin, 0, s);
-            icn::GatherGemmArgs a{x, wf, bias, y, t.fwd, t.fwd_slow, nullptr, nullptr, B * t.Pout, t.Pin, t.Pout, Cin, Cout, 1, t.n_in,
-                                  2.0 * 7 * Cin * Cout * (double)B * t.Pout};
+            float* side = reinterpret_cast<float*>(static_cast<char*>(ws) + align256((size_t)7 * Cin * Cout * sizeof(float)));
+            icn::launch_conv_prologue(w, wf, Cout, Cin, 0, x, t.d_fwd.slots, side, t.d_fwd.n_slots, 1, B, t.Pin, Cin, t.n_in, s);
+            icn::GatherGemmArgs a{x, wf, bias, y, t.fwd, t.d_fwd.code, side, t.d_fwd.n_slots, nullptr, nullptr, B * t.Pout, t.Pin,
+                                  t.Pout, Cin, Cout, 1, t.n_in, 2.0 * 7 * Cin * Cout * (double)B * t.Pout};
             icn::launch_gather_gemm_auto(a, s);
         } else if (icn::stem_supported(Cin, Cout)) {
             icn::launch_stem_fwd(x, w, bias, y, t.fwd, B * t.Pout, t.Pin, t.Pout, Cin, Cout, t.n_in, s);
@@ -310,23 +352,27 @@ int icn_conv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin
             if (!ws || ws_bytes < icn_conv_workspace_bytes(ICN_OP_CONV_BWD_DATA, B, Cin, Cout, r_in, stride))
                 throw std::invalid_argument("icn_conv_bwd_data: workspace too small");
             float* wb = static_cast<float*>(ws);
-            icn::launch_pack_weights(w, wb, Cout, Cin, 1, s);
+            const size_t wbytes = align256((size_t)7 * Cin * Cout * sizeof(float));
+            const TableCounts tc = table_counts(r_in, stride);
+            float* vout = reinterpret_cast<float*>(static_cast<char*>(ws) + wbytes);
+            float* side = reinterpret_cast<float*>(static_cast<char*>(ws) + wbytes + align256((size_t)B * tc.nv * Cin * sizeof(float)));
             // source = dy at the output level (pole corners of THAT level), rows = input pixels
             // Stride 1: the transposed gather has extra entries (duplicates / pole means) along the chart seams.
             // Where they are few (fine levels) the main GEMM gathers only the primary entries and a second, small GEMM
-            // over "virtual rows" adds the rest; where they are many (coarse levels: 23 % of the rows at r = 3) the
-            // kernel's in-line multi-entry path is cheaper than a second launch.
+            // over "virtual rows" adds the rest; where they are many (coarse levels: 23 % of the rows at r = 3) they go
+            // through the main GEMM's side buffer instead of a second launch.
             const bool split = stride == 1 && t.nv > 0 && t.nv * 8 < t.Pin;
-            icn::GatherGemmArgs a{dy, wb, nullptr, dx, split ? t.bwd1 : (stride == 2 ? t.bwd_perm : t.bwd),
-                                  split ? t.bwd1_slow : (stride == 2 ? nullptr : t.bwd_slow),
+            const DevDma& dm = split ? t.d_bwd1 : (stride == 2 ? t.d_bwdp : t.d_bwd);   // main GEMM's table
+            const DevDma& ds = split ? t.d_virt : dm;                                    // table the side buffer serves
+            icn::launch_conv_prologue(w, wb, Cout, Cin, 1, dy, ds.slots, side, ds.n_slots, ds.E, B, t.Pout, Cout, t.n_out, s);
+            icn::GatherGemmArgs a{dy, wb, nullptr, dx, split ? t.bwd1 : (stride == 2 ? t.bwd_perm : t.bwd), dm.code, side, dm.n_slots,
                                   t.perm, t.mask32, B * t.Pin, t.Pout, t.Pin, Cout, Cin, split ? 1 : t.E, t.n_out,
                                   2.0 * 7 * Cin * Cout * (double)B * t.Pout};
             icn::launch_gather_gemm_auto(a, s);
             if (split) {
                 // second, small GEMM over the virtual rows, then dx[b, vq[v], :] += result[b, v, :]
-                float* vout = reinterpret_cast<float*>(static_cast<char*>(ws) + align256((size_t)7 * Cin * Cout * sizeof(float)));
-                icn::GatherGemmArgs v{dy, wb, nullptr, vout, t.vidx, t.vslow, nullptr, nullptr, B * t.nv, t.Pout, t.nv, Cout, Cin, 1,
-                                      t.n_out, 2.0 * 7 * Cin * Cout * (double)B * t.nv};
+                icn::GatherGemmArgs v{dy, wb, nullptr, vout, t.vidx, t.d_virt.code, side, t.d_virt.n_slots, nullptr, nullptr, B * t.nv,
+                                      t.Pout, t.nv, Cout, Cin, 1, t.n_out, 2.0 * 7 * Cin * Cout * (double)B * t.nv};
                 icn::launch_gather_gemm_auto(v, s);
                 icn::launch_row_scatter_add(vout, dx, t.vq, B, t.nv, t.Pin, Cin, s);
             }
@@ -351,8 +397,13 @@ int icn_conv_bwd_weight(const float* x, const float* dy, float* dw, float* dbias
         const int M = B * t.Pout;
         float* partial = static_cast<float*>(ws);
         float* bpart = dbias ? reinterpret_cast<float*>(static_cast<char*>(ws) + wgrad_partial_bytes(M, Cin, Cout)) : nullptr;
-        icn::WgradArgs a{x, dy, t.fwd, partial, bpart, dw, dbias, M, t.Pin, t.Pout, Cin, Cout, t.n_in,
-                         2.0 * 7 * Cin * Cout * (double)M};
+        float* side = reinterpret_cast<float*>(static_cast<char*>(ws) + wgrad_partial_bytes(M, Cin, Cout) +
+                                               align256((size_t)icn::wgrad_splits(M, Cin, Cout) * Cout * sizeof(float)));
+        const bool mfma = icn::wgrad_supported(Cin, Cout);
+        if (mfma) icn::launch_conv_prologue(nullptr, nullptr, Cout, Cin, 0, x, t.d_fwd.slots, side, t.d_fwd.n_slots, 1, B, t.Pin, Cin,
+                                            t.n_in, s);
+        icn::WgradArgs a{x, dy, t.fwd, mfma ? t.d_fwd.code : nullptr, side, t.d_fwd.n_slots, partial, bpart, dw, dbias, M, t.Pin,
+                         t.Pout, Cin, Cout, t.n_in, 2.0 * 7 * Cin * Cout * (double)M};
         icn::launch_wgrad(a, s);
         ICN_HIP(hipGetLastError());
         return 0;

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <array>
+#include <map>
 #include <stdexcept>
 
 namespace icn {
@@ -173,13 +174,33 @@ void split_conv_bwd(int r_in, int stride, const std::vector<int32_t>& bwd_idx, i
         for (int t = 0; t < NTAPS; ++t) vr.vidx[(size_t)t * vr.nv + v] = rows[v][t];
 }
 
-void build_slow_mask(const std::vector<int32_t>& idx, int E, int P, std::vector<uint8_t>& mask) {
-    mask.assign(P, 0);
+void build_dma_table(const std::vector<int32_t>& idx, int E, int P, DmaTable& out) {
+    out.E = E;
+    out.n_slots = 0;
+    out.code.assign((size_t)NTAPS * P, IDX_ZERO);
+    out.slots.clear();
+    std::map<std::vector<int32_t>, int> slot_of;
+    std::vector<int32_t> ent;
     for (int t = 0; t < NTAPS; ++t)
         for (int p = 0; p < P; ++p) {
-            bool slow = idx[((size_t)t * E) * P + p] <= IDX_POLE;
-            for (int e = 1; e < E; ++e) slow |= idx[((size_t)t * E + e) * P + p] != IDX_ZERO;
-            if (slow) mask[p] |= (uint8_t)(1u << t);
+            ent.clear();
+            for (int e = 0; e < E; ++e) {
+                const int32_t c = idx[((size_t)t * E + e) * P + p];
+                if (c != IDX_ZERO) ent.push_back(c);
+            }
+            int32_t code = IDX_ZERO;
+            if (ent.size() == 1 && ent[0] >= 0) {
+                code = ent[0];
+            } else if (!ent.empty()) {
+                ent.resize(E, IDX_ZERO);
+                auto it = slot_of.find(ent);
+                if (it == slot_of.end()) {
+                    it = slot_of.emplace(ent, out.n_slots++).first;
+                    out.slots.insert(out.slots.end(), ent.begin(), ent.end());
+                }
+                code = -2 - it->second;
+            }
+            out.code[(size_t)t * P + p] = code;
         }
 }
 

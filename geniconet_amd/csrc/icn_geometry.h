@@ -45,9 +45,19 @@ struct VirtualRows {
 void split_conv_bwd(int r_in, int stride, const std::vector<int32_t>& bwd_idx, int E, std::vector<int32_t>& primary,
                     VirtualRows& vr);
 
-// Per-row bit mask (bit t set) of the taps whose gather is not a single plain pixel: a pole mean, or more than
-// one entry (transposed tables).  idx is [7][E][P].
-void build_slow_mask(const std::vector<int32_t>& idx, int E, int P, std::vector<uint8_t>& mask);
+// Gather table in the form the LDS-DMA kernels consume: one code per (tap, row), code [7][P]:
+//   >= 0       a single plain pixel (DMA'd straight from the source tensor)
+//   IDX_ZERO   nothing
+//   -2 - s     slot s of a small per-sample "side" buffer that a pre-pass fills with the sum of the entries
+//              slots[s * E + e] (pixels / pole means): everything that is not a single pixel -- pole means,
+//              duplicated transposed entries.  Equal entry lists share a slot (a forward table has <= 2 slots: the
+//              two pole means).
+struct DmaTable {
+    int n_slots = 0, E = 1;
+    std::vector<int32_t> code;    // [7][P]
+    std::vector<int32_t> slots;   // [n_slots][E]
+};
+void build_dma_table(const std::vector<int32_t>& idx, int E, int P, DmaTable& out);
 
 // ELL sparse matrices of the r -> r+1 upsample and of its transpose.
 struct Ell {

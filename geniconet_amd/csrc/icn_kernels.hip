@@ -55,14 +55,33 @@ __device__ __forceinline__ float gather1(const float* src, int32_t code, int b, 
 // weight re-layouts:  w[Cout][Cin][7]  ->  wf[t][Cout][Cin]  (forward B operand, k = ci contiguous)
 //                                      ->  wb[t][Cin][Cout]  (backward-data B operand, k = co contiguous)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_pack_weights(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int transpose) {
-    const int total = Cout * Cin * 7;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        // i enumerates the OUTPUT layout so that stores are coalesced
-        int t, co, ci;
-        if (!transpose) { ci = i % Cin; co = (i / Cin) % Cout; t = i / (Cin * Cout); }
-        else { co = i % Cout; ci = (i / Cout) % Cin; t = i / (Cin * Cout); }
-        out[i] = w[((size_t)co * Cin + ci) * 7 + t];
+// Prologue of a conv call, one launch: blocks [0, npack) repack the (Cout, Cin, 7) parameter into the GEMM's B operand
+// [7][N][K] (k-contiguous); blocks [npack, npack + B * n_slots) fill the side buffer of a DmaTable:
+//   side[b][s][:] = sum_e gather(slots[s][e])   (pixels / pole means of the source tensor; icn_geometry.h).
+__global__ __launch_bounds__(256) void k_conv_prologue(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
+                                                        int transpose, int npack, const float* __restrict__ src,
+                                                        const int32_t* __restrict__ slots, float* __restrict__ side,
+                                                        int n_slots, int E, int Ps, int K, int ns) {
+    if ((int)blockIdx.x < npack) {
+        const int total = Cout * Cin * 7;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += npack * 256) {
+            // i enumerates the OUTPUT layout so that stores are coalesced
+            int t, co, ci;
+            if (!transpose) { ci = i % Cin; co = (i / Cin) % Cout; t = i / (Cin * Cout); }
+            else { co = i % Cout; ci = (i / Cout) % Cin; t = i / (Cin * Cout); }
+            out[i] = w[((size_t)co * Cin + ci) * 7 + t];
+        }
+        return;
+    }
+    const int j = blockIdx.x - npack, b = j / n_slots, sl = j % n_slots;
+    for (int ch = 4 * threadIdx.x; ch < K; ch += 4 * 256) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < E; ++e) {
+            const int32_t c = slots[sl * E + e];
+            if (c >= 0) v += ld4(src + ((size_t)b * Ps + c) * K + ch);
+            else if (c <= -2) v += pole_mean4(src, b, Ps, ns, -2 - c, K, ch);
+        }
+        *reinterpret_cast<f32x4*>(side + ((size_t)b * n_slots + sl) * K + ch) = v;
     }
 }
 
@@ -288,26 +307,24 @@ bool gather_gemm_supported(int K, int N) { return K % BK == 0 && N % 64 == 0 && 
 //     offset because the LDS side of a DMA is lane-linear -- so the steady state has no VGPR staging and no
 //     ds_write.  Rows that contribute nothing (corner_mode 'zeros', rows past M) carry an out-of-range offset
 //     and the buffer range check writes zeros for them.
-//   * the 7 x BM/32 source byte offsets of a tile live in registers (taps are unrolled);
-//   * rows that need more than one source (pole mean, duplicated transposed entries; a per-row bit mask
-//     marks them) are summed in registers and overwrite their LDS chunk before the stage is published;
-//   * persistent blocks walk tiles b, b+G, ...: the next tile's gather codes are fetched two K-steps before
-//     the current tile ends and its first stage is DMA'd during the last K-step, so the MFMA pipe does not
-//     drain at tile boundaries and launches are not rounded up to whole dispatch waves.
-// Requires every tap in use (no row permutation / tap masks) and source tensors below 2 GiB.
+//   * the gather table is a DmaTable (icn_geometry.h): one code per (tap, row).  Everything that is not a single
+//     source pixel (pole means, duplicated transposed entries) was summed into the small per-sample `side` buffer
+//     by k_conv_prologue; such a row is DMA'd from there (second buffer resource), so the K-step loop contains no
+//     ordinary VMEM load at all.  (hipcc answers ordinary loads inside this loop with a `s_waitcnt vmcnt(0)` at the
+//     top of every K-step, which drains the DMA ring.)
+//   * the 7 x BM source byte offsets of a tile live in an LDS table built one tile ahead; bit 31 marks side-buffer
+//     (or empty) rows, which are out of range for the source resource by construction (tensors < 2 GiB).
+//   * persistent blocks walk tiles b, b+G, ...: the DMA pointer runs two K-steps ahead of the MFMA pointer and
+//     crosses into the next tile, so the MFMA pipe does not drain at tile boundaries and launches are not rounded
+//     up to whole dispatch waves.
 // ---------------------------------------------------------------------------------------------------------
 using lds_ptr_t = __attribute__((address_space(3))) void*;
 
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(integral_constant<int, N-1>{})
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-constexpr unsigned OOB_OFFSET = 0x80000000u;
+// Row offsets of the DMA kernels: < 2^31 byte offset into the source tensor; SIDE_FLAG | offset (< 2^30) a row of the side
+// buffer; NOTHING_OFFSET a row of zeros.  Both flagged forms are out of range for the source resource (tensors < 2 GiB) and
+// stay so when chunk / k-chunk offsets (< 2^30) are added, without wrapping; as signed ints: side < NOTHING_OFFSET <= pixel.
+constexpr unsigned SIDE_FLAG = 0x80000000u;
+constexpr unsigned NOTHING_OFFSET = 0xC0000000u;
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void k_conv_dma(
@@ -315,11 +332,11 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     const float* __restrict__ wt,       // [7][N][K]
     const float* __restrict__ bias,     // [N] or null
     float* __restrict__ dst,            // (B, Pd, N)
-    const int32_t* __restrict__ idx,    // [7][E][Pd]
-    const uint8_t* __restrict__ slowtab,// [Pd] or null (no slow rows)
+    const int32_t* __restrict__ dcode,  // DmaTable code [7][Pd] (row order: pre-permuted when perm != null)
+    const float* __restrict__ side,     // (B, n_slots, K) or null
     const int32_t* __restrict__ perm,   // [Pd] row -> dst pixel, or null (identity)
     const uint8_t* __restrict__ mask32, // [Pd/32] taps in use per 32 rows, or null (all 7)
-    int M, int Ps, int Pd, int K, int N, int E, int ns, unsigned src_bytes, int ntiles) {
+    int M, int Ps, int Pd, int K, int N, int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;          // rows per lane (one 16-byte chunk of each)
@@ -338,6 +355,8 @@ __global__ __launch_bounds__(256) void k_conv_dma(
 
     const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
     const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, 7 * N * K * 4, 0x00020000);
+    const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side ? side : src), 0, side ? side_bytes : 0u,
+                                                          0x00020000);
 
     // XCD-aware tile order: tiles with equal index mod 8 (one persistent block's residue class, hence one XCD
     // and one L2) form a contiguous run of (m, n) tiles.
@@ -356,16 +375,16 @@ __global__ __launch_bounds__(256) void k_conv_dma(
         const int row = 8 * (wave + 4 * i) + rsub;
         bconst[i] = (unsigned)row * (unsigned)K * 4u + 16u * (pc ^ swz(row));
     }
-    // Row-offset table of one tile (built cooperatively, one tile ahead): byte offset of the row's source pixel, or
-    // an out-of-range offset (the DMA's range check then writes zeros) for rows that gather nothing.
+    // Row-offset table of one tile (built cooperatively, one tile ahead).
     auto build_table = [&](int slot, int m0) {
         for (int e = tid; e < 7 * BM; e += 256) {
             const int t = e / BM, row = e % BM, m = m0 + row;
-            unsigned base = OOB_OFFSET;
+            unsigned base = NOTHING_OFFSET;
             if (m < M) {
-                const int b = m / Pd, p = m % Pd;        // idx / slowtab are in ROW order (pre-permuted when perm != null)
-                const int32_t c = idx[(size_t)(t * E) * Pd + p];
+                const int b = m / Pd, p = m % Pd;
+                const int32_t c = dcode[(size_t)t * Pd + p];
                 if (c >= 0) base = (unsigned)(b * Ps + c) * (unsigned)K * 4u;
+                else if (c <= -2) base = SIDE_FLAG | ((unsigned)(b * n_slots + (-2 - c)) * (unsigned)K * 4u);
             }
             otab[slot * 7 * BM + e] = base;
         }
@@ -381,17 +400,6 @@ __global__ __launch_bounds__(256) void k_conv_dma(
             if (mk == 0) mk = 1;                         // never an empty step list
         }
         return (unsigned)__builtin_amdgcn_readfirstlane((int)mk);
-    };
-    auto load_slow = [&](int m0) {                       // bit 7*i + t: row i of this lane is slow for tap t
-        unsigned sl = 0;
-        if (slowtab) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                const int m = m0 + 8 * (wave + 4 * i) + rsub;
-                if (m < M) sl |= (unsigned)(slowtab[m % Pd] & 0x7f) << (7 * i);
-            }
-        }
-        return sl;
     };
     f32x16 acc[TM][TN];
     auto zero_acc = [&]() {
@@ -440,21 +448,19 @@ __global__ __launch_bounds__(256) void k_conv_dma(
 
     // ---- 3-stage LDS ring: while step s computes from stage s, stages s+1 and s+2 are landed / in flight.
     //   top of step s : issue stage s+2 into ring slot (s+2)%3 -- last read in step s-1, and every wave has passed
-    //                   the barrier that ended step s-1.  Rows of this lane that gather a single pixel are DMA'd;
-    //                   "slow" rows (pole mean / several transposed entries) are masked out of the DMA and summed in
-    //                   registers from ordinary loads issued BEFORE the DMA, so that ...
-    //   end of step s : ... waiting until only the youngest NDMA operations (stage s+2's DMA) are outstanding means
-    //                   stage s+1 has landed AND stage s+2's slow-row sums are in registers; those are written into
-    //                   stage s+2's slot; a raw barrier publishes stage s+1.  (__syncthreads() would drain vmcnt
-    //                   to 0 and serialise the ring.)
+    //                   the barrier that ended step s-1.
+    //   end of step s : waiting until only the youngest NDMA operations (stage s+2's DMA) are outstanding means
+    //                   stage s+1 has landed; a raw barrier publishes it.  (__syncthreads() would drain vmcnt to 0 and
+    //                   serialise the ring.)  A stage that had side-buffer rows issues a lane-masked pair of DMAs per
+    //                   row, whose instruction count is not fixed (an all-masked one is branched over): such a step
+    //                   (p_exact = 0) waits for vmcnt(0) instead.
     // The DMA pointer (i_*) runs two steps ahead of the compute pointer and crosses into the next tile, so the MFMA
-    // pipe does not drain at tile boundaries; the first two iterations (c_step < 0) only fill the ring.
+    // pipe does not drain at tile boundaries; the first two iterations only fill the ring.
     // All loop state is kept in plain ints and passed through readfirstlane: hipcc must see the DMA's LDS base
     // and scalar offset as wave-uniform or it wraps every DMA in a waterfall loop.
     int tile = blockIdx.x, m0, n0;
     tile_origin(tile, m0, n0);
     build_table(0, m0);
-    unsigned slow_c = load_slow(m0), slow_n = 0;
     __syncthreads();
     int slot = 0;                                         // offset-table slot of the compute tile
     int next_tile = tile + gridDim.x;
@@ -463,51 +469,44 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     if (has_next) tile_origin(next_tile, nm0, nn0);
     unsigned mask_c = tile_taps(m0), mask_n = has_next ? tile_taps(nm0) : 0x7fu;   // taps of the compute / next tile
     int i_t = __ffs(mask_c) - 1, i_kc = 0, i_ring = 0, i_own = 1, i_live = 1;       // DMA pointer; i_own: inside compute tile
-    f32x4 ex[RA];
     unsigned pbase[RA];                                   // row offsets of the next stage to be issued (prefetched)
 #pragma unroll
     for (int i = 0; i < RA; ++i) pbase[i] = otab[i_t * BM + 8 * (wave + 4 * i) + rsub];
-    unsigned p_slow = 0;                                  // slow rows (bit 7*i) of the stage issued this step
-    int p_ring = 0, issued = 0;
-    // Issue the stage under the DMA pointer (slow-row loads first, then the DMA with those lanes masked off),
-    // advance the pointer, prefetch the next stage's row offsets.  One level of forced inlining, int state only.
+    int issued = 0, p_exact = 1;
+    // Issue the stage under the DMA pointer, advance the pointer, prefetch the next stage's row offsets.
     // (macros, not lambdas: hipcc spilled the captured loop state of a lambda to scratch, and a scratch load is a
     // VMEM op whose vmcnt(0) wait drains the DMA ring)
 #define ICN_ISSUE_STAGE() do { \
-        p_slow = 0; \
-        p_ring = i_ring; \
         issued = i_live; \
+        p_exact = 1; \
         if (i_live) { \
-            const int t = i_t, kc = i_kc; \
-            const int tm0 = __builtin_amdgcn_readfirstlane(i_own ? m0 : nm0); \
             const int tn0 = __builtin_amdgcn_readfirstlane(i_own ? n0 : nn0); \
-            p_slow = ((i_own ? slow_c : slow_n) >> t) & 0x10204081u; \
-            if (p_slow) { \
+            const int a_soff = __builtin_amdgcn_readfirstlane(i_kc * (BK * 4)); \
+            const int b_soff = __builtin_amdgcn_readfirstlane(((i_t * N + tn0) * K + i_kc * BK) * 4); \
+            bool side_row = false; \
+_Pragma("unroll") \
+            for (int i = 0; i < RA; ++i) side_row |= (int)pbase[i] < (int)NOTHING_OFFSET; \
+            if (__builtin_amdgcn_ballot_w64(side_row) == 0) { \
 _Pragma("unroll") \
                 for (int i = 0; i < RA; ++i) { \
-                    if (!((p_slow >> (i * 7)) & 1)) continue; \
-                    const int row = 8 * (wave + 4 * i) + rsub, m = tm0 + row; \
-                    const int b = m / Pd, p = m % Pd, ch = kc * BK + 4 * (pc ^ swz(row)); \
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f}; \
-                    for (int e = 0; e < E; ++e) { \
-                        const int32_t c = idx[(size_t)(t * E + e) * Pd + p]; \
-                        if (c >= 0) v += ld4(src + ((size_t)b * Ps + c) * K + ch); \
-                        else if (c <= -2) v += pole_mean4(src, b, Ps, ns, -2 - c, K, ch); \
-                    } \
-                    ex[i] = v; \
-                } \
-            } \
-            const int a_soff = __builtin_amdgcn_readfirstlane(kc * (BK * 4)); \
-            const int b_soff = __builtin_amdgcn_readfirstlane(((t * N + tn0) * K + kc * BK) * 4); \
-_Pragma("unroll") \
-            for (int i = 0; i < RA; ++i) { \
-                float* lds_dst = As + __builtin_amdgcn_readfirstlane(p_ring * BM * BK + 8 * (wave + 4 * i) * BK); \
-                if (!((p_slow >> (i * 7)) & 1)) \
+                    float* lds_dst = As + __builtin_amdgcn_readfirstlane(i_ring * BM * BK + 8 * (wave + 4 * i) * BK); \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)lds_dst, 16, pbase[i] + achunk[i], a_soff, 0, 0); \
+                } \
+            } else { \
+                p_exact = 0; \
+_Pragma("unroll") \
+                for (int i = 0; i < RA; ++i) { \
+                    float* lds_dst = As + __builtin_amdgcn_readfirstlane(i_ring * BM * BK + 8 * (wave + 4 * i) * BK); \
+                    if ((int)pbase[i] >= (int)NOTHING_OFFSET) \
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)lds_dst, 16, pbase[i] + achunk[i], a_soff, 0, 0); \
+                    else \
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_ptr_t)lds_dst, 16, \
+                                                                 (pbase[i] & ~SIDE_FLAG) + achunk[i], a_soff, 0, 0); \
+                } \
             } \
 _Pragma("unroll") \
             for (int i = 0; i < RB; ++i) { \
-                float* lds_dst = Bs + __builtin_amdgcn_readfirstlane(p_ring * BN * BK + 8 * (wave + 4 * i) * BK); \
+                float* lds_dst = Bs + __builtin_amdgcn_readfirstlane(i_ring * BN * BK + 8 * (wave + 4 * i) * BK); \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)lds_dst, 16, bconst[i], b_soff, 0, 0); \
             } \
             i_ring = i_ring == 2 ? 0 : i_ring + 1; \
@@ -532,31 +531,21 @@ _Pragma("unroll") \
             } \
         } \
     } while (0)
-    // End of a K-step: retire the previous stage (and this step's slow-row loads), write the slow-row sums into the
-    // slot of the stage issued this step, publish.
+    // End of a K-step: retire the previous stage, publish.
 #define ICN_RETIRE_AND_PUBLISH() do { \
-        if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); \
+        if (issued && p_exact) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-        if (p_slow) { \
-_Pragma("unroll") \
-            for (int i = 0; i < RA; ++i) \
-                if ((p_slow >> (i * 7)) & 1) \
-                    *reinterpret_cast<f32x4*>(As + p_ring * BM * BK + (8 * (wave + 4 * i) + rsub) * BK + 4 * pc) = ex[i]; \
-        } \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         __builtin_amdgcn_s_barrier(); \
     } while (0)
-    ICN_ISSUE_STAGE();                                    // ring fill: stages 0 and 1 (K >= 32 => >= 7 steps per tile)
+    ICN_ISSUE_STAGE();                                    // ring fill: stages 0 and 1 (>= 4 steps per tile)
     ICN_RETIRE_AND_PUBLISH();
     ICN_ISSUE_STAGE();
     ICN_RETIRE_AND_PUBLISH();
     zero_acc();
     int c_ring = 0;
     for (;;) {
-        if (has_next) {                                   // next tile's row offsets: consumed >= 5 K-steps from now
-            build_table(slot ^ 1, nm0);
-            slow_n = load_slow(nm0);
-        }
+        if (has_next) build_table(slot ^ 1, nm0);         // next tile's row offsets: consumed >= 2 K-steps from now
         const int S = __popc(mask_c) * nk;                // K-steps of this tile
         for (int step = 0; step < S; ++step) {
             frag0(c_ring);
@@ -586,7 +575,6 @@ _Pragma("unroll") \
         tile = next_tile;
         m0 = nm0;
         n0 = nn0;
-        slow_c = slow_n;
         mask_c = mask_n;
         slot ^= 1;
         i_own = 1;                                        // the DMA pointer is already inside this tile
@@ -615,18 +603,21 @@ static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
         attr_set = true;
     }
     const unsigned src_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.Ps * a.K * 4);
+    const unsigned side_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.n_slots * a.K * 4);
     prof_mark_begin(BM == 64 ? (BN == 128 ? PROF_DMA_64x128 : PROF_DMA_64x64) : (BN == 128 ? PROF_DMA_128x128 : PROF_DMA_128x64),
                     a.algo_flops, s);
-    hipLaunchKernelGGL((k_conv_dma<BM, BN>), dim3(grid), dim3(256), lds, s, a.src, a.wt, a.bias, a.dst, a.idx, a.slow, a.perm,
-                       a.mask32, a.M,
-                       a.Ps, a.Pd, a.K, a.N, a.E, a.ns, src_bytes, ntiles);
+    hipLaunchKernelGGL((k_conv_dma<BM, BN>), dim3(grid), dim3(256), lds, s, a.src, a.wt, a.bias, a.dst, a.dcode,
+                       a.n_slots > 0 ? a.side : nullptr, a.perm, a.mask32, a.M, a.Ps, a.Pd, a.K, a.N, a.n_slots, src_bytes, side_bytes,
+                       ntiles);
     prof_mark_end(s);
 }
 
 static bool conv_dma_usable(const GatherGemmArgs& a) {
     if (dbg_flags() & 16) return false;
     const size_t src_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.K * 4, wt_bytes = (size_t)7 * a.N * a.K * 4;
-    if (a.E != 1 && a.slow == nullptr) return false;      // multi-entry tables need their slow-row mask
+    const size_t side_bytes = (size_t)(a.M / a.Pd) * a.n_slots * a.K * 4;
+    if (a.dcode == nullptr || (a.n_slots > 0 && a.side == nullptr)) return false;   // needs the DmaTable form + side buffer
+    if (side_bytes >= ((size_t)1 << 30)) return false;
     // The cross-tile pipeline needs >= 4 K-steps per tile: the next tile's offset table is built in the tile's first
     // step and published by that step's barrier, and the DMA pointer (2 steps ahead) prefetches the next stage's row
     // offsets one step earlier still, i.e. in step S-3 >= 1.  With tap masks a tile may use a single tap.
@@ -817,10 +808,12 @@ __global__ __launch_bounds__(256) void k_wgrad(
 // ---------------------------------------------------------------------------------------------------------
 // k_wgrad_dma: same math as k_wgrad, staged by LDS-DMA through a 3-stage ring of 16-row stages.
 //   A stage = 16 consecutive output rows m: X[16][BI] (gathered input rows of tap t, channels ci0..) and Y[16][BJ]
-//   (dy rows, channels co0..).  A lane's gather code for stage s+3 is fetched (plain load) at step s, turned into a
-//   byte offset at step s+1 and used by the DMA of stage s+3 issued there; rows whose tap reads a pole are masked out
-//   of the DMA and patched from registers (pole mean), exactly as in k_conv_dma.  Plain loads are always issued BEFORE
-//   the step's DMA, so the single counted vmcnt at the end of a step retires the previous stage and those loads.
+//   (dy rows, channels co0..).  A lane's gather code (forward DmaTable) for stage s+3 is fetched at step s, turned
+//   into a byte offset at step s+1 and used by the DMA of stage s+3 issued there; rows whose tap reads a pole are
+//   DMA'd from the side buffer of pole means (k_conv_prologue), as in k_conv_dma.  The code fetch is itself an
+//   LDS-DMA (one dword per lane into a wave-private LDS slot, read back with ds_read one step later): a load into
+//   a VGPR would have to be tracked by the compiler, which then drains vmcnt to 0 every step.  It is issued BEFORE
+//   the step's data DMA, so the counted vmcnt at the end of the step retires it together with the previous stage.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int WG_RS = 16;   // rows per stage
 
@@ -828,10 +821,12 @@ template <int BI, int BJ>
 __global__ __launch_bounds__(256) void k_wgrad_dma(
     const float* __restrict__ x,        // (B, Ps, Cin)
     const float* __restrict__ dy,       // (B, Pd, Cout)
-    const int32_t* __restrict__ idx,    // forward table [7][Pd]
+    const int32_t* __restrict__ dcode,  // forward DmaTable code [7][Pd]
+    const float* __restrict__ side,     // (B, n_slots, Cin) pole means of x, or null
     float* __restrict__ partial,        // [S][7][Cin][Cout]
     float* __restrict__ bias_partial,   // [S][Cout] or null
-    int M, int Ps, int Pd, int Cin, int Cout, int ns, int rows_per_split, unsigned x_bytes, unsigned dy_bytes) {
+    int M, int Ps, int Pd, int Cin, int Cout, int n_slots, int rows_per_split, unsigned x_bytes, unsigned dy_bytes,
+    unsigned side_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TI = BI / 64, TJ = BJ / 64;
     constexpr int LA = BI / 4, LB = BJ / 4;            // lanes (16-byte chunks) per row
@@ -841,6 +836,7 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Xs = reinterpret_cast<float*>(smem);        // [3][WG_RS][BI]
     float* Ys = Xs + 3 * WG_RS * BI;                   // [3][WG_RS][BJ]
+    int32_t* Cs = reinterpret_cast<int32_t*>(Ys + 3 * WG_RS * BJ);   // [2][4 waves][NA][64] gather codes (wave-private)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -860,6 +856,9 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
 
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
     const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, dy_bytes, 0x00020000);
+    const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side ? side : x), 0, side ? side_bytes : 0u,
+                                                          0x00020000);
+    const auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(dcode + (size_t)t * Pd), 0, Pd * 4, 0x00020000);
 
     f32x16 acc[TI][TJ];
 #pragma unroll
@@ -882,94 +881,103 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
         c_b[i] = m / Pd;
         c_p[i] = m % Pd;
     }
-    int32_t code[NA];                                  // codes of the stage the DMA pointer will issue next
     unsigned aoff[NA];
-    f32x4 ex[NA];
-    unsigned p_slow = 0;
     int d_ring = 0, d_step = 0;                        // DMA pointer: ring slot and stage index
-    int p_ring = 0, issued = 0;
+    int c_slot = 0;                                    // code ring slot the next fetch writes
+    int issued = 0, p_exact = 1;
 
-    // fetch the gather codes of the stage under the code pointer, advance the pointer by one stage
+    // fetch the gather codes of the stage under the code pointer into code slot c_slot (c_p is always a valid pixel;
+    // rows past m_end are sorted out in ICN_WG_MAKE_OFFSETS)
 #define ICN_WG_FETCH_CODES() do { \
         _Pragma("unroll") \
         for (int i = 0; i < NA; ++i) { \
-            const int m = c_m0 + (wave + 4 * i) * RPA + arow; \
-            code[i] = m < m_end ? idx[(size_t)t * Pd + c_p[i]] : -1; \
+            int32_t* dst_ = Cs + __builtin_amdgcn_readfirstlane(((c_slot * 4 + wave) * NA + i) * 64); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)dst_, 4, (unsigned)c_p[i] * 4u, 0, 0, 0); \
         } \
+        c_slot ^= 1; \
     } while (0)
 #define ICN_WG_ADVANCE_CODE_PTR() do { \
         c_m0 += WG_RS; \
         _Pragma("unroll") \
         for (int i = 0; i < NA; ++i) { c_p[i] += WG_RS; while (c_p[i] >= Pd) { c_p[i] -= Pd; c_b[i] += 1; } } \
     } while (0)
-    // codes -> byte offsets (uses the row state BEFORE it is advanced); pole codes become slow rows
+    // codes (fetched one step ago into slot c_slot ^ 1, landed and retired by that step's counted wait) -> byte offsets;
+    // uses the row state BEFORE it is advanced; bit 31: side buffer (pole mean) or nothing
 #define ICN_WG_MAKE_OFFSETS() do { \
-        p_slow = 0; \
         _Pragma("unroll") \
         for (int i = 0; i < NA; ++i) { \
-            const int32_t c = code[i]; \
-            aoff[i] = c >= 0 ? ((unsigned)(c_b[i] * Ps + c) * (unsigned)Cin + (unsigned)(ci0 + 4 * achunk)) * 4u : OOB_OFFSET; \
-            if (c <= -2) { \
-                p_slow |= 1u << i; \
-                ex[i] = pole_mean4(x, c_b[i], Ps, ns, -2 - c, Cin, ci0 + 4 * achunk); \
-            } \
+            const int m = c_m0 + (wave + 4 * i) * RPA + arow; \
+            const int32_t c = m < m_end ? Cs[(((c_slot ^ 1) * 4 + wave) * NA + i) * 64 + lane] : -1; \
+            aoff[i] = c >= 0 ? ((unsigned)(c_b[i] * Ps + c) * (unsigned)Cin + (unsigned)(ci0 + 4 * achunk)) * 4u \
+                    : c == -1 ? NOTHING_OFFSET \
+                              : SIDE_FLAG | (((unsigned)(c_b[i] * n_slots + (-2 - c)) * (unsigned)Cin + (unsigned)(ci0 + 4 * achunk)) * 4u); \
         } \
     } while (0)
     // issue the DMA of stage d_step into ring slot d_ring (offsets prepared by ICN_WG_MAKE_OFFSETS)
 #define ICN_WG_ISSUE() do { \
-        p_ring = d_ring; \
         issued = d_step < nsteps; \
+        p_exact = 1; \
         if (issued) { \
+            bool side_row = false; \
             _Pragma("unroll") \
-            for (int i = 0; i < NA; ++i) { \
-                float* dst_ = Xs + __builtin_amdgcn_readfirstlane(p_ring * WG_RS * BI + (wave + 4 * i) * RPA * BI); \
-                if (!((p_slow >> i) & 1)) \
+            for (int i = 0; i < NA; ++i) side_row |= (int)aoff[i] < (int)NOTHING_OFFSET; \
+            if (__builtin_amdgcn_ballot_w64(side_row) == 0) { \
+                _Pragma("unroll") \
+                for (int i = 0; i < NA; ++i) { \
+                    float* dst_ = Xs + __builtin_amdgcn_readfirstlane(d_ring * WG_RS * BI + (wave + 4 * i) * RPA * BI); \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst_, 16, aoff[i], 0, 0, 0); \
+                } \
+            } else { \
+                p_exact = 0; \
+                _Pragma("unroll") \
+                for (int i = 0; i < NA; ++i) { \
+                    float* dst_ = Xs + __builtin_amdgcn_readfirstlane(d_ring * WG_RS * BI + (wave + 4 * i) * RPA * BI); \
+                    if ((int)aoff[i] >= (int)NOTHING_OFFSET) \
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst_, 16, aoff[i], 0, 0, 0); \
+                    else \
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_ptr_t)dst_, 16, aoff[i] & ~SIDE_FLAG, 0, 0, 0); \
+                } \
             } \
             const int y_soff = __builtin_amdgcn_readfirstlane((m_begin + d_step * WG_RS) * Cout * 4); \
             _Pragma("unroll") \
             for (int i = 0; i < NB; ++i) { \
-                float* dst_ = Ys + __builtin_amdgcn_readfirstlane(p_ring * WG_RS * BJ + (wave + 4 * i) * RPB * BJ); \
+                float* dst_ = Ys + __builtin_amdgcn_readfirstlane(d_ring * WG_RS * BJ + (wave + 4 * i) * RPB * BJ); \
                 const int row_ = (wave + 4 * i) * RPB + brow; \
                 const unsigned voff_ = (m_begin + d_step * WG_RS + row_ < m_end) \
-                                           ? ((unsigned)row_ * (unsigned)Cout + (unsigned)(co0 + 4 * bchunk)) * 4u : OOB_OFFSET; \
+                                           ? ((unsigned)row_ * (unsigned)Cout + (unsigned)(co0 + 4 * bchunk)) * 4u : SIDE_FLAG; \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)dst_, 16, voff_, y_soff, 0, 0); \
             } \
             d_ring = d_ring == 2 ? 0 : d_ring + 1; \
             d_step += 1; \
         } \
     } while (0)
+    // end of a step: the previous stage has landed (and the codes fetched before this step's DMA have arrived); publish
 #define ICN_WG_RETIRE_AND_PUBLISH() do { \
-        if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); \
+        if (issued && p_exact) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-        if (p_slow && issued) { \
-            _Pragma("unroll") \
-            for (int i = 0; i < NA; ++i) \
-                if ((p_slow >> i) & 1) \
-                    *reinterpret_cast<f32x4*>(Xs + p_ring * WG_RS * BI + ((wave + 4 * i) * RPA + arow) * BI + 4 * achunk) = ex[i]; \
-        } \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         __builtin_amdgcn_s_barrier(); \
     } while (0)
 
     // ring fill: stages 0 and 1; codes for stage 2 in flight
     ICN_WG_FETCH_CODES();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ICN_WG_MAKE_OFFSETS();
     ICN_WG_ADVANCE_CODE_PTR();
+    ICN_WG_FETCH_CODES();                               // codes of stage 1 (before the DMA, retired with it)
     ICN_WG_ISSUE();
     ICN_WG_RETIRE_AND_PUBLISH();
-    ICN_WG_FETCH_CODES();
     ICN_WG_MAKE_OFFSETS();
     ICN_WG_ADVANCE_CODE_PTR();
-    ICN_WG_ISSUE();
-    ICN_WG_RETIRE_AND_PUBLISH();
     ICN_WG_FETCH_CODES();                               // codes of stage 2, consumed at the top of step 0
+    ICN_WG_ISSUE();
+    ICN_WG_RETIRE_AND_PUBLISH();
     int c_ring = 0;
     for (int step = 0; step < nsteps; ++step) {
-        // stage step+2: offsets from the codes fetched one step ago, slow-row loads, next codes, then the DMA
+        // stage step+2: offsets from the codes fetched one step ago, next codes, then the DMA
         ICN_WG_MAKE_OFFSETS();
         ICN_WG_ADVANCE_CODE_PTR();
-        ICN_WG_FETCH_CODES();                           // stage step+3 (plain loads, issued before the DMA)
+        ICN_WG_FETCH_CODES();                           // stage step+3 (issued before the DMA)
         ICN_WG_ISSUE();
         const float* xa = Xs + c_ring * WG_RS * BI + wr * (BI / 2) + l31;
         const float* yb = Ys + c_ring * WG_RS * BJ + wc * (BJ / 2) + l31;
@@ -1207,13 +1215,16 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         dim3 grid((a.Cin / BI) * (a.Cout / BJ) * 7 * S);        // S is a multiple of 8 (see wgrad_splits)
         const size_t lds = (size_t)2 * 32 * (BI + BJ) * 4;
         const size_t x_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.Cin * 4, dy_bytes = (size_t)a.M * a.Cout * 4;
-        const bool dma = !(dbg_flags() & 32) && x_bytes < ((size_t)1 << 31) && dy_bytes < ((size_t)1 << 31);
-        const size_t lds_dma = (size_t)3 * WG_RS * (BI + BJ) * 4;
+        const size_t side_bytes = (size_t)(a.M / a.Pd) * a.n_slots * a.Cin * 4;
+        const bool dma = !(dbg_flags() & 32) && a.dcode != nullptr && (a.n_slots == 0 || a.side != nullptr) &&
+                         x_bytes < ((size_t)1 << 31) && dy_bytes < ((size_t)1 << 31) && side_bytes < ((size_t)1 << 30);
+        const size_t lds_dma = (size_t)3 * WG_RS * (BI + BJ) * 4 + (size_t)2 * 4 * 2 * 64 * 4;   // + code ring (NA <= 2)
 #define ICN_WG(I, J)                                                                                                       \
     do {                                                                                                                   \
         if (dma)                                                                                                           \
-            hipLaunchKernelGGL((k_wgrad_dma<I, J>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, \
-                               a.M, a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows, (unsigned)x_bytes, (unsigned)dy_bytes);         \
+            hipLaunchKernelGGL((k_wgrad_dma<I, J>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.dcode,                         \
+                               a.n_slots > 0 ? a.side : nullptr, a.partial, a.bias_partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout,   \
+                               a.n_slots, rows, (unsigned)x_bytes, (unsigned)dy_bytes, (unsigned)side_bytes);                \
         else                                                                                                               \
             hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M,   \
                                a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows);                                                     \
@@ -1354,9 +1365,13 @@ void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int 
                        nv, P, C);
 }
 
-void launch_pack_weights(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t s) {
-    const int total = Cout * Cin * 7;
-    hipLaunchKernelGGL(k_pack_weights, dim3(std::min(2048, (total + 255) / 256)), dim3(256), 0, s, w, out, Cout, Cin, transpose);
+void launch_conv_prologue(const float* w, float* packed, int Cout, int Cin, int transpose, const float* src, const int32_t* slots,
+                          float* side, int n_slots, int E, int B, int Ps, int K, int ns, hipStream_t s) {
+    const int npack = w ? std::min(2048, (Cout * Cin * 7 + 255) / 256) : 0;
+    const int nside = (side && n_slots > 0) ? B * n_slots : 0;
+    if (npack + nside == 0) return;
+    hipLaunchKernelGGL(k_conv_prologue, dim3(npack + nside), dim3(256), 0, s, w, packed, Cout, Cin, transpose, npack, src, slots,
+                       side, n_slots, E, Ps, K, ns);
 }
 
 }  // namespace icn

@@ -10,8 +10,10 @@ struct GatherGemmArgs {
     const float* wt;        // [7][N][K]
     const float* bias;      // [N] or null
     float* dst;             // (B, Pd, N)
-    const int32_t* idx;     // [7][E][Pd]
-    const uint8_t* slow;    // [Pd] per-row mask of taps needing the slow gather
+    const int32_t* idx;     // [7][E][Pd] full table (register-staged fall-back kernel)
+    const int32_t* dcode;   // DmaTable code [7][Pd] of the same table (LDS-DMA kernel), or null
+    const float* side;      // (B, n_slots, K) side buffer filled by launch_conv_prologue, or null
+    int n_slots;
     const int32_t* perm;    // [Pd] or null
     const uint8_t* mask32;  // [Pd/32] or null
     int M, Ps, Pd, K, N, E, ns;
@@ -22,6 +24,9 @@ struct WgradArgs {
     const float* x;         // (B, Ps, Cin)
     const float* dy;        // (B, Pd, Cout)
     const int32_t* idx;     // forward table [7][Pd]
+    const int32_t* dcode;   // its DmaTable code [7][Pd] (LDS-DMA kernel), or null
+    const float* side;      // (B, n_slots, Cin) pole means of x filled by launch_conv_prologue, or null
+    int n_slots;
     float* partial;         // [S][7][Cin][Cout]
     float* bias_partial;    // [S][Cout] (null when dbias is null)
     float* dw;              // [Cout][Cin][7]
@@ -49,7 +54,10 @@ void launch_conv_generic(const float* src, const float* w, const float* bias, fl
 // dst[b, q[v], :] += src[b, v, :]   (q sorted; rows of one q are summed in order by one thread => deterministic)
 void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int B, int nv, int P, int C, hipStream_t s);
 
-void launch_pack_weights(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t s);
+// One launch ahead of a conv call: repack the weights (skipped when w is null) and fill the side buffer of a DmaTable
+// (skipped when side is null or n_slots == 0) from `src` (B, Ps, K).
+void launch_conv_prologue(const float* w, float* packed, int Cout, int Cin, int transpose, const float* src, const int32_t* slots,
+                          float* side, int n_slots, int E, int B, int Ps, int K, int ns, hipStream_t s);
 
 // ---- fused BatchNorm (+ residual) + ReLU (icn_bn.hip); stat = [mean | invstd] (2*C), sums = NS*C, ws = chunks*NS*C floats
 bool bn_supported(int C);
