@@ -58,8 +58,10 @@ struct ConvTables {
     int32_t* fwd = nullptr;    // [7][Pout]
     int32_t* bwd = nullptr;    // [7][E][Pin]
     int32_t* bwd1 = nullptr;      // [7][Pin] primary (single plain pixel) entries of the transposed table
-    int nv = 0;                   // virtual rows: extra transposed entries, run as a second small GEMM
-    int32_t* vidx = nullptr;      // [7][nv]
+    int nv = 0, nvp = 0;          // virtual rows: extra transposed entries, run as a second small GEMM of nvp >= nv rows
+    int32_t* vidx = nullptr;      // [7][nvp] codes in GEMM row order (rows sorted by the taps they use, padded)
+    int32_t* vorder = nullptr;    // [nvp] GEMM row -> row of the (B, nvp, C) result (= virtual row; vq order)
+    uint8_t* vmask32 = nullptr;   // [nvp/32] taps in use per 32 GEMM rows
     int32_t* vq = nullptr;        // [nv] target input pixel (sorted)
     int32_t* perm = nullptr;   // [Pin] (stride 2 only)
     int32_t* bwd_perm = nullptr;  // [7][E][Pin] transposed table in permuted row order (stride 2 only)
@@ -103,8 +105,13 @@ const ConvTables& conv_tables(int r_in, int stride, int mode) {
     t.d_bwd1 = upload_dma(primary, 1, t.Pin);
     t.nv = vr.nv;
     if (vr.nv > 0) {
-        t.vidx = upload(vr.vidx);
-        t.d_virt = upload_dma(vr.vidx, 1, vr.nv);
+        std::vector<int32_t> order, vidx_o;
+        std::vector<uint8_t> vmask;
+        icn::build_virtual_order(vr, t.nvp, order, vidx_o, vmask);
+        t.vidx = upload(vidx_o);
+        t.vorder = upload(order);
+        t.vmask32 = upload(vmask);
+        t.d_virt = upload_dma(vidx_o, 1, t.nvp);
         t.vq = upload(vr.vq);
     }
     if (stride == 2) {
@@ -160,7 +167,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Table sizes the workspace query needs, per (r, stride): virtual rows of the stride-1 transposed gather and side-buffer
 // slots of each DmaTable, the larger of the two corner modes.  Host-only, cached.
-struct TableCounts { int nv = 0, slots_fwd = 0, slots_bwd = 0; };
+struct TableCounts { int nv = 0, slots_fwd = 0, slots_bwd = 0; };   // nv: padded (nvp)
 TableCounts table_counts(int r_in, int stride) {
     static std::mutex mu;
     static std::map<std::pair<int, int>, TableCounts> cache;
@@ -182,7 +189,7 @@ TableCounts table_counts(int r_in, int stride) {
         if (stride == 1) {
             icn::VirtualRows vr;
             icn::split_conv_bwd(r_in, 1, bwd, E, primary, vr);
-            c.nv = std::max(c.nv, vr.nv);
+            c.nv = std::max(c.nv, (vr.nv + 31) / 32 * 32);   // rows of the padded virtual-row GEMM
             if (vr.nv > 0) {
                 icn::build_dma_table(vr.vidx, 1, vr.nv, d);
                 c.slots_bwd = std::max(c.slots_bwd, d.n_slots);
@@ -371,10 +378,10 @@ int icn_conv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin
             icn::launch_gather_gemm_auto(a, s);
             if (split) {
                 // second, small GEMM over the virtual rows, then dx[b, vq[v], :] += result[b, v, :]
-                icn::GatherGemmArgs v{dy, wb, nullptr, vout, t.vidx, t.d_virt.code, side, t.d_virt.n_slots, nullptr, nullptr, B * t.nv,
-                                      t.Pout, t.nv, Cout, Cin, 1, t.n_out, 2.0 * 7 * Cin * Cout * (double)B * t.nv};
+                icn::GatherGemmArgs v{dy, wb, nullptr, vout, t.vidx, t.d_virt.code, side, t.d_virt.n_slots, t.vorder, t.vmask32,
+                                      B * t.nvp, t.Pout, t.nvp, Cout, Cin, 1, t.n_out, 2.0 * 7 * Cin * Cout * (double)B * t.nv};
                 icn::launch_gather_gemm_auto(v, s);
-                icn::launch_row_scatter_add(vout, dx, t.vq, B, t.nv, t.Pin, Cin, s);
+                icn::launch_row_scatter_add(vout, dx, t.vq, B, t.nv, t.nvp, t.Pin, Cin, s);
             }
         } else {
             icn::launch_conv_generic(dy, w, nullptr, dx, t.bwd, B, t.Pout, t.Pin, Cout, Cin, t.E, t.n_out, 1, s);

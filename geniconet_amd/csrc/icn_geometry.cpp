@@ -174,6 +174,25 @@ void split_conv_bwd(int r_in, int stride, const std::vector<int32_t>& bwd_idx, i
         for (int t = 0; t < NTAPS; ++t) vr.vidx[(size_t)t * vr.nv + v] = rows[v][t];
 }
 
+void build_virtual_order(const VirtualRows& vr, int& nvp, std::vector<int32_t>& order, std::vector<int32_t>& vidx_o,
+                         std::vector<uint8_t>& mask32) {
+    const int nv = vr.nv;
+    nvp = (nv + 31) / 32 * 32;
+    std::vector<unsigned> taps(nv, 0);
+    for (int v = 0; v < nv; ++v)
+        for (int t = 0; t < NTAPS; ++t)
+            if (vr.vidx[(size_t)t * nv + v] != IDX_ZERO) taps[v] |= 1u << t;
+    order.resize(nvp);
+    for (int k = 0; k < nvp; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.begin() + nv, [&](int x, int y) { return taps[x] < taps[y]; });
+    vidx_o.assign((size_t)NTAPS * nvp, IDX_ZERO);
+    mask32.assign(nvp / 32, 0);
+    for (int k = 0; k < nv; ++k) {
+        for (int t = 0; t < NTAPS; ++t) vidx_o[(size_t)t * nvp + k] = vr.vidx[(size_t)t * nv + order[k]];
+        mask32[k / 32] |= (uint8_t)taps[order[k]];
+    }
+}
+
 void build_dma_table(const std::vector<int32_t>& idx, int E, int P, DmaTable& out) {
     out.E = E;
     out.n_slots = 0;

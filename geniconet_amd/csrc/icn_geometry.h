@@ -45,6 +45,13 @@ struct VirtualRows {
 void split_conv_bwd(int r_in, int stride, const std::vector<int32_t>& bwd_idx, int E, std::vector<int32_t>& primary,
                     VirtualRows& vr);
 
+// Row order of the virtual-row GEMM.  A virtual row uses ~1 of the 7 taps, so GEMM rows are sorted by the set of taps
+// they use and padded to nvp = a multiple of 32 rows; 32-row groups then skip the taps none of their rows use (mask32,
+// as for stride-2 bwd-data).  order[k] = virtual row computed by GEMM row k (k >= nv: padding, order[k] = k), i.e. the
+// row of the (B, nvp, C) result it is stored to; vidx_o [7][nvp] = the codes in GEMM row order (padding: IDX_ZERO).
+void build_virtual_order(const VirtualRows& vr, int& nvp, std::vector<int32_t>& order, std::vector<int32_t>& vidx_o,
+                         std::vector<uint8_t>& mask32);
+
 // Gather table in the form the LDS-DMA kernels consume: one code per (tap, row), code [7][P]:
 //   >= 0       a single plain pixel (DMA'd straight from the source tensor)
 //   IDX_ZERO   nothing

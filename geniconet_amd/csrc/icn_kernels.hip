@@ -1343,7 +1343,7 @@ void launch_conv_generic(const float* src, const float* w, const float* bias, fl
 // back into dx.  q is sorted, so the thread that owns the first virtual row of a pixel adds all of them in order.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void k_row_scatter_add(const float* __restrict__ src, float* __restrict__ dst, const int32_t* __restrict__ q, int B,
-                                  int nv, int P, int C) {
+                                  int nv, int nvp, int P, int C) {
     const int c4n = C / 4;
     const size_t total = (size_t)B * nv * c4n;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -1354,15 +1354,15 @@ __global__ void k_row_scatter_add(const float* __restrict__ src, float* __restri
         if (v > 0 && q[v - 1] == qv) continue;            // not the first virtual row of this pixel
         float* d = dst + ((size_t)b * P + qv) * C + c;
         f32x4 acc = ld4(d);
-        for (int k = v; k < nv && q[k] == qv; ++k) acc += ld4(src + ((size_t)b * nv + k) * C + c);
+        for (int k = v; k < nv && q[k] == qv; ++k) acc += ld4(src + ((size_t)b * nvp + k) * C + c);
         *reinterpret_cast<f32x4*>(d) = acc;
     }
 }
 
-void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int B, int nv, int P, int C, hipStream_t s) {
+void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int B, int nv, int nvp, int P, int C, hipStream_t s) {
     const size_t total = (size_t)B * nv * (C / 4);
     hipLaunchKernelGGL(k_row_scatter_add, dim3((unsigned)std::min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s, src, dst, q, B,
-                       nv, P, C);
+                       nv, nvp, P, C);
 }
 
 void launch_conv_prologue(const float* w, float* packed, int Cout, int Cin, int transpose, const float* src, const int32_t* slots,

@@ -51,8 +51,9 @@ void launch_spmm_ell(const float* in, float* out, const int32_t* idx, const floa
 void launch_conv_generic(const float* src, const float* w, const float* bias, float* dst, const int32_t* idx, int B, int Ps,
                          int Pd, int K, int N, int E, int ns, int transpose, hipStream_t s);
 
-// dst[b, q[v], :] += src[b, v, :]   (q sorted; rows of one q are summed in order by one thread => deterministic)
-void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int B, int nv, int P, int C, hipStream_t s);
+// dst[b, q[v], :] += src[b, v, :], src (B, nvp, C), v < nv   (q sorted; rows of one q are summed in order by one thread
+// => deterministic)
+void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int B, int nv, int nvp, int P, int C, hipStream_t s);
 
 // One launch ahead of a conv call: repack the weights (skipped when w is null) and fill the side buffer of a DmaTable
 // (skipped when side is null or n_slots == 0) from `src` (B, Ps, K).

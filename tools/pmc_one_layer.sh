@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc_one_layer.sh <layer-substring> <outdir>   (GPU box; separate --pmc passes, kernel-trace only)
 set -e
-L="$1"; OUT="$2"; mkdir -p "$OUT"
+L="$1"; OUT="$(realpath -m "$2")"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT/$1 -- python3 $R/tools/bench_layers.py --only "$L" --iters 3 $EXTRA > $OUT/$1.log 2>&1; }
