@@ -61,11 +61,11 @@ struct ConvTables {
     int nv = 0, nvp = 0;          // virtual rows: extra transposed entries, run as a second small GEMM of nvp >= nv rows
     int32_t* vidx = nullptr;      // [7][nvp] codes in GEMM row order (rows sorted by the taps they use, padded)
     int32_t* vorder = nullptr;    // [nvp] GEMM row -> row of the (B, nvp, C) result (= virtual row; vq order)
-    uint8_t* vmask32 = nullptr;   // [nvp/32] taps in use per 32 GEMM rows
+    uint32_t* vmask32 = nullptr;  // [nvp/32] taps in use per 32 GEMM rows
     int32_t* vq = nullptr;        // [nv] target input pixel (sorted)
     int32_t* perm = nullptr;   // [Pin] (stride 2 only)
     int32_t* bwd_perm = nullptr;  // [7][E][Pin] transposed table in permuted row order (stride 2 only)
-    uint8_t* mask32 = nullptr; // [Pin/32] (stride 2 only)
+    uint32_t* mask32 = nullptr; // [Pin/32] (stride 2 only)
     DevDma d_fwd, d_bwd, d_bwd1, d_virt, d_bwdp;   // DmaTable forms of fwd, bwd, bwd1, vidx, bwd_perm
 };
 struct UpTables {
@@ -110,14 +110,14 @@ const ConvTables& conv_tables(int r_in, int stride, int mode) {
         icn::build_virtual_order(vr, t.nvp, order, vidx_o, vmask);
         t.vidx = upload(vidx_o);
         t.vorder = upload(order);
-        t.vmask32 = upload(vmask);
+        t.vmask32 = upload(std::vector<uint32_t>(vmask.begin(), vmask.end()));
         t.d_virt = upload_dma(vidx_o, 1, t.nvp);
         t.vq = upload(vr.vq);
     }
     if (stride == 2) {
         icn::build_bwd_row_order(r_in, stride, bwd, t.E, perm, mask);
         t.perm = upload(perm);
-        t.mask32 = upload(mask);
+        t.mask32 = upload(std::vector<uint32_t>(mask.begin(), mask.end()));
         // the same table in permuted row order (row k of a sample = pixel perm[k]): one load level in the kernels
         std::vector<int32_t> bwd_p(bwd.size());
         for (int te = 0; te < icn::NTAPS * t.E; ++te)

@@ -299,15 +299,22 @@ void build_bwd_row_order(int r_in, int stride, const std::vector<int32_t>& bwd_i
     const int n = 1 << r_in, Pin = 10 * n * n;
     perm.resize(Pin);
     for (int q = 0; q < Pin; ++q) perm[q] = q;
-    if (stride == 2) {
-        auto cls = [n](int q) { const int I = (q / (2 * n)) % n, J = q % (2 * n); return (I & 1) * 2 + (J & 1); };
-        std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return cls(x) < cls(y); });
-    }
-    mask32.assign((Pin + 31) / 32, 0);
-    for (int k = 0; k < Pin; ++k)
+    std::vector<unsigned> taps(Pin, 0);
+    for (int q = 0; q < Pin; ++q)
         for (int t = 0; t < NTAPS; ++t)
             for (int e = 0; e < E; ++e)
-                if (bwd_idx[((size_t)t * E + e) * Pin + perm[k]] != IDX_ZERO) mask32[k / 32] |= (uint8_t)(1u << t);
+                if (bwd_idx[((size_t)t * E + e) * Pin + q] != IDX_ZERO) taps[q] |= 1u << t;
+    if (stride == 2) {
+        // Rows grouped by lattice parity class (a class uses 1-2 of the 7 taps), and inside a class by the exact tap
+        // set: pixels on a chart seam reach their neighbours through other taps than interior pixels do, and every
+        // second 64-row tile would otherwise contain one of them and run its taps for all 64 rows.
+        auto cls = [n](int q) { const int I = (q / (2 * n)) % n, J = q % (2 * n); return (I & 1) * 2 + (J & 1); };
+        std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) {
+            return cls(x) != cls(y) ? cls(x) < cls(y) : taps[x] < taps[y];
+        });
+    }
+    mask32.assign((Pin + 31) / 32, 0);
+    for (int k = 0; k < Pin; ++k) mask32[k / 32] |= (uint8_t)taps[perm[k]];
 }
 
 void build_faces(int r, std::vector<int32_t>& faces) {

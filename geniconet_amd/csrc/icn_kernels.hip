@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(
     float* __restrict__ dst,            // (B, Pd, N)
     const int32_t* __restrict__ idx,    // [7][E][Pd]
     const int32_t* __restrict__ perm,   // [Pd] row -> dst pixel, or null (identity)
-    const uint8_t* __restrict__ mask32, // [Pd/32] taps in use per 32 rows, or null (all)
+    const uint32_t* __restrict__ mask32,// [Pd/32] taps in use per 32 rows, or null (all)
     int M, int Ps, int Pd, int K, int N, int E, int ns, int dbg) {
     constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (waves are 2 x 2)
     constexpr int RA = BM / 32, RB = BN / 32;      // 16-byte chunks each thread stages per tile
@@ -335,16 +335,21 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     const int32_t* __restrict__ dcode,  // DmaTable code [7][Pd] (row order: pre-permuted when perm != null)
     const float* __restrict__ side,     // (B, n_slots, K) or null
     const int32_t* __restrict__ perm,   // [Pd] row -> dst pixel, or null (identity)
-    const uint8_t* __restrict__ mask32, // [Pd/32] taps in use per 32 rows, or null (all 7)
+    const uint32_t* __restrict__ mask32,// [Pd/32] taps in use per 32 rows, or null (all 7)
     int M, int Ps, int Pd, int K, int N, int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;          // rows per lane (one 16-byte chunk of each)
     constexpr int NDMA = RA + RB;                      // DMA instructions per wave per stage
+    constexpr int RL = BM / 64;                        // tile rows per lane in the metadata pass (row r*64 + lane)
+    constexpr int NJ = 7 * RL;                         // code DMA instructions per tile (64 codes each)
+    constexpr int JW = (NJ + 3) / 4;                   // ... per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);        // [3][BM*32]   3-stage ring
     float* Bs = As + 3 * BM * BK;                      // [3][BN*32]
     unsigned* otab = reinterpret_cast<unsigned*>(Bs + 3 * BN * BK);   // [2][7][BM] source byte offset of each row
+    unsigned* drow_s = otab + 2 * 7 * BM;              // [3][BM] destination row of each tile row (perm != null only)
+    float* bias_s = reinterpret_cast<float*>(drow_s + (perm ? 3 * BM : 0));   // [3][BN] (bias != null only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -357,6 +362,9 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, 7 * N * K * 4, 0x00020000);
     const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side ? side : src), 0, side ? side_bytes : 0u,
                                                           0x00020000);
+    const auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(dcode), 0, 7 * Pd * 4, 0x00020000);
+    const auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(perm ? perm : dcode), 0, Pd * 4, 0x00020000);
+    const auto rsrc_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias ? bias : src), 0, bias ? N * 4 : 0, 0x00020000);
 
     // XCD-aware tile order: tiles with equal index mod 8 (one persistent block's residue class, hence one XCD
     // and one L2) form a contiguous run of (m, n) tiles.
@@ -375,21 +383,29 @@ __global__ __launch_bounds__(256) void k_conv_dma(
         const int row = 8 * (wave + 4 * i) + rsub;
         bconst[i] = (unsigned)row * (unsigned)K * 4u + 16u * (pc ^ swz(row));
     }
-    // Row-offset table of one tile (built cooperatively, one tile ahead).
-    auto build_table = [&](int slot, int m0) {
+    // gather code of row (sample b) -> DMA byte offset
+    auto row_offset = [&](int32_t c, int b) __attribute__((always_inline)) {
+        return c >= 0 ? (unsigned)(b * Ps + c) * (unsigned)K * 4u
+             : c == -1 ? NOTHING_OFFSET
+                       : SIDE_FLAG | ((unsigned)(b * n_slots + (-2 - c)) * (unsigned)K * 4u);
+    };
+    // Metadata of the block's FIRST tile, built synchronously with ordinary loads: row offsets, destination rows, bias.
+    // (Later tiles: ICN_META_ISSUE / ICN_META_CONVERT below, by LDS-DMA, one tile ahead.)
+    auto build_first = [&](int m0, int n0) {
         for (int e = tid; e < 7 * BM; e += 256) {
             const int t = e / BM, row = e % BM, m = m0 + row;
-            unsigned base = NOTHING_OFFSET;
-            if (m < M) {
-                const int b = m / Pd, p = m % Pd;
-                const int32_t c = dcode[(size_t)t * Pd + p];
-                if (c >= 0) base = (unsigned)(b * Ps + c) * (unsigned)K * 4u;
-                else if (c <= -2) base = SIDE_FLAG | ((unsigned)(b * n_slots + (-2 - c)) * (unsigned)K * 4u);
-            }
-            otab[slot * 7 * BM + e] = base;
+            otab[e] = m < M ? row_offset(dcode[(size_t)t * Pd + m % Pd], m / Pd) : NOTHING_OFFSET;
         }
+        if (perm)
+            for (int row = tid; row < BM; row += 256) {
+                const int m = m0 + row;
+                drow_s[row] = m < M ? (unsigned)((m / Pd) * Pd + perm[m % Pd]) : 0u;
+            }
+        if (bias)
+            for (int c = tid; c < BN; c += 256) bias_s[c] = bias[n0 + c];
     };
-    // taps in use by a tile (stride-2 dgrad: rows are grouped by lattice parity class, a class uses 1-2 taps)
+    // taps in use by a tile (stride-2 dgrad: rows are grouped by lattice parity class, a class uses 1-2 taps);
+    // wave-uniform index => scalar loads
     auto tile_taps = [&](int m0) __attribute__((always_inline)) {
         unsigned mk = 0x7f;
         if (mask32) {
@@ -456,13 +472,18 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     //                   (p_exact = 0) waits for vmcnt(0) instead.
     // The DMA pointer (i_*) runs two steps ahead of the compute pointer and crosses into the next tile, so the MFMA
     // pipe does not drain at tile boundaries; the first two iterations only fill the ring.
+    // The next tile's metadata (gather codes, destination rows, bias) is itself fetched by LDS-DMA at the top of the
+    // tile's first step -- ahead of that step's stage, so the step's counted wait retires it --, converted in place
+    // to byte offsets after that wait and published by the step's barrier; its first reader is the row-offset
+    // prefetch in step S-3 >= 1.  The persistent loop therefore contains no load into a VGPR at all: hipcc answers
+    // those with `s_waitcnt vmcnt(0)`, which drains the ring.
     // All loop state is kept in plain ints and passed through readfirstlane: hipcc must see the DMA's LDS base
     // and scalar offset as wave-uniform or it wraps every DMA in a waterfall loop.
     int tile = blockIdx.x, m0, n0;
     tile_origin(tile, m0, n0);
-    build_table(0, m0);
+    build_first(m0, n0);
     __syncthreads();
-    int slot = 0;                                         // offset-table slot of the compute tile
+    int slot = 0, eslot = 0;                              // offset-table slot / epilogue-table slot of the compute tile
     int next_tile = tile + gridDim.x;
     int has_next = next_tile < ntiles;
     int nm0 = m0, nn0 = n0;
@@ -473,6 +494,7 @@ __global__ __launch_bounds__(256) void k_conv_dma(
 #pragma unroll
     for (int i = 0; i < RA; ++i) pbase[i] = otab[i_t * BM + 8 * (wave + 4 * i) + rsub];
     int issued = 0, p_exact = 1;
+    int mb[RL];                                           // metadata pass: sample of the lane's rows in the next tile, or -1
     // Issue the stage under the DMA pointer, advance the pointer, prefetch the next stage's row offsets.
     // (macros, not lambdas: hipcc spilled the captured loop state of a lambda to scratch, and a scratch load is a
     // VMEM op whose vmcnt(0) wait drains the DMA ring)
@@ -531,41 +553,99 @@ _Pragma("unroll") \
             } \
         } \
     } while (0)
-    // End of a K-step: retire the previous stage, publish.
-#define ICN_RETIRE_AND_PUBLISH() do { \
+    // Metadata of the NEXT tile (rows nm0.., columns nn0..), fetched by LDS-DMA: code DMA j (of NJ, wave j % 4) brings the
+    // 64 codes of tap j / RL, rows (j % RL) * 64 + lane, to their final place in the offset table; waves < RL fetch the
+    // destination-row permutation, the last BN / 64 waves the bias.
+#define ICN_META_ISSUE() do { \
+        const int ne_ = __builtin_amdgcn_readfirstlane(eslot == 2 ? 0 : eslot + 1); \
+        int mp_[RL]; \
+_Pragma("unroll") \
+        for (int r = 0; r < RL; ++r) { \
+            const int m = nm0 + r * 64 + lane; \
+            mb[r] = m < M ? m / Pd : -1; \
+            mp_[r] = m - (m / Pd) * Pd; \
+        } \
+_Pragma("unroll") \
+        for (int jj = 0; jj < JW; ++jj) { \
+            const int j = wave + 4 * jj; \
+            if (j < NJ) { \
+                const int r = j % RL; \
+                const int b_ = RL == 1 ? mb[0] : (r ? mb[RL - 1] : mb[0]); \
+                const int p_ = RL == 1 ? mp_[0] : (r ? mp_[RL - 1] : mp_[0]); \
+                unsigned* dst_ = otab + __builtin_amdgcn_readfirstlane((slot ^ 1) * 7 * BM + j * 64); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)dst_, 4, \
+                                                         b_ >= 0 ? (unsigned)((j / RL) * Pd + p_) * 4u : SIDE_FLAG, 0, 0, 0); \
+            } \
+        } \
+        if (perm && wave < RL) { \
+            const int b_ = RL == 1 ? mb[0] : (wave ? mb[RL - 1] : mb[0]); \
+            const int p_ = RL == 1 ? mp_[0] : (wave ? mp_[RL - 1] : mp_[0]); \
+            unsigned* dst_ = drow_s + __builtin_amdgcn_readfirstlane(ne_ * BM + wave * 64); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_p, (lds_ptr_t)dst_, 4, b_ >= 0 ? (unsigned)p_ * 4u : SIDE_FLAG, 0, 0, 0); \
+        } \
+        if (bias && wave >= 4 - BN / 64) { \
+            const int c_ = __builtin_amdgcn_readfirstlane((wave - (4 - BN / 64)) * 64); \
+            float* dst_ = bias_s + __builtin_amdgcn_readfirstlane(ne_ * BN + c_); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_bias, (lds_ptr_t)dst_, 4, (unsigned)(nn0 + c_ + lane) * 4u, 0, 0, 0); \
+        } \
+    } while (0)
+    // ... and, once landed (after the step's counted wait), turned in place into byte offsets / destination rows by the
+    // lane that fetched them; the step's barrier publishes the tables.
+#define ICN_META_CONVERT() do { \
+        const int ne_ = eslot == 2 ? 0 : eslot + 1; \
+_Pragma("unroll") \
+        for (int jj = 0; jj < JW; ++jj) { \
+            const int j = wave + 4 * jj; \
+            if (j < NJ) { \
+                const int r = j % RL; \
+                const int b_ = RL == 1 ? mb[0] : (r ? mb[RL - 1] : mb[0]); \
+                unsigned* e_ = otab + (slot ^ 1) * 7 * BM + j * 64 + lane; \
+                *e_ = b_ >= 0 ? row_offset((int32_t)*e_, b_) : NOTHING_OFFSET; \
+            } \
+        } \
+        if (perm && wave < RL) { \
+            const int b_ = RL == 1 ? mb[0] : (wave ? mb[RL - 1] : mb[0]); \
+            unsigned* e_ = drow_s + ne_ * BM + wave * 64 + lane; \
+            *e_ = b_ >= 0 ? (unsigned)(b_ * Pd) + *e_ : 0u; \
+        } \
+    } while (0)
+    // End of a K-step: retire the previous stage (and the metadata fetched ahead of this step's stage), publish.
+#define ICN_RETIRE_AND_PUBLISH(META) do { \
         if (issued && p_exact) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        if (META) ICN_META_CONVERT(); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         __builtin_amdgcn_s_barrier(); \
     } while (0)
     ICN_ISSUE_STAGE();                                    // ring fill: stages 0 and 1 (>= 4 steps per tile)
-    ICN_RETIRE_AND_PUBLISH();
+    ICN_RETIRE_AND_PUBLISH(false);
     ICN_ISSUE_STAGE();
-    ICN_RETIRE_AND_PUBLISH();
+    ICN_RETIRE_AND_PUBLISH(false);
     zero_acc();
     int c_ring = 0;
     for (;;) {
-        if (has_next) build_table(slot ^ 1, nm0);         // next tile's row offsets: consumed >= 2 K-steps from now
         const int S = __popc(mask_c) * nk;                // K-steps of this tile
         for (int step = 0; step < S; ++step) {
+            const bool meta = step == 0 && has_next;      // wave-uniform
             frag0(c_ring);
+            if (meta) ICN_META_ISSUE();                   // next tile's tables: consumed >= 2 K-steps from now
             ICN_ISSUE_STAGE();                            // stage s+2
             compute(c_ring);
-            ICN_RETIRE_AND_PUBLISH();                     // stage s+1 landed and visible
+            ICN_RETIRE_AND_PUBLISH(meta);                 // stage s+1 landed and visible
             c_ring = c_ring == 2 ? 0 : c_ring + 1;
         }
         // ---- tile epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wc * (BN / 2) + j * 32 + l31;
-            const float bv = bias ? bias[col] : 0.f;
+            const int cl = wc * (BN / 2) + j * 32 + l31, col = n0 + cl;
+            const float bv = bias ? bias_s[eslot * BN + cl] : 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int rl = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, m = m0 + rl;
                     if (m < M) {
-                        const size_t drow = perm ? (size_t)(m / Pd) * Pd + perm[m % Pd] : (size_t)m;
+                        const size_t drow = perm ? (size_t)drow_s[eslot * BM + rl] : (size_t)m;
                         dst[drow * N + col] = acc[i][j][r] + bv;
                     }
                 }
@@ -577,6 +657,7 @@ _Pragma("unroll") \
         n0 = nn0;
         mask_c = mask_n;
         slot ^= 1;
+        eslot = eslot == 2 ? 0 : eslot + 1;
         i_own = 1;                                        // the DMA pointer is already inside this tile
         next_tile = tile + gridDim.x;
         has_next = next_tile < ntiles;
@@ -586,8 +667,15 @@ _Pragma("unroll") \
         }
     }
 #undef ICN_ISSUE_STAGE
+#undef ICN_META_ISSUE
+#undef ICN_META_CONVERT
 #undef ICN_RETIRE_AND_PUBLISH
 #endif
+}
+
+// dynamic LDS of k_conv_dma: A/B rings, offset table, destination-row table (row permutation only), bias (bias only)
+static size_t conv_dma_lds(int bm, int bn, bool perm, bool bias) {
+    return (size_t)3 * (bm + bn) * BK * 4 + (size_t)2 * 7 * bm * 4 + (perm ? (size_t)3 * bm * 4 : 0) + (bias ? (size_t)3 * bn * 4 : 0);
 }
 
 template <int BM, int BN>
@@ -595,7 +683,7 @@ static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
     const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     int grid = std::min(ntiles, 256 * occ);
     if (grid >= 8) grid -= grid % 8;                     // keep a block's tiles in one residue class mod 8 (one XCD)
-    const size_t lds = (size_t)3 * (BM + BN) * BK * 4 + (size_t)2 * 7 * BM * 4;
+    const size_t lds = conv_dma_lds(BM, BN, a.perm != nullptr, a.bias != nullptr);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_dma<BM, BN>),
@@ -633,23 +721,25 @@ struct DmaCfg { int bm, bn, occ; double eff; };
 static const DmaCfg kDma[] = {{128, 128, 1, 0.80}, {128, 64, 2, 0.92}, {64, 128, 2, 1.00}, {64, 64, 3, 0.95}};
 
 static void launch_conv_dma_auto(const GatherGemmArgs& a, hipStream_t s) {
-    int best = -1;
+    int best = -1, best_occ = 1;
     double best_cost = 0;
     const char* force = getenv("ICN_TILE");          // developer override: 0..3 = index into kDma
     for (int i = 0; i < 4; ++i) {
         const DmaCfg& c = kDma[i];
         if (a.N % c.bn != 0) continue;
+        // blocks per CU: the shape's design point, unless the epilogue tables push its LDS over 160 KB / occ
+        const int occ = std::max(1, std::min(c.occ, (int)((160 * 1024) / conv_dma_lds(c.bm, c.bn, a.perm != nullptr, a.bias != nullptr))));
         const long tiles = (long)((a.M + c.bm - 1) / c.bm) * (a.N / c.bn);
-        const long slots = 256L * c.occ;
-        double cost = (double)((tiles + slots - 1) / slots) * c.occ * c.bm * c.bn / c.eff;
+        const long slots = 256L * occ;
+        double cost = (double)((tiles + slots - 1) / slots) * occ * c.bm * c.bn / (c.eff * occ / c.occ);
         if (force && atoi(force) == i) cost = -1;
-        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; best_occ = occ; }
     }
     switch (best) {
-        case 0: return launch_conv_dma<128, 128>(a, kDma[0].occ, s);
-        case 1: return launch_conv_dma<128, 64>(a, kDma[1].occ, s);
-        case 2: return launch_conv_dma<64, 128>(a, kDma[2].occ, s);
-        default: return launch_conv_dma<64, 64>(a, kDma[3].occ, s);
+        case 0: return launch_conv_dma<128, 128>(a, best_occ, s);
+        case 1: return launch_conv_dma<128, 64>(a, best_occ, s);
+        case 2: return launch_conv_dma<64, 128>(a, best_occ, s);
+        default: return launch_conv_dma<64, 64>(a, best_occ, s);
     }
 }
 

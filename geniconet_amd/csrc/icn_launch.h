@@ -15,7 +15,7 @@ struct GatherGemmArgs {
     const float* side;      // (B, n_slots, K) side buffer filled by launch_conv_prologue, or null
     int n_slots;
     const int32_t* perm;    // [Pd] or null
-    const uint8_t* mask32;  // [Pd/32] or null
+    const uint32_t* mask32; // [Pd/32] tap mask per 32 rows (one word each: scalar loads), or null
     int M, Ps, Pd, K, N, E, ns;
     double algo_flops;      // algorithmic FLOPs of this launch (profiling only)
 };
