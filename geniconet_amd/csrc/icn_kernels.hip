@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void k_wgrad(
     const int32_t* __restrict__ idx,    // forward table [7][Pd]
     float* __restrict__ partial,        // [S][7][Cin][Cout]
     float* __restrict__ bias_partial,   // [S][Cout] or null
-    int M, int Ps, int Pd, int Cin, int Cout, int ns, int rows_per_split) {
+    int M, int Ps, int Pd, int Cin, int Cout, int ns, int rows_per_split, int n_splits) {
     constexpr int TI = BI / 64, TJ = BJ / 64;
     constexpr int CI = BI / 4, CJ = BJ / 4;             // 16-byte chunks per row
     constexpr int RI = 32 * CI / 256, RJ = 32 * CJ / 256;   // chunks per thread per stage (32 rows per stage)
@@ -797,6 +797,7 @@ __global__ __launch_bounds__(256) void k_wgrad(
     const int group = (Cin / BI) * ntj * 7;              // blocks per row split
     const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
     const int split = (j / group) * 8 + xcd, g = j % group;
+    if (split >= n_splits) return;                       // grid is rounded up to whole XCD rounds
     const int t = g % 7, tile = g / 7;
     const int ci0 = (tile / ntj) * BI, co0 = (tile % ntj) * BJ;
     const int m_begin = split * rows_per_split;
@@ -915,7 +916,7 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
     const float* __restrict__ side,     // (B, n_slots, Cin) pole means of x, or null
     float* __restrict__ partial,        // [S][7][Cin][Cout]
     float* __restrict__ bias_partial,   // [S][Cout] or null
-    int M, int Ps, int Pd, int Cin, int Cout, int n_slots, int rows_per_split, unsigned x_bytes, unsigned dy_bytes,
+    int M, int Ps, int Pd, int Cin, int Cout, int n_slots, int rows_per_split, int n_splits, unsigned x_bytes, unsigned dy_bytes,
     unsigned side_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TI = BI / 64, TJ = BJ / 64;
@@ -937,6 +938,7 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
     const int group = (Cin / BI) * ntj * 7;
     const int xcd = blockIdx.x % 8, jb = blockIdx.x / 8;
     const int split = (jb / group) * 8 + xcd, g = jb % group;
+    if (split >= n_splits) return;                       // grid is rounded up to whole XCD rounds
     const int t = g % 7, tile = g / 7;
     const int ci0 = (tile / ntj) * BI, co0 = (tile % ntj) * BJ;
     const int m_begin = split * rows_per_split;
@@ -1280,16 +1282,27 @@ void launch_stem_fwd(const float* x, const float* w, const float* bias, float* y
 
 bool wgrad_supported(int Cin, int Cout) { return Cin % 64 == 0 && Cout % 64 == 0; }
 
+// LDS bytes / co-resident blocks per CU of the MFMA wgrad kernels
+static size_t wgrad_lds(int bi, int bj, bool dma) {
+    return dma ? (size_t)3 * WG_RS * (bi + bj) * 4 + (size_t)2 * 4 * 2 * 64 * 4 /* code ring, NA <= 2 */ : (size_t)2 * 32 * (bi + bj) * 4;
+}
+static int wgrad_occ(int bi, int bj) { return std::min(4, (int)((160 * 1024) / wgrad_lds(bi, bj, true))); }
+
 // number of row splits (= partial slabs) each wgrad flavour uses; shared by the workspace query and the launch
 int wgrad_splits(int M, int Cin, int Cout) {
     if (wgrad_supported(Cin, Cout)) {
+        // One block per (ci tile, co tile, tap, row split).  Measured on I5 / batch 36 (tools/bench_layers.py with
+        // ICN_WG_MULT = 0.75 ... 6): about three rounds of blocks over the chip's co-resident block slots is best -- one
+        // exactly filled round of long blocks is 15 % slower (blocks drift apart and the tail idles), many more rounds
+        // only add partial-slab traffic.
         const int bi = (Cin % 128 == 0) ? 128 : 64, bj = (Cout % 128 == 0) ? 128 : 64;
         const long tiles = 7L * (Cin / bi) * (Cout / bj);
-        long s = (1024 + tiles - 1) / tiles;                   // ~4 blocks per CU in flight
-        const long max_s = (M + 255) / 256;                    // >= 8 stages of 32 rows per block
+        static const double mult = getenv("ICN_WG_MULT") ? atof(getenv("ICN_WG_MULT")) : 3.0;   // developer override
+        long s = (long)(mult * 256L * wgrad_occ(bi, bj) / tiles);
+        const long max_s = (M + 255) / 256;                    // >= 16 stages of 16 rows per block
         if (s > max_s) s = max_s;
         if (s < 1) s = 1;
-        return (int)((s + 7) / 8 * 8);                         // whole number of splits per XCD (k_wgrad's block order)
+        return (int)s;
     }
     if (stem_supported(Cin, Cout)) return std::min(2048, (M + 255) / 256);
     return std::min(512, (M + 127) / 128);
@@ -1302,22 +1315,22 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         rows = (rows + 31) / 32 * 32;
         const bool bi128 = a.Cin % 128 == 0, bj128 = a.Cout % 128 == 0;
         const int BI = bi128 ? 128 : 64, BJ = bj128 ? 128 : 64;
-        dim3 grid((a.Cin / BI) * (a.Cout / BJ) * 7 * S);        // S is a multiple of 8 (see wgrad_splits)
-        const size_t lds = (size_t)2 * 32 * (BI + BJ) * 4;
+        dim3 grid((a.Cin / BI) * (a.Cout / BJ) * 7 * ((S + 7) / 8 * 8));   // whole XCD rounds; blocks of splits >= S exit
+        const size_t lds = wgrad_lds(BI, BJ, false);
         const size_t x_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.Cin * 4, dy_bytes = (size_t)a.M * a.Cout * 4;
         const size_t side_bytes = (size_t)(a.M / a.Pd) * a.n_slots * a.Cin * 4;
         const bool dma = !(dbg_flags() & 32) && a.dcode != nullptr && (a.n_slots == 0 || a.side != nullptr) &&
                          x_bytes < ((size_t)1 << 31) && dy_bytes < ((size_t)1 << 31) && side_bytes < ((size_t)1 << 30);
-        const size_t lds_dma = (size_t)3 * WG_RS * (BI + BJ) * 4 + (size_t)2 * 4 * 2 * 64 * 4;   // + code ring (NA <= 2)
+        const size_t lds_dma = wgrad_lds(BI, BJ, true);
 #define ICN_WG(I, J)                                                                                                       \
     do {                                                                                                                   \
         if (dma)                                                                                                           \
             hipLaunchKernelGGL((k_wgrad_dma<I, J>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.dcode,                         \
                                a.n_slots > 0 ? a.side : nullptr, a.partial, a.bias_partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout,   \
-                               a.n_slots, rows, (unsigned)x_bytes, (unsigned)dy_bytes, (unsigned)side_bytes);                \
+                               a.n_slots, rows, S, (unsigned)x_bytes, (unsigned)dy_bytes, (unsigned)side_bytes);             \
         else                                                                                                               \
             hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M,   \
-                               a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows);                                                     \
+                               a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows, S);                                                  \
     } while (0)
         prof_mark_begin((bi128 ? (bj128 ? PROF_WG_128x128 : PROF_WG_128x64) : (bj128 ? PROF_WG_64x128 : PROF_WG_64x64)) -
                             (dma ? PROF_WG_128x128 - PROF_WGD_128x128 : 0),

@@ -1,6 +1,7 @@
 // Diagnostic ladder: start from a bare MFMA loop and add the conv kernel's ingredients one at a time.
 //   L0 registers only | L1 + swizzled ds_read_b128 fragments (TM+TN per 4*TM*TN MFMAs) | L2 + one barrier per K-step
 //   L3 + LDS-DMA of (BM+BN) x 128 B per K-step from an L2-resident buffer into a 3-stage ring (counted vmcnt)
+//   L4 the conv's real gather traffic | L5 = L4 with the A rows fetched by global_load_lds (64-bit per-lane addresses)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -8,6 +9,7 @@
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using lds_ptr_t = __attribute__((address_space(3))) void*;
+using glb_ptr_t = __attribute__((address_space(1))) void*;
 constexpr int BK = 32;
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
@@ -48,6 +50,10 @@ __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_b
             for (int i = 0; i < RA; ++i) {
                 int row = tile * BM + 8 * (wave + 4 * i) + rsub + shift[t];
                 row = row < 0 ? row + a_rows : (row >= a_rows ? row - a_rows : row);
+                if (LEVEL >= 5)
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(reinterpret_cast<const char*>(src) + (size_t)row * 1024u + 16u * pc + kc * 128),
+                                                     (lds_ptr_t)(As + slot * BM * BK + 8 * (wave + 4 * i) * BK), 16, 0, 0);
+                else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(As + slot * BM * BK + 8 * (wave + 4 * i) * BK), 16,
                                                          (unsigned)row * 1024u + 16u * pc, kc * 128, 0, 0);
             }
@@ -140,6 +146,12 @@ int main(int argc, char** argv) {
 #define LADDER(BM, BN, OCC) run<BM, BN, 0>(OCC, src, src_bytes, out); run<BM, BN, 1>(OCC, src, src_bytes, out); \
                             run<BM, BN, 2>(OCC, src, src_bytes, out); run<BM, BN, 3>(OCC, src, src_bytes, out); \
                             run<BM, BN, 4>(OCC, src, src_bytes, out);
+    if (argc > 1 && argv[1][0] == 'g') {   // buffer vs global LDS-DMA addressing of the gathered rows
+        run<64, 128, 4>(2, src, src_bytes, out); run<64, 128, 5>(2, src, src_bytes, out);
+        run<64, 64, 4>(3, src, src_bytes, out); run<64, 64, 5>(3, src, src_bytes, out);
+        run<128, 64, 4>(2, src, src_bytes, out); run<128, 64, 5>(2, src, src_bytes, out);
+        return 0;
+    }
     LADDER(128, 128, 1)
     LADDER(128, 64, 2)
     LADDER(64, 128, 2)
