@@ -287,21 +287,27 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dy, 
 }
 
 // dw[o][c] = sum_chunks partial[chunk][o][c];  db[o] = sum_chunks partial[chunk][o][Cin]     (row stride Cin + 4)
-__global__ void k_head_reduce(const float* __restrict__ partial, int chunks, int Cin, int Cout, float* __restrict__ dw,
-                              float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per output element: lanes stride over the chunks (independent loads), then a fixed butterfly (deterministic).
+__global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ partial, int chunks, int Cin, int Cout,
+                                                      float* __restrict__ dw, float* __restrict__ db) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= Cout * (Cin + 1)) return;
     const int o = i / (Cin + 1), c = i % (Cin + 1);
     double s = 0.0;
-    for (int k = 0; k < chunks; ++k) s += partial[((size_t)k * HEAD_MAX_OUT + o) * (Cin + 4) + c];
-    if (c < Cin) dw[o * Cin + c] = (float)s;
-    else db[o] = (float)s;
+    for (int k = lane; k < chunks; k += 64) s += partial[((size_t)k * HEAD_MAX_OUT + o) * (Cin + 4) + c];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) {
+        if (c < Cin) dw[o * Cin + c] = (float)s;
+        else db[o] = (float)s;
+    }
 }
 
 bool head_supported(int Cin, int Cout) {
     return Cout >= 1 && Cout <= HEAD_MAX_OUT && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128 || Cin == 256);
 }
-int head_chunks(int M) { return std::min(256, (M + 255) / 256); }
+int head_chunks(int M) { return std::min(4096, (M + 63) / 64); }
 
 #define ICN_HEAD_DISPATCH(KERNEL, ...)                                                  \
     switch (Cin) {                                                                      \
@@ -322,7 +328,7 @@ void launch_head_bwd(const float* dy, const float* y, const float* x, const floa
                      int M, int Cin, int Cout, hipStream_t s) {
     const int chunks = head_chunks(M), rows = (M + chunks - 1) / chunks;
     ICN_HEAD_DISPATCH(k_head_bwd, dim3(chunks), dim3(256), 0, s, dy, y, x, w, dx, ws, M, Cout, rows)
-    hipLaunchKernelGGL(k_head_reduce, dim3((Cout * (Cin + 1) + 63) / 64), dim3(64), 0, s, ws, chunks, Cin, Cout, dw, db);
+    hipLaunchKernelGGL(k_head_reduce, dim3((Cout * (Cin + 1) + 3) / 4), dim3(256), 0, s, ws, chunks, Cin, Cout, dw, db);
 }
 #undef ICN_HEAD_DISPATCH
 
