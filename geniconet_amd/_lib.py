@@ -30,6 +30,11 @@ SIGNATURES = {
     'icn_conv_fwd': (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'icn_conv_bwd_data': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'icn_conv_bwd_weight': (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'icn_conv_pair_supported': (ctypes.c_int, [ctypes.c_int] * 6),
+    'icn_conv_pair_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 7),
+    'icn_conv_pair_fwd': (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'icn_conv_pair_bwd_data': (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'icn_conv_pair_bwd_weight': (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'icn_upsample_fwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'icn_upsample_bwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'icn_bn_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),

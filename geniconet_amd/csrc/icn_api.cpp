@@ -1,6 +1,7 @@
 // C ABI of libicn (see include/icn.h): argument checking, per-device index-table cache, kernel dispatch.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -199,9 +200,141 @@ TableCounts table_counts(int r_in, int stride) {
     return cache[key] = c;
 }
 
-// workspace layout of bwd-weight: [wgrad partial slabs S x 7 x Cin x Cout][bias partials S x Cout]
-size_t wgrad_partial_bytes(int M, int Cin, int Cout) {
-    return align256((size_t)icn::wgrad_splits(M, Cin, Cout) * 7 * Cin * Cout * sizeof(float));
+// workspace layout of bwd-weight: [wgrad partial slabs S x 7 x Cin x Cout][bias partials S x Cout][side buffer]
+// (Cout = total output channels, Cout0 of them in the first tensor of a pair)
+size_t wgrad_partial_bytes(int M, int Cin, int Cout, int Cout0) {
+    return align256((size_t)icn::wgrad_splits(M, Cin, Cout, Cout0) * 7 * Cin * Cout * sizeof(float));
+}
+size_t wgrad_bias_partial_bytes(int M, int Cin, int Cout, int Cout0) {
+    return align256((size_t)icn::wgrad_splits(M, Cin, Cout, Cout0) * Cout * sizeof(float));
+}
+
+bool args_ok(int B, int Cin, int Cout, int r_in, int stride) {
+    return B >= 1 && Cin >= 1 && Cout >= 1 && r_in >= 0 && r_in <= 10 && (stride == 1 || stride == 2);
+}
+
+// Two convolutions of the same input (C0, C1 output channels) can run as one launch per pass when every GEMM of the
+// three passes fits the LDS-DMA kernels (icn_launch.h: GatherGemmArgs / WgradArgs pair forms).
+bool pair_supported(int B, int Cin, int C0, int C1, int r_in, int stride) {
+    if (!args_ok(B, Cin, C0, r_in, stride) || C0 != C1 || Cin % 64 != 0 || C0 % 64 != 0) return false;
+    const size_t Pin = icn::pixels(r_in), Pout = Pin / (stride * stride), lim = (size_t)1 << 31;
+    if ((size_t)B * Pin >= lim) return false;
+    const TableCounts tc = table_counts(r_in, stride);
+    const size_t slots = std::max(tc.slots_fwd, tc.slots_bwd);
+    if ((size_t)B * Pin * Cin * 4 >= lim || (size_t)B * Pout * C0 * 4 >= lim || (size_t)7 * (C0 + C1) * Cin * 4 >= lim) return false;
+    if ((size_t)B * slots * std::max(Cin, C0) * 4 >= lim / 2) return false;
+    return icn::wgrad_pair_supported((int)(B * Pout), (int)Pin, (int)Pout, Cin, C0, C1);
+}
+
+// Workspace layouts (each piece 256-byte aligned), C = C0 + C1 (C1 = 0: single convolution):
+//   fwd        [packed weights 7 x Cin x C][pair: concatenated bias C][side buffer (B, slots_fwd, Cin)]
+//   bwd-data   [packed weights][stride 1: virtual-row GEMM result (B, nvp, Cin)][side buffer(s) (B, slots_bwd, C0) per dy]
+//   bwd-weight [partial slabs S x 7 x Cin x C][bias partials S x C][side buffer (B, slots_fwd, Cin)]
+size_t conv_ws_bytes(int op, int B, int Cin, int C0, int C1, int r_in, int stride) {
+    const int C = C0 + C1, n_out = (1 << r_in) / stride, M = B * 10 * n_out * n_out;
+    const size_t wbytes = align256((size_t)7 * Cin * C * sizeof(float));
+    switch (op) {
+        case ICN_OP_CONV_FWD:
+            if (!icn::gather_gemm_supported(Cin, C)) return 0;
+            return wbytes + (C1 ? align256((size_t)C * sizeof(float)) : 0) +
+                   align256((size_t)B * table_counts(r_in, stride).slots_fwd * Cin * sizeof(float));
+        case ICN_OP_CONV_BWD_DATA: {
+            if (!icn::gather_gemm_supported(C, Cin)) return 0;
+            const TableCounts c = table_counts(r_in, stride);
+            return wbytes + align256((size_t)B * c.nv * Cin * sizeof(float)) +
+                   (C1 ? 2 : 1) * align256((size_t)B * c.slots_bwd * C0 * sizeof(float));
+        }
+        case ICN_OP_CONV_BWD_WEIGHT:
+            return wgrad_partial_bytes(M, Cin, C, C0) + wgrad_bias_partial_bytes(M, Cin, C, C0) +
+                   align256((size_t)B * table_counts(r_in, stride).slots_fwd * Cin * sizeof(float));
+        default: return 0;
+    }
+}
+
+char* at(void* ws, size_t off) { return static_cast<char*>(ws) + off; }
+
+// ---- the three passes; w1 == nullptr: one convolution, else a pair sharing x (C1 = its output channels) -------------
+void conv_fwd_impl(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, float* y0, float* y1, int B,
+                   int Cin, int C0, int C1, const ConvTables& t, void* ws, hipStream_t s) {
+    const int C = C0 + C1;
+    const size_t wbytes = align256((size_t)7 * Cin * C * sizeof(float));
+    float* wf = static_cast<float*>(ws);
+    float* bias_cat = (w1 && b0) ? reinterpret_cast<float*>(at(ws, wbytes)) : nullptr;
+    float* side = reinterpret_cast<float*>(at(ws, wbytes + (w1 ? align256((size_t)C * sizeof(float)) : 0)));
+    icn::PrologueArgs p{};
+    p.w = w0; p.w2 = w1; p.packed = wf; p.Cout = C0; p.Cout2 = C1; p.Cin = Cin; p.transpose = 0;
+    p.bias = b0; p.bias2 = b1; p.bias_cat = bias_cat;
+    p.src = x; p.slots = t.d_fwd.slots; p.side = side; p.n_slots = t.d_fwd.n_slots; p.E = 1; p.B = B; p.Ps = t.Pin; p.K = Cin;
+    p.ns = t.n_in;
+    icn::launch_conv_prologue(p, s);
+    icn::GatherGemmArgs a{};
+    a.src = x; a.wt = wf; a.bias = w1 ? bias_cat : b0; a.dst = y0; a.dst2 = w1 ? y1 : nullptr; a.N0 = C0;
+    a.idx = t.fwd; a.dcode = t.d_fwd.code; a.side = side; a.n_slots = t.d_fwd.n_slots;
+    a.M = B * t.Pout; a.Ps = t.Pin; a.Pd = t.Pout; a.K = Cin; a.N = C; a.E = 1; a.ns = t.n_in;
+    a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pout;
+    icn::launch_gather_gemm_auto(a, s);
+}
+
+void conv_bwd_data_impl(const float* dy0, const float* dy1, const float* w0, const float* w1, float* dx, int B, int Cin, int C0,
+                        int C1, int r_in, int stride, const ConvTables& t, void* ws, hipStream_t s) {
+    const int C = C0 + C1;
+    const size_t wbytes = align256((size_t)7 * Cin * C * sizeof(float));
+    const TableCounts tc = table_counts(r_in, stride);
+    const size_t side_bytes = align256((size_t)B * tc.slots_bwd * C0 * sizeof(float));
+    float* wb = static_cast<float*>(ws);
+    float* vout = reinterpret_cast<float*>(at(ws, wbytes));
+    float* side = reinterpret_cast<float*>(at(ws, wbytes + align256((size_t)B * tc.nv * Cin * sizeof(float))));
+    float* side2 = dy1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(side) + side_bytes) : nullptr;
+    // source = dy at the output level (pole corners of THAT level), rows = input pixels
+    // Stride 1: the transposed gather has extra entries (duplicates / pole means) along the chart seams.
+    // Where they are few (fine levels) the main GEMM gathers only the primary entries and a second, small GEMM
+    // over "virtual rows" adds the rest; where they are many (coarse levels: 23 % of the rows at r = 3) they go
+    // through the main GEMM's side buffer instead of a second launch.
+    const bool split = stride == 1 && t.nv > 0 && t.nv * 8 < t.Pin;
+    const DevDma& dm = split ? t.d_bwd1 : (stride == 2 ? t.d_bwdp : t.d_bwd);   // main GEMM's table
+    const DevDma& ds = split ? t.d_virt : dm;                                    // table the side buffer serves
+    icn::PrologueArgs p{};
+    p.w = w0; p.w2 = w1; p.packed = wb; p.Cout = C0; p.Cout2 = C1; p.Cin = Cin; p.transpose = 1;
+    p.src = dy0; p.src2 = dy1; p.slots = ds.slots; p.side = side; p.side2 = side2; p.n_slots = ds.n_slots; p.E = ds.E; p.B = B;
+    p.Ps = t.Pout; p.K = C0; p.ns = t.n_out;
+    icn::launch_conv_prologue(p, s);
+    icn::GatherGemmArgs a{};
+    a.src = dy0; a.src2 = dy1; a.wt = wb; a.dst = dx; a.N0 = Cin;
+    a.idx = split ? t.bwd1 : (stride == 2 ? t.bwd_perm : t.bwd); a.dcode = dm.code; a.side = side; a.side2 = side2;
+    a.n_slots = dm.n_slots; a.perm = t.perm; a.mask32 = t.mask32;
+    a.M = B * t.Pin; a.Ps = t.Pout; a.Pd = t.Pin; a.K = C; a.N = Cin; a.E = split ? 1 : t.E; a.ns = t.n_out;
+    a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pout;
+    icn::launch_gather_gemm_auto(a, s);
+    if (split) {
+        // second, small GEMM over the virtual rows, then dx[b, vq[v], :] += result[b, v, :]
+        icn::GatherGemmArgs v = a;
+        v.dst = vout; v.idx = t.vidx; v.dcode = t.d_virt.code; v.n_slots = t.d_virt.n_slots; v.perm = t.vorder; v.mask32 = t.vmask32;
+        v.M = B * t.nvp; v.Pd = t.nvp; v.E = 1;
+        v.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.nv;
+        icn::launch_gather_gemm_auto(v, s);
+        icn::launch_row_scatter_add(vout, dx, t.vq, B, t.nv, t.nvp, t.Pin, Cin, s);
+    }
+}
+
+void conv_bwd_weight_impl(const float* x, const float* dy0, const float* dy1, float* dw0, float* db0, float* dw1, float* db1, int B,
+                          int Cin, int C0, int C1, const ConvTables& t, void* ws, hipStream_t s) {
+    const int C = C0 + C1, M = B * t.Pout;
+    float* partial = static_cast<float*>(ws);
+    float* bpart = (db0 || db1) ? reinterpret_cast<float*>(at(ws, wgrad_partial_bytes(M, Cin, C, C0))) : nullptr;
+    float* side = reinterpret_cast<float*>(at(ws, wgrad_partial_bytes(M, Cin, C, C0) + wgrad_bias_partial_bytes(M, Cin, C, C0)));
+    const bool mfma = icn::wgrad_supported(Cin, C);
+    if (mfma) {
+        icn::PrologueArgs p{};
+        p.Cin = Cin; p.src = x; p.slots = t.d_fwd.slots; p.side = side; p.n_slots = t.d_fwd.n_slots; p.E = 1; p.B = B; p.Ps = t.Pin;
+        p.K = Cin; p.ns = t.n_in;
+        icn::launch_conv_prologue(p, s);
+    }
+    icn::WgradArgs a{};
+    a.x = x; a.dy = dy0; a.dy2 = dy1; a.Cout0 = C0; a.idx = t.fwd; a.dcode = mfma ? t.d_fwd.code : nullptr; a.side = side;
+    a.n_slots = t.d_fwd.n_slots; a.partial = partial; a.bias_partial = bpart; a.dw = dw0; a.dbias = db0; a.dw2 = dw1; a.dbias2 = db1;
+    a.M = M; a.Ps = t.Pin; a.Pd = t.Pout; a.Cin = Cin; a.Cout = C; a.ns = t.n_in;
+    a.algo_flops = 2.0 * 7 * Cin * C * (double)M;
+    icn::launch_wgrad(a, s);
 }
 
 }  // namespace
@@ -292,31 +425,10 @@ int icn_prepare_upsample(int r_in, int corner_mode) {
     }
 }
 
-// Workspace layouts (each piece 256-byte aligned):
-//   fwd        [packed weights][side buffer (B, slots_fwd, Cin)]
-//   bwd-data   [packed weights][stride 1: virtual-row GEMM result (B, nv, Cin)][side buffer (B, slots_bwd, Cout)]
-//   bwd-weight [partial slabs S x 7 x Cin x Cout][bias partials S x Cout][side buffer (B, slots_fwd, Cin)]
 size_t icn_conv_workspace_bytes(int op, int B, int Cin, int Cout, int r_in, int stride) {
-    if (B < 1 || Cin < 1 || Cout < 1 || r_in < 0 || r_in > 10 || (stride != 1 && stride != 2)) return 0;
-    const int n_out = (1 << r_in) / stride;
-    const int M = B * 10 * n_out * n_out;
-    const size_t wbytes = align256((size_t)7 * Cin * Cout * sizeof(float));
+    if (!args_ok(B, Cin, Cout, r_in, stride)) return 0;
     try {
-        switch (op) {
-            case ICN_OP_CONV_FWD:
-                if (!icn::gather_gemm_supported(Cin, Cout)) return 0;
-                return wbytes + align256((size_t)B * table_counts(r_in, stride).slots_fwd * Cin * sizeof(float));
-            case ICN_OP_CONV_BWD_DATA: {
-                if (!icn::gather_gemm_supported(Cout, Cin)) return 0;
-                const TableCounts c = table_counts(r_in, stride);
-                return wbytes + align256((size_t)B * c.nv * Cin * sizeof(float)) +
-                       align256((size_t)B * c.slots_bwd * Cout * sizeof(float));
-            }
-            case ICN_OP_CONV_BWD_WEIGHT:
-                return wgrad_partial_bytes(M, Cin, Cout) + align256((size_t)icn::wgrad_splits(M, Cin, Cout) * Cout * sizeof(float)) +
-                       align256((size_t)B * table_counts(r_in, stride).slots_fwd * Cin * sizeof(float));
-            default: return 0;
-        }
+        return conv_ws_bytes(op, B, Cin, Cout, 0, r_in, stride);
     } catch (const std::exception&) {
         return 0;
     }
@@ -329,14 +441,9 @@ int icn_conv_fwd(const float* x, const float* w, const float* bias, float* y, in
         const ConvTables& t = conv_tables(r_in, stride, corner_mode);
         hipStream_t s = static_cast<hipStream_t>(stream);
         if (icn::gather_gemm_supported(Cin, Cout)) {
-            if (!ws || ws_bytes < icn_conv_workspace_bytes(ICN_OP_CONV_FWD, B, Cin, Cout, r_in, stride))
+            if (!ws || ws_bytes < conv_ws_bytes(ICN_OP_CONV_FWD, B, Cin, Cout, 0, r_in, stride))
                 throw std::invalid_argument("icn_conv_fwd: workspace too small");
-            float* wf = static_cast<float*>(ws);
-            float* side = reinterpret_cast<float*>(static_cast<char*>(ws) + align256((size_t)7 * Cin * Cout * sizeof(float)));
-            icn::launch_conv_prologue(w, wf, Cout, Cin, 0, x, t.d_fwd.slots, side, t.d_fwd.n_slots, 1, B, t.Pin, Cin, t.n_in, s);
-            icn::GatherGemmArgs a{x, wf, bias, y, t.fwd, t.d_fwd.code, side, t.d_fwd.n_slots, nullptr, nullptr, B * t.Pout, t.Pin,
-                                  t.Pout, Cin, Cout, 1, t.n_in, 2.0 * 7 * Cin * Cout * (double)B * t.Pout};
-            icn::launch_gather_gemm_auto(a, s);
+            conv_fwd_impl(x, w, bias, nullptr, nullptr, y, nullptr, B, Cin, Cout, 0, t, ws, s);
         } else if (icn::stem_supported(Cin, Cout)) {
             icn::launch_stem_fwd(x, w, bias, y, t.fwd, B * t.Pout, t.Pin, t.Pout, Cin, Cout, t.n_in, s);
         } else {
@@ -356,33 +463,9 @@ int icn_conv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin
         const ConvTables& t = conv_tables(r_in, stride, corner_mode);
         hipStream_t s = static_cast<hipStream_t>(stream);
         if (icn::gather_gemm_supported(Cout, Cin)) {
-            if (!ws || ws_bytes < icn_conv_workspace_bytes(ICN_OP_CONV_BWD_DATA, B, Cin, Cout, r_in, stride))
+            if (!ws || ws_bytes < conv_ws_bytes(ICN_OP_CONV_BWD_DATA, B, Cin, Cout, 0, r_in, stride))
                 throw std::invalid_argument("icn_conv_bwd_data: workspace too small");
-            float* wb = static_cast<float*>(ws);
-            const size_t wbytes = align256((size_t)7 * Cin * Cout * sizeof(float));
-            const TableCounts tc = table_counts(r_in, stride);
-            float* vout = reinterpret_cast<float*>(static_cast<char*>(ws) + wbytes);
-            float* side = reinterpret_cast<float*>(static_cast<char*>(ws) + wbytes + align256((size_t)B * tc.nv * Cin * sizeof(float)));
-            // source = dy at the output level (pole corners of THAT level), rows = input pixels
-            // Stride 1: the transposed gather has extra entries (duplicates / pole means) along the chart seams.
-            // Where they are few (fine levels) the main GEMM gathers only the primary entries and a second, small GEMM
-            // over "virtual rows" adds the rest; where they are many (coarse levels: 23 % of the rows at r = 3) they go
-            // through the main GEMM's side buffer instead of a second launch.
-            const bool split = stride == 1 && t.nv > 0 && t.nv * 8 < t.Pin;
-            const DevDma& dm = split ? t.d_bwd1 : (stride == 2 ? t.d_bwdp : t.d_bwd);   // main GEMM's table
-            const DevDma& ds = split ? t.d_virt : dm;                                    // table the side buffer serves
-            icn::launch_conv_prologue(w, wb, Cout, Cin, 1, dy, ds.slots, side, ds.n_slots, ds.E, B, t.Pout, Cout, t.n_out, s);
-            icn::GatherGemmArgs a{dy, wb, nullptr, dx, split ? t.bwd1 : (stride == 2 ? t.bwd_perm : t.bwd), dm.code, side, dm.n_slots,
-                                  t.perm, t.mask32, B * t.Pin, t.Pout, t.Pin, Cout, Cin, split ? 1 : t.E, t.n_out,
-                                  2.0 * 7 * Cin * Cout * (double)B * t.Pout};
-            icn::launch_gather_gemm_auto(a, s);
-            if (split) {
-                // second, small GEMM over the virtual rows, then dx[b, vq[v], :] += result[b, v, :]
-                icn::GatherGemmArgs v{dy, wb, nullptr, vout, t.vidx, t.d_virt.code, side, t.d_virt.n_slots, t.vorder, t.vmask32,
-                                      B * t.nvp, t.Pout, t.nvp, Cout, Cin, 1, t.n_out, 2.0 * 7 * Cin * Cout * (double)B * t.nv};
-                icn::launch_gather_gemm_auto(v, s);
-                icn::launch_row_scatter_add(vout, dx, t.vq, B, t.nv, t.nvp, t.Pin, Cin, s);
-            }
+            conv_bwd_data_impl(dy, nullptr, w, nullptr, dx, B, Cin, Cout, 0, r_in, stride, t, ws, s);
         } else {
             icn::launch_conv_generic(dy, w, nullptr, dx, t.bwd, B, t.Pout, t.Pin, Cout, Cin, t.E, t.n_out, 1, s);
         }
@@ -399,19 +482,83 @@ int icn_conv_bwd_weight(const float* x, const float* dy, float* dw, float* dbias
         check_conv(x, dy, dw, B, Cin, Cout, r_in, stride);
         const ConvTables& t = conv_tables(r_in, stride, corner_mode);
         hipStream_t s = static_cast<hipStream_t>(stream);
-        if (!ws || ws_bytes < icn_conv_workspace_bytes(ICN_OP_CONV_BWD_WEIGHT, B, Cin, Cout, r_in, stride))
+        if (!ws || ws_bytes < conv_ws_bytes(ICN_OP_CONV_BWD_WEIGHT, B, Cin, Cout, 0, r_in, stride))
             throw std::invalid_argument("icn_conv_bwd_weight: workspace too small");
-        const int M = B * t.Pout;
-        float* partial = static_cast<float*>(ws);
-        float* bpart = dbias ? reinterpret_cast<float*>(static_cast<char*>(ws) + wgrad_partial_bytes(M, Cin, Cout)) : nullptr;
-        float* side = reinterpret_cast<float*>(static_cast<char*>(ws) + wgrad_partial_bytes(M, Cin, Cout) +
-                                               align256((size_t)icn::wgrad_splits(M, Cin, Cout) * Cout * sizeof(float)));
-        const bool mfma = icn::wgrad_supported(Cin, Cout);
-        if (mfma) icn::launch_conv_prologue(nullptr, nullptr, Cout, Cin, 0, x, t.d_fwd.slots, side, t.d_fwd.n_slots, 1, B, t.Pin, Cin,
-                                            t.n_in, s);
-        icn::WgradArgs a{x, dy, t.fwd, mfma ? t.d_fwd.code : nullptr, side, t.d_fwd.n_slots, partial, bpart, dw, dbias, M, t.Pin,
-                         t.Pout, Cin, Cout, t.n_in, 2.0 * 7 * Cin * Cout * (double)M};
-        icn::launch_wgrad(a, s);
+        conv_bwd_weight_impl(x, dy, nullptr, dw, dbias, nullptr, nullptr, B, Cin, Cout, 0, t, ws, s);
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+// ---- pair forms: two convolutions of the same input (reference models.py:37-39 conv00 / conv10, 59-60) in one launch per
+// pass: forward with the output channels concatenated, bwd-data with the two dy concatenated along the GEMM's K axis
+// (one dx, no separate gradient add), bwd-weight with the shared x gathered once.
+int icn_conv_pair_supported(int B, int Cin, int Cout0, int Cout1, int r_in, int stride) {
+    try {
+        return pair_supported(B, Cin, Cout0, Cout1, r_in, stride) ? 1 : 0;
+    } catch (const std::exception&) {
+        return 0;
+    }
+}
+
+size_t icn_conv_pair_workspace_bytes(int op, int B, int Cin, int Cout0, int Cout1, int r_in, int stride) {
+    try {
+        if (!pair_supported(B, Cin, Cout0, Cout1, r_in, stride)) return 0;
+        return conv_ws_bytes(op, B, Cin, Cout0, Cout1, r_in, stride);
+    } catch (const std::exception&) {
+        return 0;
+    }
+}
+
+int icn_conv_pair_fwd(const float* x, const float* w0, const float* bias0, const float* w1, const float* bias1, float* y0, float* y1,
+                      int B, int Cin, int Cout0, int Cout1, int r_in, int stride, int corner_mode, void* ws, size_t ws_bytes,
+                      void* stream) {
+    try {
+        check_conv(x, w0, y0, B, Cin, Cout0, r_in, stride);
+        if (!w1 || !y1) throw std::invalid_argument("icn: null tensor pointer");
+        if ((bias0 == nullptr) != (bias1 == nullptr)) throw std::invalid_argument("icn_conv_pair_fwd: both biases or none");
+        if (!pair_supported(B, Cin, Cout0, Cout1, r_in, stride)) throw std::invalid_argument("icn_conv_pair_fwd: unsupported shape");
+        if (!ws || ws_bytes < conv_ws_bytes(ICN_OP_CONV_FWD, B, Cin, Cout0, Cout1, r_in, stride))
+            throw std::invalid_argument("icn_conv_pair_fwd: workspace too small");
+        const ConvTables& t = conv_tables(r_in, stride, corner_mode);
+        conv_fwd_impl(x, w0, bias0, w1, bias1, y0, y1, B, Cin, Cout0, Cout1, t, ws, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_conv_pair_bwd_data(const float* dy0, const float* dy1, const float* w0, const float* w1, float* dx, int B, int Cin, int Cout0,
+                           int Cout1, int r_in, int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream) {
+    try {
+        check_conv(dy0, w0, dx, B, Cin, Cout0, r_in, stride);
+        if (!dy1 || !w1) throw std::invalid_argument("icn: null tensor pointer");
+        if (!pair_supported(B, Cin, Cout0, Cout1, r_in, stride)) throw std::invalid_argument("icn_conv_pair_bwd_data: unsupported shape");
+        if (!ws || ws_bytes < conv_ws_bytes(ICN_OP_CONV_BWD_DATA, B, Cin, Cout0, Cout1, r_in, stride))
+            throw std::invalid_argument("icn_conv_pair_bwd_data: workspace too small");
+        const ConvTables& t = conv_tables(r_in, stride, corner_mode);
+        conv_bwd_data_impl(dy0, dy1, w0, w1, dx, B, Cin, Cout0, Cout1, r_in, stride, t, ws, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_conv_pair_bwd_weight(const float* x, const float* dy0, const float* dy1, float* dw0, float* dbias0, float* dw1, float* dbias1,
+                             int B, int Cin, int Cout0, int Cout1, int r_in, int stride, int corner_mode, void* ws, size_t ws_bytes,
+                             void* stream) {
+    try {
+        check_conv(x, dy0, dw0, B, Cin, Cout0, r_in, stride);
+        if (!dy1 || !dw1) throw std::invalid_argument("icn: null tensor pointer");
+        if (!pair_supported(B, Cin, Cout0, Cout1, r_in, stride)) throw std::invalid_argument("icn_conv_pair_bwd_weight: unsupported shape");
+        if (!ws || ws_bytes < conv_ws_bytes(ICN_OP_CONV_BWD_WEIGHT, B, Cin, Cout0, Cout1, r_in, stride))
+            throw std::invalid_argument("icn_conv_pair_bwd_weight: workspace too small");
+        const ConvTables& t = conv_tables(r_in, stride, corner_mode);
+        conv_bwd_weight_impl(x, dy0, dy1, dw0, dbias0, dw1, dbias1, B, Cin, Cout0, Cout1, t, ws, static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());
         return 0;
     } catch (const std::exception& e) {

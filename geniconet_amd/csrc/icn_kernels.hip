@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <stdexcept>
 #include <type_traits>
 #include <utility>
 
@@ -55,33 +56,36 @@ __device__ __forceinline__ float gather1(const float* src, int32_t code, int b, 
 // weight re-layouts:  w[Cout][Cin][7]  ->  wf[t][Cout][Cin]  (forward B operand, k = ci contiguous)
 //                                      ->  wb[t][Cin][Cout]  (backward-data B operand, k = co contiguous)
 // ---------------------------------------------------------------------------------------------------------
-// Prologue of a conv call, one launch: blocks [0, npack) repack the (Cout, Cin, 7) parameter into the GEMM's B operand
-// [7][N][K] (k-contiguous); blocks [npack, npack + B * n_slots) fill the side buffer of a DmaTable:
-//   side[b][s][:] = sum_e gather(slots[s][e])   (pixels / pole means of the source tensor; icn_geometry.h).
-__global__ __launch_bounds__(256) void k_conv_prologue(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
-                                                        int transpose, int npack, const float* __restrict__ src,
-                                                        const int32_t* __restrict__ slots, float* __restrict__ side,
-                                                        int n_slots, int E, int Ps, int K, int ns) {
+// Prologue of a conv call, one launch: blocks [0, npack) repack the (Cout, Cin, 7) parameter(s) into the GEMM's B operand
+// [7][N][K] (k-contiguous) and concatenate the biases; blocks [npack, npack + nsrc * B * n_slots) fill the side buffer(s)
+// of a DmaTable:  side[b][s][:] = sum_e gather(slots[s][e])   (pixels / pole means of the source tensor; icn_geometry.h).
+__global__ __launch_bounds__(256) void k_conv_prologue(PrologueArgs a, int npack) {
     if ((int)blockIdx.x < npack) {
-        const int total = Cout * Cin * 7;
+        const int Ct = a.Cout + a.Cout2, total = Ct * a.Cin * 7;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += npack * 256) {
             // i enumerates the OUTPUT layout so that stores are coalesced
             int t, co, ci;
-            if (!transpose) { ci = i % Cin; co = (i / Cin) % Cout; t = i / (Cin * Cout); }
-            else { co = i % Cout; ci = (i / Cout) % Cin; t = i / (Cin * Cout); }
-            out[i] = w[((size_t)co * Cin + ci) * 7 + t];
+            if (!a.transpose) { ci = i % a.Cin; co = (i / a.Cin) % Ct; t = i / (a.Cin * Ct); }
+            else { co = i % Ct; ci = (i / Ct) % a.Cin; t = i / (a.Cin * Ct); }
+            a.packed[i] = co < a.Cout ? a.w[((size_t)co * a.Cin + ci) * 7 + t] : a.w2[((size_t)(co - a.Cout) * a.Cin + ci) * 7 + t];
         }
+        if (a.bias_cat && blockIdx.x == 0)
+            for (int c = threadIdx.x; c < Ct; c += 256) a.bias_cat[c] = c < a.Cout ? a.bias[c] : a.bias2[c - a.Cout];
         return;
     }
-    const int j = blockIdx.x - npack, b = j / n_slots, sl = j % n_slots;
-    for (int ch = 4 * threadIdx.x; ch < K; ch += 4 * 256) {
+    int j = blockIdx.x - npack;
+    const float* src = a.src;
+    float* side = a.side;
+    if (j >= a.B * a.n_slots) { j -= a.B * a.n_slots; src = a.src2; side = a.side2; }
+    const int b = j / a.n_slots, sl = j % a.n_slots;
+    for (int ch = 4 * threadIdx.x; ch < a.K; ch += 4 * 256) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int e = 0; e < E; ++e) {
-            const int32_t c = slots[sl * E + e];
-            if (c >= 0) v += ld4(src + ((size_t)b * Ps + c) * K + ch);
-            else if (c <= -2) v += pole_mean4(src, b, Ps, ns, -2 - c, K, ch);
+        for (int e = 0; e < a.E; ++e) {
+            const int32_t c = a.slots[sl * a.E + e];
+            if (c >= 0) v += ld4(src + ((size_t)b * a.Ps + c) * a.K + ch);
+            else if (c <= -2) v += pole_mean4(src, b, a.Ps, a.ns, -2 - c, a.K, ch);
         }
-        *reinterpret_cast<f32x4*>(side + ((size_t)b * n_slots + sl) * K + ch) = v;
+        *reinterpret_cast<f32x4*>(side + ((size_t)b * a.n_slots + sl) * a.K + ch) = v;
     }
 }
 
@@ -328,15 +332,18 @@ constexpr unsigned NOTHING_OFFSET = 0xC0000000u;
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void k_conv_dma(
-    const float* __restrict__ src,      // (B, Ps, K)
+    const float* __restrict__ src,      // (B, Ps, Ks)   Ks = K, or K / 2 with src2
+    const float* __restrict__ src2,     // second half of the K axis (pair bwd-data), or null
     const float* __restrict__ wt,       // [7][N][K]
     const float* __restrict__ bias,     // [N] or null
-    float* __restrict__ dst,            // (B, Pd, N)
+    float* __restrict__ dst,            // (B, Pd, N0)
+    float* __restrict__ dst2,           // (B, Pd, N - N0) columns N0.. (pair forward), or null (N0 = N)
     const int32_t* __restrict__ dcode,  // DmaTable code [7][Pd] (row order: pre-permuted when perm != null)
-    const float* __restrict__ side,     // (B, n_slots, K) or null
+    const float* __restrict__ side,     // (B, n_slots, Ks) or null
+    const float* __restrict__ side2,    // same for src2
     const int32_t* __restrict__ perm,   // [Pd] row -> dst pixel, or null (identity)
     const uint32_t* __restrict__ mask32,// [Pd/32] taps in use per 32 rows, or null (all 7)
-    int M, int Ps, int Pd, int K, int N, int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles) {
+    int M, int Ps, int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;          // rows per lane (one 16-byte chunk of each)
@@ -357,11 +364,15 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     const int l31 = lane & 31, h = lane >> 5;
     const int rsub = lane >> 3, pc = lane & 7;         // DMA: row within its 8-row group, physical 16-byte chunk
     const int ntn = N / BN, nk = K / BK;
+    const int Ks = src2 ? K / 2 : K, nk0 = Ks / BK;    // channels / k-chunks per source tensor
 
     const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+    const auto rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src2 ? src2 : src), 0, src_bytes, 0x00020000);
     const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, 7 * N * K * 4, 0x00020000);
     const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side ? side : src), 0, side ? side_bytes : 0u,
                                                           0x00020000);
+    const auto rsrc_s2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side2 ? side2 : src), 0, side2 ? side_bytes : 0u,
+                                                           0x00020000);
     const auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(dcode), 0, 7 * Pd * 4, 0x00020000);
     const auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(perm ? perm : dcode), 0, Pd * 4, 0x00020000);
     const auto rsrc_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias ? bias : src), 0, bias ? N * 4 : 0, 0x00020000);
@@ -385,9 +396,9 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     }
     // gather code of row (sample b) -> DMA byte offset
     auto row_offset = [&](int32_t c, int b) __attribute__((always_inline)) {
-        return c >= 0 ? (unsigned)(b * Ps + c) * (unsigned)K * 4u
+        return c >= 0 ? (unsigned)(b * Ps + c) * (unsigned)Ks * 4u
              : c == -1 ? NOTHING_OFFSET
-                       : SIDE_FLAG | ((unsigned)(b * n_slots + (-2 - c)) * (unsigned)K * 4u);
+                       : SIDE_FLAG | ((unsigned)(b * n_slots + (-2 - c)) * (unsigned)Ks * 4u);
     };
     // Metadata of the block's FIRST tile, built synchronously with ordinary loads: row offsets, destination rows, bias.
     // (Later tiles: ICN_META_ISSUE / ICN_META_CONVERT below, by LDS-DMA, one tile ahead.)
@@ -503,8 +514,10 @@ __global__ __launch_bounds__(256) void k_conv_dma(
         p_exact = 1; \
         if (i_live) { \
             const int tn0 = __builtin_amdgcn_readfirstlane(i_own ? n0 : nn0); \
-            const int a_soff = __builtin_amdgcn_readfirstlane(i_kc * (BK * 4)); \
+            const int sec_ = __builtin_amdgcn_readfirstlane(i_kc >= nk0);   /* k-chunk of the second source tensor */ \
+            const int a_soff = __builtin_amdgcn_readfirstlane((sec_ ? i_kc - nk0 : i_kc) * (BK * 4)); \
             const int b_soff = __builtin_amdgcn_readfirstlane(((i_t * N + tn0) * K + i_kc * BK) * 4); \
+            const auto ra_ = sec_ ? rsrc_a2 : rsrc_a; \
             bool side_row = false; \
 _Pragma("unroll") \
             for (int i = 0; i < RA; ++i) side_row |= (int)pbase[i] < (int)NOTHING_OFFSET; \
@@ -512,17 +525,18 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                 for (int i = 0; i < RA; ++i) { \
                     float* lds_dst = As + __builtin_amdgcn_readfirstlane(i_ring * BM * BK + 8 * (wave + 4 * i) * BK); \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)lds_dst, 16, pbase[i] + achunk[i], a_soff, 0, 0); \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_ptr_t)lds_dst, 16, pbase[i] + achunk[i], a_soff, 0, 0); \
                 } \
             } else { \
                 p_exact = 0; \
+                const auto rs_ = sec_ ? rsrc_s2 : rsrc_s; \
 _Pragma("unroll") \
                 for (int i = 0; i < RA; ++i) { \
                     float* lds_dst = As + __builtin_amdgcn_readfirstlane(i_ring * BM * BK + 8 * (wave + 4 * i) * BK); \
                     if ((int)pbase[i] >= (int)NOTHING_OFFSET) \
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)lds_dst, 16, pbase[i] + achunk[i], a_soff, 0, 0); \
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_ptr_t)lds_dst, 16, pbase[i] + achunk[i], a_soff, 0, 0); \
                     else \
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_ptr_t)lds_dst, 16, \
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)lds_dst, 16, \
                                                                  (pbase[i] & ~SIDE_FLAG) + achunk[i], a_soff, 0, 0); \
                 } \
             } \
@@ -639,6 +653,10 @@ _Pragma("unroll") \
         for (int j = 0; j < TN; ++j) {
             const int cl = wc * (BN / 2) + j * 32 + l31, col = n0 + cl;
             const float bv = bias ? bias_s[eslot * BN + cl] : 0.f;
+            // pair forward: 32-column groups at or beyond N0 belong to the second output tensor
+            const bool second = n0 + wc * (BN / 2) + j * 32 >= N0;
+            float* const dcol = second ? dst2 + (col - N0) : dst + col;
+            const size_t dstride = second ? (size_t)(N - N0) : (size_t)N0;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -646,7 +664,7 @@ _Pragma("unroll") \
                     const int rl = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, m = m0 + rl;
                     if (m < M) {
                         const size_t drow = perm ? (size_t)drow_s[eslot * BM + rl] : (size_t)m;
-                        dst[drow * N + col] = acc[i][j][r] + bv;
+                        dcol[drow * dstride] = acc[i][j][r] + bv;
                     }
                 }
         }
@@ -691,23 +709,27 @@ static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const unsigned src_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.Ps * a.K * 4);
-    const unsigned side_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.n_slots * a.K * 4);
+    const int Ks = a.src2 ? a.K / 2 : a.K;
+    const unsigned src_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.Ps * Ks * 4);
+    const unsigned side_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.n_slots * Ks * 4);
     prof_mark_begin(BM == 64 ? (BN == 128 ? PROF_DMA_64x128 : PROF_DMA_64x64) : (BN == 128 ? PROF_DMA_128x128 : PROF_DMA_128x64),
                     a.algo_flops, s);
-    hipLaunchKernelGGL((k_conv_dma<BM, BN>), dim3(grid), dim3(256), lds, s, a.src, a.wt, a.bias, a.dst, a.dcode,
-                       a.n_slots > 0 ? a.side : nullptr, a.perm, a.mask32, a.M, a.Ps, a.Pd, a.K, a.N, a.n_slots, src_bytes, side_bytes,
-                       ntiles);
+    hipLaunchKernelGGL((k_conv_dma<BM, BN>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2,
+                       a.dcode, a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.mask32, a.M,
+                       a.Ps, a.Pd, a.K, a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles);
     prof_mark_end(s);
 }
 
-static bool conv_dma_usable(const GatherGemmArgs& a) {
+bool conv_dma_usable(const GatherGemmArgs& a) {
     if (dbg_flags() & 16) return false;
-    const size_t src_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.K * 4, wt_bytes = (size_t)7 * a.N * a.K * 4;
-    const size_t side_bytes = (size_t)(a.M / a.Pd) * a.n_slots * a.K * 4;
-    if (a.dcode == nullptr || (a.n_slots > 0 && a.side == nullptr)) return false;   // needs the DmaTable form + side buffer
+    const int Ks = a.src2 ? a.K / 2 : a.K;
+    const size_t src_bytes = (size_t)(a.M / a.Pd) * a.Ps * Ks * 4, wt_bytes = (size_t)7 * a.N * a.K * 4;
+    const size_t side_bytes = (size_t)(a.M / a.Pd) * a.n_slots * Ks * 4;
+    if (a.dcode == nullptr || (a.n_slots > 0 && (a.side == nullptr || (a.src2 && a.side2 == nullptr)))) return false;
     if (side_bytes >= ((size_t)1 << 30)) return false;
-    // The cross-tile pipeline needs >= 4 K-steps per tile: the next tile's offset table is built in the tile's first
+    if (a.src2 && Ks % BK != 0) return false;
+    if (a.dst2 && (a.N0 % 64 != 0 || (a.N - a.N0) % 64 != 0)) return false;
+    // The cross-tile pipeline needs >= 4 K-steps per tile: the next tile's metadata is fetched in the tile's first
     // step and published by that step's barrier, and the DMA pointer (2 steps ahead) prefetches the next stage's row
     // offsets one step earlier still, i.e. in step S-3 >= 1.  With tap masks a tile may use a single tap.
     if ((a.mask32 ? 1 : 7) * (a.K / BK) < 4) return false;
@@ -761,6 +783,7 @@ static int pick_tile(int M, int N, int E) {
 
 void launch_gather_gemm_auto(const GatherGemmArgs& a, hipStream_t s) {
     if (conv_dma_usable(a)) return launch_conv_dma_auto(a, s);
+    if (a.src2 || a.dst2) throw std::invalid_argument("icn: pair gather-GEMM outside the LDS-DMA kernel's limits");
     switch (pick_tile(a.M, a.N, a.E)) {
         case 0: return launch_gather_gemm<128, 128>(a, s);
         case 1: return launch_gather_gemm<128, 64>(a, s);
@@ -912,12 +935,13 @@ constexpr int WG_RS = 16;   // rows per stage
 template <int BI, int BJ>
 __global__ __launch_bounds__(256) void k_wgrad_dma(
     const float* __restrict__ x,        // (B, Ps, Cin)
-    const float* __restrict__ dy,       // (B, Pd, Cout)
+    const float* __restrict__ dy,       // (B, Pd, Cout0)
+    const float* __restrict__ dy2,      // (B, Pd, Cout - Cout0): output channels Cout0.. (pair sharing x), or null
     const int32_t* __restrict__ dcode,  // forward DmaTable code [7][Pd]
     const float* __restrict__ side,     // (B, n_slots, Cin) pole means of x, or null
     float* __restrict__ partial,        // [S][7][Cin][Cout]
     float* __restrict__ bias_partial,   // [S][Cout] or null
-    int M, int Ps, int Pd, int Cin, int Cout, int n_slots, int rows_per_split, int n_splits, unsigned x_bytes, unsigned dy_bytes,
+    int M, int Ps, int Pd, int Cin, int Cout, int Cout0, int n_slots, int rows_per_split, int n_splits, unsigned x_bytes,
     unsigned side_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TI = BI / 64, TJ = BJ / 64;
@@ -947,8 +971,12 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
     const int nsteps = (m_end - m_begin + WG_RS - 1) / WG_RS;
     const bool do_bias = bias_partial != nullptr && t == 0 && ci0 == 0;   // block-uniform
 
+    // the block's output-channel tile lies in one of the two dy tensors (block-uniform)
+    const bool ysec = co0 >= Cout0;
+    const int yC = ysec ? Cout - Cout0 : Cout0, yc0 = ysec ? co0 - Cout0 : co0;      // its row stride / first channel there
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
-    const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, dy_bytes, 0x00020000);
+    const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ysec ? dy2 : dy), 0, (unsigned)M * (unsigned)yC * 4u,
+                                                          0x00020000);
     const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side ? side : x), 0, side ? side_bytes : 0u,
                                                           0x00020000);
     const auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(dcode + (size_t)t * Pd), 0, Pd * 4, 0x00020000);
@@ -1031,13 +1059,13 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_ptr_t)dst_, 16, aoff[i] & ~SIDE_FLAG, 0, 0, 0); \
                 } \
             } \
-            const int y_soff = __builtin_amdgcn_readfirstlane((m_begin + d_step * WG_RS) * Cout * 4); \
+            const int y_soff = __builtin_amdgcn_readfirstlane((m_begin + d_step * WG_RS) * yC * 4); \
             _Pragma("unroll") \
             for (int i = 0; i < NB; ++i) { \
                 float* dst_ = Ys + __builtin_amdgcn_readfirstlane(d_ring * WG_RS * BJ + (wave + 4 * i) * RPB * BJ); \
                 const int row_ = (wave + 4 * i) * RPB + brow; \
                 const unsigned voff_ = (m_begin + d_step * WG_RS + row_ < m_end) \
-                                           ? ((unsigned)row_ * (unsigned)Cout + (unsigned)(co0 + 4 * bchunk)) * 4u : SIDE_FLAG; \
+                                           ? ((unsigned)row_ * (unsigned)yC + (unsigned)(yc0 + 4 * bchunk)) * 4u : SIDE_FLAG; \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)dst_, 16, voff_, y_soff, 0, 0); \
             } \
             d_ring = d_ring == 2 ? 0 : d_ring + 1; \
@@ -1121,13 +1149,14 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
 // four waves each sum a quarter of the S slabs (256-byte coalesced reads, independent loads), the quarters are
 // combined in a fixed order through LDS (deterministic), and wave 0 stores into the (Cout, Cin, 7) parameter layout.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
-                                                       const float* __restrict__ bias_partial, float* __restrict__ dbias, int S,
-                                                       int Cin, int Cout) {
+                                                       const float* __restrict__ bias_partial, float* __restrict__ dbias,
+                                                       float* __restrict__ dw2, float* __restrict__ dbias2, int S, int Cin, int Cout,
+                                                       int Cout0) {
     __shared__ float red[4][64];
     const int total = 7 * Cin * Cout;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;                  // element of [weights | bias]
-    const bool is_w = i < total, is_b = !is_w && dbias != nullptr && i - total < Cout;
+    const bool is_w = i < total, is_b = !is_w && bias_partial != nullptr && i - total < Cout;
     const float* src = is_w ? partial + i : bias_partial + (i - total);
     const size_t stride = is_w ? (size_t)total : (size_t)Cout;
     const int k0 = (S * q) / 4, k1 = (S * (q + 1)) / 4;
@@ -1148,9 +1177,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
         const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
         if (is_w) {
             const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cin * Cout);
-            dw[((size_t)co * Cin + ci) * 7 + t] = v;
+            if (co < Cout0) dw[((size_t)co * Cin + ci) * 7 + t] = v;
+            else dw2[((size_t)(co - Cout0) * Cin + ci) * 7 + t] = v;
         } else if (is_b) {
-            dbias[i - total] = v;
+            const int co = i - total;
+            if (co < Cout0) { if (dbias) dbias[co] = v; }
+            else if (dbias2) dbias2[co - Cout0] = v;
         }
     }
 }
@@ -1289,14 +1321,28 @@ static size_t wgrad_lds(int bi, int bj, bool dma) {
 }
 static int wgrad_occ(int bi, int bj) { return std::min(4, (int)((160 * 1024) / wgrad_lds(bi, bj, true))); }
 
+// co tile of the MFMA wgrad kernels; a pair's tiles must not straddle its two output tensors
+static int wgrad_bj(int Cout, int Cout0) {
+    const int c1 = Cout - Cout0;
+    return (Cout0 % 128 == 0 && c1 % 128 == 0) ? 128 : 64;
+}
+
+bool wgrad_pair_supported(int M, int Ps, int Pd, int Cin, int Cout0, int Cout1) {
+    if (dbg_flags() & 32) return false;
+    if (Cin % 64 != 0 || Cout0 % 64 != 0 || Cout1 % 64 != 0) return false;
+    const size_t x_bytes = (size_t)(M / Pd) * Ps * Cin * 4, dy_bytes = (size_t)M * std::max(Cout0, Cout1) * 4;
+    return x_bytes < ((size_t)1 << 31) && dy_bytes < ((size_t)1 << 31);
+}
+
 // number of row splits (= partial slabs) each wgrad flavour uses; shared by the workspace query and the launch
-int wgrad_splits(int M, int Cin, int Cout) {
+int wgrad_splits(int M, int Cin, int Cout, int Cout0) {
+    if (Cout0 <= 0 || Cout0 > Cout) Cout0 = Cout;
     if (wgrad_supported(Cin, Cout)) {
         // One block per (ci tile, co tile, tap, row split).  Measured on I5 / batch 36 (tools/bench_layers.py with
         // ICN_WG_MULT = 0.75 ... 6): about three rounds of blocks over the chip's co-resident block slots is best -- one
         // exactly filled round of long blocks is 15 % slower (blocks drift apart and the tail idles), many more rounds
         // only add partial-slab traffic.
-        const int bi = (Cin % 128 == 0) ? 128 : 64, bj = (Cout % 128 == 0) ? 128 : 64;
+        const int bi = (Cin % 128 == 0) ? 128 : 64, bj = wgrad_bj(Cout, Cout0);
         const long tiles = 7L * (Cin / bi) * (Cout / bj);
         static const double mult = getenv("ICN_WG_MULT") ? atof(getenv("ICN_WG_MULT")) : 3.0;   // developer override
         long s = (long)(mult * 256L * wgrad_occ(bi, bj) / tiles);
@@ -1310,25 +1356,28 @@ int wgrad_splits(int M, int Cin, int Cout) {
 }
 
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
-    const int S = wgrad_splits(a.M, a.Cin, a.Cout);
+    const bool pair = a.dy2 != nullptr;
+    const int Cout0 = pair ? a.Cout0 : a.Cout;
+    const int S = wgrad_splits(a.M, a.Cin, a.Cout, Cout0);
     if (wgrad_supported(a.Cin, a.Cout)) {
         int rows = (a.M + S - 1) / S;
         rows = (rows + 31) / 32 * 32;
-        const bool bi128 = a.Cin % 128 == 0, bj128 = a.Cout % 128 == 0;
+        const bool bi128 = a.Cin % 128 == 0, bj128 = wgrad_bj(a.Cout, Cout0) == 128;
         const int BI = bi128 ? 128 : 64, BJ = bj128 ? 128 : 64;
         dim3 grid((a.Cin / BI) * (a.Cout / BJ) * 7 * ((S + 7) / 8 * 8));   // whole XCD rounds; blocks of splits >= S exit
         const size_t lds = wgrad_lds(BI, BJ, false);
-        const size_t x_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.Cin * 4, dy_bytes = (size_t)a.M * a.Cout * 4;
+        const size_t x_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.Cin * 4, dy_bytes = (size_t)a.M * std::max(Cout0, a.Cout - Cout0) * 4;
         const size_t side_bytes = (size_t)(a.M / a.Pd) * a.n_slots * a.Cin * 4;
         const bool dma = !(dbg_flags() & 32) && a.dcode != nullptr && (a.n_slots == 0 || a.side != nullptr) &&
                          x_bytes < ((size_t)1 << 31) && dy_bytes < ((size_t)1 << 31) && side_bytes < ((size_t)1 << 30);
+        if (pair && !dma) throw std::invalid_argument("icn: pair weight gradient outside the LDS-DMA kernel's limits");
         const size_t lds_dma = wgrad_lds(BI, BJ, true);
 #define ICN_WG(I, J)                                                                                                       \
     do {                                                                                                                   \
         if (dma)                                                                                                           \
-            hipLaunchKernelGGL((k_wgrad_dma<I, J>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.dcode,                         \
+            hipLaunchKernelGGL((k_wgrad_dma<I, J>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.dy2, a.dcode,                  \
                                a.n_slots > 0 ? a.side : nullptr, a.partial, a.bias_partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout,   \
-                               a.n_slots, rows, S, (unsigned)x_bytes, (unsigned)dy_bytes, (unsigned)side_bytes);             \
+                               Cout0, a.n_slots, rows, S, (unsigned)x_bytes, (unsigned)side_bytes);                          \
         else                                                                                                               \
             hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M,   \
                                a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows, S);                                                  \
@@ -1358,8 +1407,8 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
                            a.Pd, a.Cin, a.Cout, a.ns, rows);
     }
     const int elems = 7 * a.Cin * a.Cout + a.Cout;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems + 63) / 64), dim3(256), 0, s, a.partial, a.dw, a.bias_partial, a.dbias, S,
-                       a.Cin, a.Cout);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems + 63) / 64), dim3(256), 0, s, a.partial, a.dw, a.bias_partial, a.dbias, a.dw2,
+                       a.dbias2, S, a.Cin, a.Cout, Cout0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1469,13 +1518,11 @@ void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int 
                        nv, nvp, P, C);
 }
 
-void launch_conv_prologue(const float* w, float* packed, int Cout, int Cin, int transpose, const float* src, const int32_t* slots,
-                          float* side, int n_slots, int E, int B, int Ps, int K, int ns, hipStream_t s) {
-    const int npack = w ? std::min(2048, (Cout * Cin * 7 + 255) / 256) : 0;
-    const int nside = (side && n_slots > 0) ? B * n_slots : 0;
+void launch_conv_prologue(const PrologueArgs& a, hipStream_t s) {
+    const int npack = a.w ? std::min(2048, ((a.Cout + a.Cout2) * a.Cin * 7 + 255) / 256) : 0;
+    const int nside = (a.side && a.n_slots > 0) ? a.B * a.n_slots * (a.src2 ? 2 : 1) : 0;
     if (npack + nside == 0) return;
-    hipLaunchKernelGGL(k_conv_prologue, dim3(npack + nside), dim3(256), 0, s, w, packed, Cout, Cin, transpose, npack, src, slots,
-                       side, n_slots, E, Ps, K, ns);
+    hipLaunchKernelGGL(k_conv_prologue, dim3(npack + nside), dim3(256), 0, s, a, npack);
 }
 
 }  // namespace icn

@@ -5,14 +5,22 @@
 
 namespace icn {
 
+// Gather-GEMM  dst[m, :] = sum_t gather_t(src)[m, :] . wt[t]^T (+ bias).
+// Pair forms (two convolutions sharing their input, reference models.py:37-39,59-60) are plain concatenations:
+//   * src2 != null: the K (channel) axis is [src | src2], K / 2 channels each (bwd-data of a pair: dy0 | dy1);
+//   * dst2 != null: the N axis is [dst (N0 columns) | dst2 (N - N0 columns)] (forward of a pair).
 struct GatherGemmArgs {
-    const float* src;       // (B, Ps, K)
+    const float* src;       // (B, Ps, K)  [or (B, Ps, K/2) with src2]
+    const float* src2;      // second half of the K axis, or null
     const float* wt;        // [7][N][K]
     const float* bias;      // [N] or null
-    float* dst;             // (B, Pd, N)
+    float* dst;             // (B, Pd, N)  [or (B, Pd, N0) with dst2]
+    float* dst2;            // (B, Pd, N - N0) or null
+    int N0;                 // columns of dst (= N without dst2)
     const int32_t* idx;     // [7][E][Pd] full table (register-staged fall-back kernel)
     const int32_t* dcode;   // DmaTable code [7][Pd] of the same table (LDS-DMA kernel), or null
     const float* side;      // (B, n_slots, K) side buffer filled by launch_conv_prologue, or null
+    const float* side2;     // same for src2
     int n_slots;
     const int32_t* perm;    // [Pd] or null
     const uint32_t* mask32; // [Pd/32] tap mask per 32 rows (one word each: scalar loads), or null
@@ -22,24 +30,31 @@ struct GatherGemmArgs {
 
 struct WgradArgs {
     const float* x;         // (B, Ps, Cin)
-    const float* dy;        // (B, Pd, Cout)
+    const float* dy;        // (B, Pd, Cout)  [or (B, Pd, Cout0) with dy2: Cout = Cout0 + Cout1]
+    const float* dy2;       // (B, Pd, Cout - Cout0) or null: weight gradient of a pair sharing x
+    int Cout0;              // channels of dy (= Cout without dy2)
     const int32_t* idx;     // forward table [7][Pd]
     const int32_t* dcode;   // its DmaTable code [7][Pd] (LDS-DMA kernel), or null
     const float* side;      // (B, n_slots, Cin) pole means of x filled by launch_conv_prologue, or null
     int n_slots;
     float* partial;         // [S][7][Cin][Cout]
     float* bias_partial;    // [S][Cout] (null when dbias is null)
-    float* dw;              // [Cout][Cin][7]
-    float* dbias;           // [Cout] or null
+    float* dw;              // [Cout0][Cin][7]
+    float* dbias;           // [Cout0] or null
+    float* dw2;             // [Cout - Cout0][Cin][7] (pair only)
+    float* dbias2;          // [Cout - Cout0] or null
     int M, Ps, Pd, Cin, Cout, ns;
     double algo_flops;
 };
 
 bool gather_gemm_supported(int K, int N);
+bool conv_dma_usable(const GatherGemmArgs& a);     // the LDS-DMA kernel can run these arguments (pairs need it)
 void launch_gather_gemm_auto(const GatherGemmArgs& a, hipStream_t s);
 
 bool wgrad_supported(int Cin, int Cout);
-int wgrad_splits(int M, int Cin, int Cout);
+bool wgrad_pair_supported(int M, int Ps, int Pd, int Cin, int Cout0, int Cout1);
+// row splits (= partial slabs); Cout0 < Cout: pair whose co tiles must not straddle the two outputs
+int wgrad_splits(int M, int Cin, int Cout, int Cout0 = 0);
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
 bool stem_supported(int Cin, int Cout);
 void launch_stem_fwd(const float* x, const float* w, const float* bias, float* y, const int32_t* idx, int M, int Ps, int Pd,
@@ -57,8 +72,14 @@ void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int 
 
 // One launch ahead of a conv call: repack the weights (skipped when w is null) and fill the side buffer of a DmaTable
 // (skipped when side is null or n_slots == 0) from `src` (B, Ps, K).
-void launch_conv_prologue(const float* w, float* packed, int Cout, int Cin, int transpose, const float* src, const int32_t* slots,
-                          float* side, int n_slots, int E, int B, int Ps, int K, int ns, hipStream_t s);
+// Pairs: w2 (Cout2, Cin, 7) is packed behind w along the output-channel axis, bias / bias2 are concatenated into bias_cat
+// (skipped when null), src2 / side2 is a second source tensor of the same shape.
+struct PrologueArgs {
+    const float* w; const float* w2; float* packed; int Cout, Cout2, Cin, transpose;
+    const float* bias; const float* bias2; float* bias_cat;
+    const float* src; const float* src2; const int32_t* slots; float* side; float* side2; int n_slots, E, B, Ps, K, ns;
+};
+void launch_conv_prologue(const PrologueArgs& a, hipStream_t s);
 
 // ---- fused BatchNorm (+ residual) + ReLU (icn_bn.hip); stat = [mean | invstd] (2*C), sums = NS*C, ws = chunks*NS*C floats
 bool bn_supported(int C);

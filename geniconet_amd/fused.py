@@ -13,7 +13,7 @@ import os
 import torch
 
 from . import _lib
-from .ico_conv import _nhwc, _stream
+from .ico_conv import _nhwc, _stream, ico_conv_pair, ico_conv_pair_supported
 
 _DISABLED = os.environ.get('ICN_NO_FUSED_BN', '') == '1'
 
@@ -30,6 +30,26 @@ def can_fuse(x, *bns):
         if c % 4 or c > 1024 or 256 % (c // 4):
             return False
     return True
+
+
+_NO_PAIR = os.environ.get('ICN_NO_PAIR', '') == '1'
+
+
+def conv_pair(x, conv_a, conv_b):
+    """(conv_a(x), conv_b(x)) for two IcoConvS2S modules that see the same tensor -- conv00 / conv10 of the reference's
+    residual blocks (models.py:37-39,59-60).  One launch per pass (icn_conv_pair_*) when the two agree in stride / level /
+    corner mode / bias, the shape is inside the pair path and nobody hooked either module; else two module calls."""
+    ok = (not _NO_PAIR and x.is_cuda and x.dtype == torch.float32
+          and conv_a.stride == conv_b.stride and conv_a.subdivisions == conv_b.subdivisions
+          and conv_a.corner_mode == conv_b.corner_mode and (conv_a.bias is None) == (conv_b.bias is None))
+    if ok:
+        for m in (conv_a, conv_b):
+            if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks:
+                ok = False
+    if ok and ico_conv_pair_supported(x, conv_a.weight, conv_b.weight, conv_a.subdivisions, conv_a.stride):
+        return ico_conv_pair(x, conv_a.weight, conv_a.bias, conv_b.weight, conv_b.bias, conv_a.subdivisions,
+                             conv_a.stride, conv_a.corner_mode)
+    return conv_a(x), conv_b(x)
 
 
 class _BnReluFn(torch.autograd.Function):

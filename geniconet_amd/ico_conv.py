@@ -96,6 +96,67 @@ class _IcoConvFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class _IcoConvPairFn(torch.autograd.Function):
+    """Two IcoConvS2S of the SAME input (the conv00 / conv10 branches of the reference's residual blocks,
+    models.py:37-39,59-60) as one launch per pass -- icn_conv_pair_* in include/icn.h.  Same results as two
+    _IcoConvFn calls (bwd-data: as their sum)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, r, stride, mode):
+        L = _lib.lib()
+        B, Cin = x.shape[0], x.shape[1]
+        C0, C1 = w0.shape[0], w1.shape[0]
+        n_out = 2 ** r // stride
+        xp = _nhwc(x)
+        w0c, w1c = w0.contiguous(), w1.contiguous()
+        b0c = b0.contiguous() if b0 is not None else None
+        b1c = b1.contiguous() if b1 is not None else None
+        y0 = torch.empty(B, 5 * n_out, 2 * n_out, C0, dtype=torch.float32, device=x.device)
+        y1 = torch.empty(B, 5 * n_out, 2 * n_out, C1, dtype=torch.float32, device=x.device)
+        ws_bytes = L.icn_conv_pair_workspace_bytes(_lib.OP_CONV_FWD, B, Cin, C0, C1, r, stride)
+        ws = _workspace(ws_bytes, x.device)
+        with torch.cuda.device(x.device):
+            rc = L.icn_conv_pair_fwd(xp.data_ptr(), w0c.data_ptr(), b0c.data_ptr() if b0c is not None else None,
+                                     w1c.data_ptr(), b1c.data_ptr() if b1c is not None else None, y0.data_ptr(),
+                                     y1.data_ptr(), B, Cin, C0, C1, r, stride, mode, ws.data_ptr(), ws_bytes, _stream())
+        _lib.check(rc, 'icn_conv_pair_fwd')
+        ctx.save_for_backward(xp, w0c, w1c)
+        ctx.cfg = (B, Cin, C0, C1, r, stride, mode, b0 is not None)
+        return y0.permute(0, 3, 1, 2), y1.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy0, gy1):
+        L = _lib.lib()
+        xp, w0, w1 = ctx.saved_tensors
+        B, Cin, C0, C1, r, stride, mode, has_bias = ctx.cfg
+        g0, g1 = _nhwc(gy0), _nhwc(gy1)
+        dx = dw0 = db0 = dw1 = db1 = None
+        need = ctx.needs_input_grad
+        with torch.cuda.device(g0.device):
+            if need[0]:
+                dxp = torch.empty_like(xp)
+                ws_bytes = L.icn_conv_pair_workspace_bytes(_lib.OP_CONV_BWD_DATA, B, Cin, C0, C1, r, stride)
+                ws = _workspace(ws_bytes, g0.device)
+                rc = L.icn_conv_pair_bwd_data(g0.data_ptr(), g1.data_ptr(), w0.data_ptr(), w1.data_ptr(), dxp.data_ptr(),
+                                              B, Cin, C0, C1, r, stride, mode, ws.data_ptr(), ws_bytes, _stream())
+                _lib.check(rc, 'icn_conv_pair_bwd_data')
+                dx = dxp.permute(0, 3, 1, 2)
+            if need[1] or need[3] or (has_bias and (need[2] or need[4])):
+                dw0, dw1 = torch.empty_like(w0), torch.empty_like(w1)
+                if has_bias:
+                    db0 = torch.empty(C0, dtype=torch.float32, device=w0.device)
+                    db1 = torch.empty(C1, dtype=torch.float32, device=w1.device)
+                ws_bytes = L.icn_conv_pair_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, B, Cin, C0, C1, r, stride)
+                ws = _workspace(ws_bytes, g0.device)
+                rc = L.icn_conv_pair_bwd_weight(xp.data_ptr(), g0.data_ptr(), g1.data_ptr(), dw0.data_ptr(),
+                                                db0.data_ptr() if db0 is not None else None, dw1.data_ptr(),
+                                                db1.data_ptr() if db1 is not None else None, B, Cin, C0, C1, r, stride, mode,
+                                                ws.data_ptr(), ws_bytes, _stream())
+                _lib.check(rc, 'icn_conv_pair_bwd_weight')
+        return dx, dw0, db0, dw1, db1, None, None, None
+
+
 class _IcoUpsampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, r, mode):
@@ -133,6 +194,29 @@ def ico_conv(x, weight, bias, subdivisions, stride=1, corner_mode='zeros'):
     if stride not in (1, 2):
         raise ValueError('ico_conv: stride must be 1 or 2')
     return _IcoConvFn.apply(x, weight, bias, subdivisions, stride, _lib.corner_code(corner_mode))
+
+
+def ico_conv_pair_supported(x, weight0, weight1, subdivisions, stride=1):
+    """True when two convolutions of x with these weights can take the one-launch-per-pass pair path."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight0.dim() == 3 and weight1.dim() == 3):
+        return False
+    return bool(_lib.lib().icn_conv_pair_supported(x.shape[0], x.shape[1], weight0.shape[0], weight1.shape[0],
+                                                    subdivisions, stride))
+
+
+def ico_conv_pair(x, weight0, bias0, weight1, bias1, subdivisions, stride=1, corner_mode='zeros'):
+    """(ico_conv(x, weight0, bias0, ...), ico_conv(x, weight1, bias1, ...)) in one launch per pass.  Raises when the
+    shape is outside the pair path (ico_conv_pair_supported); the caller then uses two ico_conv calls."""
+    _require_gpu(x, 'ico_conv_pair')
+    _check_grid(x, subdivisions, 'ico_conv_pair')
+    for w in (weight0, weight1):
+        if w.dim() != 3 or w.shape[1] != x.shape[1] or w.shape[2] != 7:
+            raise ValueError('ico_conv_pair: weight must be (Cout, %d, 7), got %s' % (x.shape[1], tuple(w.shape)))
+    if (bias0 is None) != (bias1 is None):
+        raise ValueError('ico_conv_pair: both convolutions carry a bias or neither does')
+    if stride not in (1, 2):
+        raise ValueError('ico_conv_pair: stride must be 1 or 2')
+    return _IcoConvPairFn.apply(x, weight0, bias0, weight1, bias1, subdivisions, stride, _lib.corner_code(corner_mode))
 
 
 def ico_upsample(x, subdivisions, corner_mode='zeros'):

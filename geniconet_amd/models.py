@@ -37,11 +37,12 @@ class BasicIcoS2SDownBlock(nn.Module):
         self.icobn10 = nn.BatchNorm2d(out_features)
 
     def forward(self, x):
+        c00, c10 = fused.conv_pair(x, self.conv00, self.conv10)             # both branches read x: one launch per pass
         if fused.can_fuse(x, self.icobn00, self.icobn01, self.icobn10):    # same math, fused HIP BN / ReLU passes
-            h = fused.bn_relu(self.conv00(x), self.icobn00)
-            return fused.bn_add_relu(self.conv01(h), self.icobn01, self.conv10(x), self.icobn10)
-        main = self.icobn01(self.conv01(F.relu(self.icobn00(self.conv00(x)))))
-        skip = self.icobn10(self.conv10(x))
+            h = fused.bn_relu(c00, self.icobn00)
+            return fused.bn_add_relu(self.conv01(h), self.icobn01, c10, self.icobn10)
+        main = self.icobn01(self.conv01(F.relu(self.icobn00(c00))))
+        skip = self.icobn10(c10)
         return F.relu(main + skip)
 
 
@@ -67,11 +68,15 @@ class BasicIcoS2SUpBlock(nn.Module):
         up = self.upsample00(x)
         hooked = self.upsample10._forward_hooks or self.upsample10._forward_pre_hooks
         up_skip = self.upsample10(x) if hooked else up
+        if up_skip is up:
+            c00, c10 = fused.conv_pair(up, self.conv00, self.conv10)
+        else:
+            c00, c10 = self.conv00(up), self.conv10(up_skip)
         if fused.can_fuse(x, self.icobn00, self.icobn01, self.icobn10):
-            h = fused.bn_relu(self.conv00(up), self.icobn00)
-            return fused.bn_add_relu(self.conv01(h), self.icobn01, self.conv10(up_skip), self.icobn10)
-        main = self.icobn01(self.conv01(F.relu(self.icobn00(self.conv00(up)))))
-        skip = self.icobn10(self.conv10(up_skip))
+            h = fused.bn_relu(c00, self.icobn00)
+            return fused.bn_add_relu(self.conv01(h), self.icobn01, c10, self.icobn10)
+        main = self.icobn01(self.conv01(F.relu(self.icobn00(c00))))
+        skip = self.icobn10(c10)
         return F.relu(main + skip)
 
 

@@ -67,6 +67,24 @@ int icn_conv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin
 int icn_conv_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout,
                         int r_in, int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream);
 
+/* Pair forms: two convolutions of the SAME input with equal stride / level / corner mode -- the conv00 / conv10 branches
+ * of the reference's residual blocks (models.py:25-39 BasicIcoS2SDownBlock, 43-62 BasicIcoS2SUpBlock) -- as one launch
+ * per pass: forward with the output channels concatenated (one gather feeds both), bwd-data with dy0 | dy1 concatenated
+ * along the GEMM's K axis (one dx; no separate gradient add), bwd-weight with the shared x gathered once.  Results are
+ * those of the two single calls (bwd-data: of their sum).  icn_conv_pair_supported() says whether a shape can take this
+ * path (equal output channel counts, multiples of 64, tensors below 2 GiB); otherwise use the single-conv entry points.
+ * bias0 / bias1: both or neither.  Workspace: icn_conv_pair_workspace_bytes(op, ...), op as above. */
+int icn_conv_pair_supported(int B, int Cin, int Cout0, int Cout1, int r_in, int stride);
+size_t icn_conv_pair_workspace_bytes(int op, int B, int Cin, int Cout0, int Cout1, int r_in, int stride);
+int icn_conv_pair_fwd(const float* x, const float* w0, const float* bias0, const float* w1, const float* bias1, float* y0, float* y1,
+                      int B, int Cin, int Cout0, int Cout1, int r_in, int stride, int corner_mode, void* ws, size_t ws_bytes,
+                      void* stream);
+int icn_conv_pair_bwd_data(const float* dy0, const float* dy1, const float* w0, const float* w1, float* dx, int B, int Cin, int Cout0,
+                           int Cout1, int r_in, int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream);
+int icn_conv_pair_bwd_weight(const float* x, const float* dy0, const float* dy1, float* dw0, float* dbias0, float* dw1, float* dbias1,
+                             int B, int Cin, int Cout0, int Cout1, int r_in, int stride, int corner_mode, void* ws, size_t ws_bytes,
+                             void* stream);
+
 /* r_in -> r_in+1: copy at coarse sites (2i,2j+1), mean of the two edge endpoints elsewhere  (IcoUpsampleS2S) */
 int icn_upsample_fwd(const float* x, float* y, int B, int C, int r_in, int corner_mode, void* stream);
 int icn_upsample_bwd(const float* dy, float* dx, int B, int C, int r_in, int corner_mode, void* stream);

@@ -64,6 +64,72 @@ def test_conv_forward_backward(case):
         assert rel_l2(got.detach().cpu().numpy(), want.detach().numpy()) < TOL, k
 
 
+# Pair path (icn_conv_pair_*): conv00 / conv10 of a residual block share their input (reference models.py:37-39,59-60).
+# (r, stride, cin, cout per branch, B, mode, bias): stride-1 bwd-data in split mode (r >= 4) and through the side buffer
+# (r <= 3), stride 2 (row permutation + tap masks with the two dy concatenated along K), 64-channel branches (a 128-column
+# tile straddles the two outputs), no bias, 'zeros' corners.
+PAIR_CASES = [
+    (4, 1, 128, 64, 2, 'average', True), (3, 1, 64, 128, 2, 'average', True), (3, 2, 64, 128, 2, 'average', True),
+    (4, 2, 128, 256, 1, 'average', True), (2, 2, 256, 256, 3, 'average', False), (5, 1, 64, 64, 1, 'average', True),
+    (2, 1, 256, 256, 2, 'zeros', True), (4, 2, 64, 64, 2, 'zeros', False), (1, 1, 128, 128, 2, 'average', True),
+]
+
+
+@pytest.mark.parametrize('case', PAIR_CASES, ids=lambda c: 'r%d_s%d_%dx2x%d_b%d_%s_bias%d' % c)
+def test_conv_pair_matches_two_oracle_convs(case):
+    from geniconet_amd.ico_conv import ico_conv_pair, ico_conv_pair_supported
+    r, stride, cin, cout, B, mode, bias = case
+    g = torch.Generator().manual_seed(23)
+    n = 2 ** r
+    x = torch.randn(B, cin, 5 * n, 2 * n, generator=g)
+    ws = [torch.randn(cout, cin, 7, generator=g) / (7 * cin) ** 0.5 for _ in range(2)]
+    bs = [torch.randn(cout, generator=g) if bias else None for _ in range(2)]
+    xr = x.clone().requires_grad_()
+    wr = [w.clone().requires_grad_() for w in ws]
+    br = [b.clone().requires_grad_() if bias else None for b in bs]
+    yr = [ico_ref.ico_conv(xr, wr[k], br[k], r, stride, mode) for k in range(2)]
+    gys = [torch.randn(y.shape, generator=g) for y in yr]
+    (yr[0] * gys[0]).sum().add((yr[1] * gys[1]).sum()).backward()          # dx = sum of the two branches' gradients
+    xg = x.cuda().requires_grad_()
+    wg = [w.cuda().requires_grad_() for w in ws]
+    bg = [b.cuda().requires_grad_() if bias else None for b in bs]
+    assert ico_conv_pair_supported(xg, wg[0], wg[1], r, stride)
+    yg = ico_conv_pair(xg, wg[0], bg[0], wg[1], bg[1], r, stride, mode)
+    torch.autograd.backward(yg, [gy.cuda() for gy in gys])
+    pairs = {'y0': (yg[0], yr[0]), 'y1': (yg[1], yr[1]), 'dx': (xg.grad, xr.grad), 'dw0': (wg[0].grad, wr[0].grad),
+             'dw1': (wg[1].grad, wr[1].grad)}
+    if bias:
+        pairs.update({'db0': (bg[0].grad, br[0].grad), 'db1': (bg[1].grad, br[1].grad)})
+    for k, (got, want) in pairs.items():
+        assert got.shape == want.shape, k
+        assert rel_l2(got.detach().cpu().numpy(), want.detach().numpy()) < TOL, k
+
+
+def test_conv_pair_falls_back_outside_its_limits():
+    """Unequal branch widths are outside the pair path: the query says so, the op refuses loudly, and the block-level
+    dispatch (fused.conv_pair) silently uses two single convolutions -- also when someone hooked one of the modules."""
+    from geniconet_amd import fused
+    from geniconet_amd.ico_conv import IcoConvS2S, ico_conv_pair, ico_conv_pair_supported
+    torch.manual_seed(3)
+    x = torch.randn(2, 64, 20, 8, device='cuda')
+    a = IcoConvS2S(64, 64, subdivisions=2, corner_mode='average').cuda()
+    b = IcoConvS2S(64, 128, subdivisions=2, corner_mode='average').cuda()
+    assert not ico_conv_pair_supported(x, a.weight, b.weight, 2, 1)
+    with pytest.raises(RuntimeError):
+        ico_conv_pair(x, a.weight, a.bias, b.weight, b.bias, 2, 1, 'average')
+    ya, yb = fused.conv_pair(x, a, b)
+    assert torch.equal(ya, a(x)) and torch.equal(yb, b(x))
+    c = IcoConvS2S(64, 64, subdivisions=2, corner_mode='average').cuda()
+    paired = fused.conv_pair(x, a, c)
+    seen = []
+    h = c.register_forward_hook(lambda m, i, o: seen.append(1))
+    hooked = fused.conv_pair(x, a, c)
+    h.remove()
+    assert seen == [1]                                   # the hooked module was really called
+    for p_, h_ in zip(paired, hooked):
+        assert rel_l2(p_.detach().cpu().numpy(), h_.detach().cpu().numpy()) < 1e-6
+
+
 def test_conv_without_bias_and_noncontiguous_input():
     from geniconet_amd.ico_conv import ico_conv
     for k, (got, want) in conv_both(2, 1, 64, 64, 2, 'average', seed=5, bias=False).items():
