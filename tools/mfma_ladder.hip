@@ -2,6 +2,7 @@
 //   L0 registers only | L1 + swizzled ds_read_b128 fragments (TM+TN per 4*TM*TN MFMAs) | L2 + one barrier per K-step
 //   L3 + LDS-DMA of (BM+BN) x 128 B per K-step from an L2-resident buffer into a 3-stage ring (counted vmcnt)
 //   L4 the conv's real gather traffic | L5 = L4 with the A rows fetched by global_load_lds (64-bit per-lane addresses)
+//   NST (template): ring stages; the DMA pointer runs NST - 1 stages ahead, the counted wait leaves (NST - 2) * NDMA in flight
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -13,17 +14,17 @@ using glb_ptr_t = __attribute__((address_space(1))) void*;
 constexpr int BK = 32;
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-template <int BM, int BN, int LEVEL>
+template <int BM, int BN, int LEVEL, int NST = 3>
 __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_bytes, float* out, int steps, int rows_total) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TM = BM / 64, TN = BN / 64, RA = BM / 32, RB = BN / 32, NDMA = RA + RB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);
-    float* Bs = As + 3 * BM * BK;
+    float* Bs = As + NST * BM * BK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5, rsub = lane >> 3, pc = lane & 7;
-    for (int i = tid; i < 3 * (BM + BN) * BK; i += 256) As[i] = 1e-3f * (float)((i * 37) % 101 - 50);
+    for (int i = tid; i < NST * (BM + BN) * BK; i += 256) As[i] = 1e-3f * (float)((i * 37) % 101 - 50);
     __syncthreads();
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
     unsigned aoff[RA], boff[RB];
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_b
     f32x4 fa[2][TM], fb[2][TN];
     for (int i = 0; i < TM; ++i) fa[0][i] = fa[1][i] = f32x4{1e-3f * lane, 2e-3f, -1e-3f, 5e-4f};
     for (int j = 0; j < TN; ++j) fb[0][j] = fb[1][j] = f32x4{-1e-3f, 1e-3f * (lane & 7), 3e-3f, 1e-3f};
-    int ring = 0, iring = 2;
+    int ring = 0, iring = NST - 1;             // the DMA pointer runs NST - 1 stages ahead
     auto dma = [&](int slot, int step) {
         if (LEVEL >= 4) {
             const int tile = (blockIdx.x + (step / 56) * gridDim.x) % (a_rows / BM);
@@ -73,7 +74,10 @@ __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_b
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(Bs + slot * BN * BK + 8 * (wave + 4 * i) * BK), 16, boff[i],
                                                      (step & 7) * 128, 0, 0);
     };
-    if (LEVEL >= 3) { dma(0, 0); dma(1, 1); }
+    if (LEVEL >= 3) {
+#pragma unroll
+        for (int q = 0; q < NST - 1; ++q) dma(q, q);
+    }
     for (int step = 0; step < steps; ++step) {
         const float* a_base = As + ring * BM * BK + (wr * (BM / 2) + l31) * BK;
         const float* b_base = Bs + ring * BN * BK + (wc * (BN / 2) + l31) * BK;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_b
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BK + 4 * (h ^ fl));
         }
-        if (LEVEL >= 3) dma(iring, step + 2);
+        if (LEVEL >= 3) dma(iring, step + NST - 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if (LEVEL >= 1 && kk < 3) {
@@ -103,10 +107,10 @@ __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_b
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i][s], fb[kk & 1][j][s], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (LEVEL >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        if (LEVEL >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NDMA) : "memory");   // stage step+1 landed
         if (LEVEL >= 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-        ring = ring == 2 ? 0 : ring + 1;
-        iring = iring == 2 ? 0 : iring + 1;
+        ring = ring == NST - 1 ? 0 : ring + 1;
+        iring = iring == NST - 1 ? 0 : iring + 1;
     }
     float sum = 0.f;
     for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
@@ -114,21 +118,21 @@ __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_b
 #endif
 }
 
-template <int BM, int BN, int LEVEL>
+template <int BM, int BN, int LEVEL, int NST = 3>
 void run(int blocks_per_cu, const float* src, unsigned src_bytes, float* out) {
     const int blocks = 256 * blocks_per_cu, steps = 4000 / blocks_per_cu;
-    const size_t lds = (size_t)3 * (BM + BN) * BK * 4;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ladder<BM, BN, LEVEL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t lds = (size_t)NST * (BM + BN) * BK * 4;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ladder<BM, BN, LEVEL, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_ladder<BM, BN, LEVEL>), dim3(blocks), dim3(256), lds, 0, src, src_bytes, out, steps, (int)(src_bytes / 1024));
+        hipLaunchKernelGGL((k_ladder<BM, BN, LEVEL, NST>), dim3(blocks), dim3(256), lds, 0, src, src_bytes, out, steps, (int)(src_bytes / 1024));
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
     }
     const double flops = (double)blocks * steps * 2.0 * BM * BN * BK;
-    printf("tile %3dx%-3d level %d  %d block(s)/CU  %.3f ms  %.1f TFLOP/s\n", BM, BN, LEVEL, blocks_per_cu, best, flops / best / 1e9);
+    printf("tile %3dx%-3d level %d  %d-stage ring  %d block(s)/CU  %.3f ms  %.1f TFLOP/s\n", BM, BN, LEVEL, NST, blocks_per_cu, best, flops / best / 1e9);
 }
 
 int main(int argc, char** argv) {
@@ -146,6 +150,20 @@ int main(int argc, char** argv) {
 #define LADDER(BM, BN, OCC) run<BM, BN, 0>(OCC, src, src_bytes, out); run<BM, BN, 1>(OCC, src, src_bytes, out); \
                             run<BM, BN, 2>(OCC, src, src_bytes, out); run<BM, BN, 3>(OCC, src, src_bytes, out); \
                             run<BM, BN, 4>(OCC, src, src_bytes, out);
+    if (argc > 1 && argv[1][0] == 'r') {   // ring depth vs occupancy at the conv's real traffic (level 4), each measured twice
+        for (int rep = 0; rep < 2; ++rep) {
+            run<64, 64, 4, 3>(3, src, src_bytes, out);      // production: 48 KB, 3 blocks / CU
+            run<64, 64, 4, 4>(2, src, src_bytes, out);      // 64 KB, 2 blocks / CU
+            run<64, 64, 4, 3>(2, src, src_bytes, out);      // control: 3 stages at 2 blocks / CU
+            run<64, 128, 4, 3>(2, src, src_bytes, out);     // production: 72 KB, 2 blocks / CU
+            run<64, 128, 4, 4>(1, src, src_bytes, out);     // 96 KB, 1 block / CU
+            run<64, 128, 4, 2>(2, src, src_bytes, out);     // 48 KB: would fit 3 blocks / CU
+            run<64, 128, 4, 2>(3, src, src_bytes, out);
+            run<64, 64, 4, 2>(3, src, src_bytes, out);      // 32 KB: control at production occupancy
+            run<64, 64, 4, 2>(4, src, src_bytes, out);      // ... and with the freed LDS spent on a 4th block
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'g') {   // buffer vs global LDS-DMA addressing of the gathered rows
         run<64, 128, 4>(2, src, src_bytes, out); run<64, 128, 5>(2, src, src_bytes, out);
         run<64, 64, 4>(3, src, src_bytes, out); run<64, 64, 5>(3, src, src_bytes, out);
