@@ -129,6 +129,20 @@ const ConvTables& conv_tables(int r_in, int stride, int mode) {
     return g_conv.emplace(key, t).first->second;
 }
 
+std::map<std::pair<int, int>, int32_t*> g_vf;                  // (device, r) -> incident-face table of the loss
+
+const int32_t* vertex_faces(int r) {
+    int dev = 0;
+    ICN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_pair(dev, r);
+    auto it = g_vf.find(key);
+    if (it != g_vf.end()) return it->second;
+    std::vector<int32_t> vf;
+    icn::build_vertex_faces(r, vf);
+    return g_vf.emplace(key, upload(vf)).first->second;
+}
+
 const UpTables& up_tables(int r_in, int mode) {
     int dev = 0;
     ICN_HIP(hipGetDevice(&dev));
@@ -583,6 +597,39 @@ int icn_upsample_bwd(const float* dy, float* dx, int B, int C, int r_in, int cor
         if (!dy || !dx || B < 1 || C < 1) throw std::invalid_argument("icn_upsample_bwd: bad arguments");
         const UpTables& t = up_tables(r_in, corner_mode);
         icn::launch_spmm_ell(dy, dx, t.idx_b, t.coef_b, B, t.Pf, t.Pc, C, t.Wb, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+// ---- point-to-point loss -----------------------------------------------------------------------------------------
+size_t icn_p2p_loss_workspace_floats(int B, int r) {
+    return (B < 1 || r < 0 || r > 10) ? 0 : (size_t)3 * icn::p2p_loss_blocks(B, icn::pixels(r));
+}
+
+int icn_p2p_loss_fwd(const float* grid, const float* target, int B, int r, float f_pos, float f_nor, float f_lap, float* terms,
+                     float* ws, void* stream) {
+    try {
+        if (!grid || !target || !terms || !ws) throw std::invalid_argument("icn_p2p_loss_fwd: null pointer");
+        if (B < 1 || r < 0 || r > 10) throw std::invalid_argument("icn_p2p_loss_fwd: bad B / subdivisions");
+        if ((size_t)B * (icn::pixels(r) + 2) >= (size_t)1 << 31) throw std::invalid_argument("icn_p2p_loss_fwd: B * vertices exceeds int32");
+        icn::launch_p2p_loss_fwd(grid, target, vertex_faces(r), ws, terms, B, icn::pixels(r), 1 << r, f_pos, f_nor, f_lap,
+                                 static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_p2p_loss_bwd_pos(const float* grid, const float* target, const float* upstream, int B, int r, float f_pos, float* dgrid,
+                         void* stream) {
+    try {
+        if (!grid || !target || !upstream || !dgrid) throw std::invalid_argument("icn_p2p_loss_bwd_pos: null pointer");
+        if (B < 1 || r < 0 || r > 10) throw std::invalid_argument("icn_p2p_loss_bwd_pos: bad B / subdivisions");
+        icn::launch_p2p_loss_bwd_pos(grid, target, upstream, f_pos, dgrid, B, icn::pixels(r), 1 << r, static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());
         return 0;
     } catch (const std::exception& e) {

@@ -334,4 +334,20 @@ void build_faces(int r, std::vector<int32_t>& faces) {
             }
 }
 
+void build_vertex_faces(int r, std::vector<int32_t>& vf) {
+    std::vector<int32_t> faces;
+    build_faces(r, faces);
+    const int V = pixels(r) + 2;
+    vf.assign((size_t)V * 12, -1);
+    std::vector<int> cnt(V, 0);
+    for (size_t f = 0; f + 2 < faces.size(); f += 3)
+        for (int k = 0; k < 3; ++k) {
+            const int i = faces[f + k];
+            if (cnt[i] >= 6) throw std::logic_error("build_vertex_faces: vertex with more than 6 faces");
+            vf[((size_t)i * 6 + cnt[i]) * 2 + 0] = faces[f + (k + 1) % 3];
+            vf[((size_t)i * 6 + cnt[i]) * 2 + 1] = faces[f + (k + 2) % 3];
+            ++cnt[i];
+        }
+}
+
 }  // namespace icn

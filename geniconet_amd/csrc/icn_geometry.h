@@ -85,4 +85,10 @@ void build_bwd_row_order(int r_in, int stride, const std::vector<int32_t>& bwd_i
 // Faces (20*4^r, 3) in the reference vertex order (grid row-major, then N, S).
 void build_faces(int r, std::vector<int32_t>& faces);
 
+// Incident faces of every vertex, for the mesh terms of the loss (reference losses.py:52-57): vf[(i * 6 + f) * 2 + {0, 1}] =
+// the other two vertices (p, q) of the f-th face at vertex i, in the face's orientation rotated so that i comes first
+// (cross(p - i, q - i) is the face normal of generate.py:28-31 whichever corner i is); -1 padded (the 12 five-valent
+// vertices have 5 faces).  On the closed mesh the p entries of a vertex are exactly its one-ring, each neighbour once.
+void build_vertex_faces(int r, std::vector<int32_t>& vf);
+
 }  // namespace icn

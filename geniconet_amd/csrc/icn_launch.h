@@ -98,6 +98,13 @@ void launch_head_fwd(const float* x, const float* w, const float* bias, float* y
 void launch_head_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
                      int M, int Cin, int Cout, hipStream_t s);
 
+// ---- point-to-point loss (icn_loss.hip): terms[4] = {pos, nor, lap, weighted total}; partial = 3 * p2p_loss_blocks floats
+int p2p_loss_blocks(int B, int P);
+void launch_p2p_loss_fwd(const float* grid, const float* target, const int32_t* vf, float* partial, float* terms, int B, int P, int n,
+                         float f_pos, float f_nor, float f_lap, hipStream_t s);
+void launch_p2p_loss_bwd_pos(const float* grid, const float* target, const float* upstream, float f_pos, float* dgrid, int B, int P,
+                             int n, hipStream_t s);
+
 // ---- optional per-launch HIP-event timing of the MFMA kernels (bench.py's live roofline measurement) ----------
 enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA_64x64, PROF_GG_128x128, PROF_GG_128x64,
                 PROF_GG_64x128, PROF_GG_64x64, PROF_WGD_128x128, PROF_WGD_128x64, PROF_WGD_64x128, PROF_WGD_64x64, PROF_WG_128x128,

@@ -1,0 +1,183 @@
+// Point-to-point loss of the training step on the HIP path (reference losses.py:10-85 Point2Point_Loss; mesh helpers as
+// restated in geniconet_amd/losses.py: vertex normals = area-weighted face-normal sums, generate.py:20-43; Laplacian =
+// uniform umbrella mean(1-ring) - v).  HBM/L2-bound, a few tens of microseconds; replaces ~25 torch launches per step.
+//
+//   v[b, i]   i < P: network output pixel i (channels-last (B, P, 3));  i = P, P + 1: N / S pole = mean of 5 corner pixels
+//   terms[0] = mean_{b,i,c} (v - t_pos)^2           terms[1] = mean_{b,i} (1 - cos(unit vertex normal, t_nor))
+//   terms[2] = mean_{b,i,c} (lap(v) - t_lap)^2      terms[3] = f_pos * terms[0] + f_nor * terms[1] + f_lap * terms[2]
+// target is (B, 9, V): rows 0:3 positions, 3:6 normals, 6:9 Laplacians (data.py:64-69).
+// Sums are two-level with fixed block size and a fixed tree (deterministic).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "icn_launch.h"
+
+namespace icn {
+
+namespace {
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+__device__ __forceinline__ int pole_corner(int n, int k, int c) {      // reference ico_utils.py:10-24
+    return k == 0 ? (c * n) * 2 * n : ((c + 1) * n - 1) * 2 * n + (2 * n - 1);
+}
+
+// vertex j of sample b from the channels-last grid (B, P, 3); poles: sum of the 5 corners / 5 (torch .mean)
+__device__ __forceinline__ f3 vertex(const float* __restrict__ g, int b, int j, int P, int n) {
+    if (j < P) {
+        const float* p = g + ((size_t)b * P + j) * 3;
+        return {p[0], p[1], p[2]};
+    }
+    f3 s = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const float* p = g + ((size_t)b * P + pole_corner(n, j - P, c)) * 3;
+        s = s + f3{p[0], p[1], p[2]};
+    }
+    return {s.x / 5.f, s.y / 5.f, s.z / 5.f};
+}
+
+constexpr int LOSS_BLOCK = 256;
+
+// fixed-order block sum of three values; result valid in thread 0
+__device__ __forceinline__ void block_sum3(float& a, float& b, float& c) {
+    __shared__ float red[3][LOSS_BLOCK / 64];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d, 64);
+        b += __shfl_xor(b, d, 64);
+        c += __shfl_xor(c, d, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = a; red[1][w] = b; red[2][w] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        c = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    }
+}
+
+__global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_fwd(const float* __restrict__ g, const float* __restrict__ target,
+                                                         const int32_t* __restrict__ vf, float* __restrict__ partial, int B, int P,
+                                                         int n) {
+    const int V = P + 2;
+    const long idx = (long)blockIdx.x * LOSS_BLOCK + threadIdx.x;
+    float e_pos = 0.f, e_nor = 0.f, e_lap = 0.f;
+    if (idx < (long)B * V) {
+        const int b = (int)(idx / V), i = (int)(idx % V);
+        const f3 v = vertex(g, b, i, P, n);
+        const float* t = target + (size_t)b * 9 * V + i;                 // component c at t[c * V]
+        const f3 tp = {t[0], t[(size_t)V], t[(size_t)2 * V]};
+        const f3 tn = {t[(size_t)3 * V], t[(size_t)4 * V], t[(size_t)5 * V]};
+        const f3 tl = {t[(size_t)6 * V], t[(size_t)7 * V], t[(size_t)8 * V]};
+        const f3 d = v - tp;
+        e_pos = dot(d, d);
+        f3 vn = {0.f, 0.f, 0.f}, ring = {0.f, 0.f, 0.f};
+        int k = 0;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const int p = vf[((size_t)i * 6 + f) * 2], q = vf[((size_t)i * 6 + f) * 2 + 1];
+            if (p < 0) continue;
+            const f3 vp = vertex(g, b, p, P, n), vq = vertex(g, b, q, P, n);
+            vn = vn + cross(vp - v, vq - v);
+            ring = ring + vp;
+            ++k;
+        }
+        const float len = fmaxf(sqrtf(dot(vn, vn)), 1e-10f);              // losses.py helper: vn / clamp_min(|vn|, eps)
+        const f3 u = {vn.x / len, vn.y / len, vn.z / len};
+        // F.cosine_similarity(u, tn, eps = 1e-8): each norm clamped separately
+        const float cs = dot(u, tn) / (fmaxf(sqrtf(dot(u, u)), 1e-8f) * fmaxf(sqrtf(dot(tn, tn)), 1e-8f));
+        e_nor = 1.f - cs;
+        const float inv = 1.f / (float)k;
+        const f3 lp = f3{ring.x * inv, ring.y * inv, ring.z * inv} - v;
+        const f3 dl = lp - tl;
+        e_lap = dot(dl, dl);
+    }
+    block_sum3(e_pos, e_nor, e_lap);
+    if (threadIdx.x == 0) {
+        partial[(size_t)blockIdx.x * 3 + 0] = e_pos;
+        partial[(size_t)blockIdx.x * 3 + 1] = e_nor;
+        partial[(size_t)blockIdx.x * 3 + 2] = e_lap;
+    }
+}
+
+// terms from the per-block partials: one block, lanes stride over the partials in double, fixed tree
+__global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_finalize(const float* __restrict__ partial, int nblocks, double count_vec,
+                                                              double count_vtx, float f_pos, float f_nor, float f_lap,
+                                                              float* __restrict__ terms) {
+    __shared__ double red[3][LOSS_BLOCK];
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int k = threadIdx.x; k < nblocks; k += LOSS_BLOCK)
+        for (int c = 0; c < 3; ++c) s[c] += (double)partial[(size_t)k * 3 + c];
+    for (int c = 0; c < 3; ++c) red[c][threadIdx.x] = s[c];
+    __syncthreads();
+    for (int d = LOSS_BLOCK / 2; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d)
+            for (int c = 0; c < 3; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float l_pos = (float)(red[0][0] / count_vec), l_nor = (float)(red[1][0] / count_vtx), l_lap = (float)(red[2][0] / count_vec);
+        terms[0] = l_pos;
+        terms[1] = l_nor;
+        terms[2] = l_lap;
+        terms[3] = f_pos * l_pos + f_nor * l_nor + f_lap * l_lap;
+    }
+}
+
+// d(f_pos * terms[0]) / d(grid) * upstream:  2 (v - t_pos) / (B V 3) at every pixel, plus a fifth of the pole's term at each
+// of its 5 corner pixels (the pole is their mean).  One thread per (sample, pixel): no write conflicts.
+__global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_bwd_pos(const float* __restrict__ g, const float* __restrict__ target,
+                                                             const float* __restrict__ upstream, float scale,
+                                                             float* __restrict__ dg, int B, int P, int n) {
+    const int V = P + 2;
+    const long idx = (long)blockIdx.x * LOSS_BLOCK + threadIdx.x;
+    if (idx >= (long)B * P) return;
+    const int b = (int)(idx / P), j = (int)(idx % P);
+    const float w = scale * upstream[0];
+    const float* t = target + (size_t)b * 9 * V;
+    const float* p = g + ((size_t)b * P + j) * 3;
+    f3 d = {p[0] - t[j], p[1] - t[(size_t)V + j], p[2] - t[(size_t)2 * V + j]};
+    const int chart = 2 * n * n;                                         // pixels per chart
+    int pole = -1;
+    if (j % chart == 0) pole = 0;                                        // (row c*n, col 0): corner of the N pole
+    else if ((j + 1) % chart == 0) pole = 1;                             // (row (c+1)*n - 1, col 2n - 1): S pole
+    if (pole >= 0) {
+        const f3 vp = vertex(g, b, P + pole, P, n);
+        const f3 dp = {vp.x - t[P + pole], vp.y - t[(size_t)V + P + pole], vp.z - t[(size_t)2 * V + P + pole]};
+        d = d + f3{dp.x / 5.f, dp.y / 5.f, dp.z / 5.f};
+    }
+    float* o = dg + ((size_t)b * P + j) * 3;
+    o[0] = w * d.x;
+    o[1] = w * d.y;
+    o[2] = w * d.z;
+}
+
+}  // namespace
+
+int p2p_loss_blocks(int B, int P) { return (int)(((long)B * (P + 2) + LOSS_BLOCK - 1) / LOSS_BLOCK); }
+
+void launch_p2p_loss_fwd(const float* grid, const float* target, const int32_t* vf, float* partial, float* terms, int B, int P, int n,
+                         float f_pos, float f_nor, float f_lap, hipStream_t s) {
+    const int nb = p2p_loss_blocks(B, P);
+    hipLaunchKernelGGL(k_p2p_fwd, dim3(nb), dim3(LOSS_BLOCK), 0, s, grid, target, vf, partial, B, P, n);
+    const double nv = (double)B * (P + 2);
+    hipLaunchKernelGGL(k_p2p_finalize, dim3(1), dim3(LOSS_BLOCK), 0, s, partial, nb, nv * 3.0, nv, f_pos, f_nor, f_lap, terms);
+}
+
+void launch_p2p_loss_bwd_pos(const float* grid, const float* target, const float* upstream, float f_pos, float* dgrid, int B, int P,
+                             int n, hipStream_t s) {
+    const long total = (long)B * P;
+    const float scale = (float)(2.0 * (double)f_pos / ((double)B * (P + 2) * 3.0));
+    hipLaunchKernelGGL(k_p2p_bwd_pos, dim3((unsigned)((total + LOSS_BLOCK - 1) / LOSS_BLOCK)), dim3(LOSS_BLOCK), 0, s, grid, target,
+                       upstream, scale, dgrid, B, P, n);
+}
+
+}  // namespace icn

@@ -7,10 +7,58 @@ imports from the absent `PythonFunctions/mesh/utils.py` (losses.py:7) are restat
   * Laplacian: uniform umbrella operator  mean(1-ring) - v  (upstream's sign/normalisation is unpinned).
 Loss values are kept as device tensors; `.item()` (a host sync in the reference on every iteration,
 losses.py:72,81,129) only happens when get_last_losses() is called.
+
+On ROCm fp32 tensors Point2Point_Loss runs as two HIP kernels (libicn's icn_p2p_loss_*) whenever only the position term
+needs a gradient -- the reference's training configuration -- or none is needed; the torch formulation below is what
+runs otherwise (other factors with gradients, other dtypes, CPU tensors as used by the CPU restatement in bench.py).
 """
+import os
+
 import torch
 
-from . import geometry
+from . import _lib, geometry
+
+_NO_HIP_LOSS = os.environ.get('ICN_NO_HIP_LOSS', '') == '1'
+
+
+class _P2PLossFn(torch.autograd.Function):
+    """Point2Point_Loss on the HIP path (icn_p2p_loss_* in include/icn.h): one kernel evaluates the three terms, one more
+    the gradient of the position term.  Only used when no other term needs a gradient (factor_nor = factor_lap = 0, the
+    configuration the reference trains with) or when no gradient is needed at all."""
+
+    @staticmethod
+    def forward(ctx, inputs, target, r, f_pos, f_nor, f_lap):
+        L = _lib.lib()
+        B = inputs.shape[0]
+        grid = inputs.permute(0, 2, 3, 1).contiguous()            # (B, 5n, 2n, 3) = (B, P, 3); free for channels_last
+        tgt = target.contiguous()
+        terms = torch.empty(4, dtype=torch.float32, device=inputs.device)
+        ws = torch.empty(max(L.icn_p2p_loss_workspace_floats(B, r), 1), dtype=torch.float32, device=inputs.device)
+        with torch.cuda.device(inputs.device):
+            rc = L.icn_p2p_loss_fwd(grid.data_ptr(), tgt.data_ptr(), B, r, f_pos, f_nor, f_lap, terms.data_ptr(), ws.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'icn_p2p_loss_fwd')
+        ctx.save_for_backward(grid, tgt)
+        ctx.cfg = (B, r, f_pos, f_nor, f_lap)
+        total = terms[3].clone()
+        ctx.mark_non_differentiable(terms)
+        return total, terms
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gtotal, _gterms):
+        B, r, f_pos, f_nor, f_lap = ctx.cfg
+        if f_nor != 0 or f_lap != 0:
+            raise RuntimeError('_P2PLossFn: the HIP backward covers the position term only')
+        L = _lib.lib()
+        grid, tgt = ctx.saved_tensors
+        dgrid = torch.empty_like(grid)
+        up = gtotal.contiguous().to(torch.float32)
+        with torch.cuda.device(grid.device):
+            rc = L.icn_p2p_loss_bwd_pos(grid.data_ptr(), tgt.data_ptr(), up.data_ptr(), B, r, f_pos, dgrid.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'icn_p2p_loss_bwd_pos')
+        return dgrid.permute(0, 3, 1, 2), None, None, None, None, None
 
 
 def grid_to_vertices(x, subdivisions):
@@ -56,7 +104,26 @@ class Point2Point_Loss(torch.nn.Module):
         self.register_buffer('nbr_w', valid.float() / valid.sum(1, keepdim=True).float())
         self.last_loss_mse = self.last_loss_cos = self.last_loss_lap = self.last_loss_total = 0
 
+    def _hip_path(self, inputs, target):
+        """HIP kernels when they cover what is asked: ROCm fp32 tensors of the expected shapes, and no gradient needed
+        through the normal / Laplacian terms (their factors are 0, or nothing requires grad)."""
+        if _NO_HIP_LOSS or not (inputs.is_cuda and target.is_cuda) or inputs.dtype != torch.float32 or target.dtype != torch.float32:
+            return False
+        n = 2 ** self.subdivisions
+        if inputs.dim() != 4 or tuple(inputs.shape[1:]) != (3, 5 * n, 2 * n):
+            return False
+        if tuple(target.shape) != (inputs.shape[0], 9, 10 * n * n + 2):
+            return False
+        needs_grad = torch.is_grad_enabled() and inputs.requires_grad
+        return not needs_grad or (self.factor_nor == 0 and self.factor_lap == 0)
+
     def forward(self, inputs, target):
+        if self._hip_path(inputs, target):
+            loss, terms = _P2PLossFn.apply(inputs, target, self.subdivisions, float(self.factor_pos), float(self.factor_nor),
+                                           float(self.factor_lap))
+            self.last_loss_mse, self.last_loss_cos, self.last_loss_lap = terms[0], terms[1], terms[2]
+            self.last_loss_total = terms[3]
+            return loss
         v = grid_to_vertices(inputs, self.subdivisions)
         tgt = target.transpose(1, 2)
         l_pos = torch.nn.functional.mse_loss(v, tgt[:, :, :3])

@@ -113,6 +113,22 @@ int icn_head_fwd(const float* x, const float* w, const float* bias, float* y, in
 int icn_head_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
                  int M, int Cin, int Cout, void* stream);
 
+/* Point-to-point loss of the training step (reference losses.py:10-85 Point2Point_Loss.forward; the absent mesh helpers as
+ * restated from generate.py:20-43: area-weighted vertex normals; uniform Laplacian mean(1-ring) - v).
+ *   grid   (B, P, 3)   network output, channels-last; vertices = pixels, then N / S pole = mean of their 5 corner pixels
+ *                      (ico_utils.py:10-24, losses.py:47-51)
+ *   target (B, 9, V)   V = P + 2: rows 0:3 positions, 3:6 normals, 6:9 Laplacians (data.py:64-69)
+ *   terms  [4]         mse(v, pos) | mean(1 - cos(normal(v), nor)) | mse(lap(v), lap) | f_pos*[0] + f_nor*[1] + f_lap*[2]
+ * All three terms are always evaluated (the reference reports them every iteration, losses.py:72-81).  The backward entry
+ * point covers the position term only -- the configuration the reference trains with (factor_nor = factor_lap = 0); with
+ * other factors the caller differentiates its own formulation.  upstream: device scalar dLoss/dterms[3].
+ * ws: icn_p2p_loss_workspace_floats(B, r) floats.  Deterministic (fixed two-level sums). */
+size_t icn_p2p_loss_workspace_floats(int B, int r);
+int icn_p2p_loss_fwd(const float* grid, const float* target, int B, int r, float f_pos, float f_nor, float f_lap, float* terms,
+                     float* ws, void* stream);
+int icn_p2p_loss_bwd_pos(const float* grid, const float* target, const float* upstream, int B, int r, float f_pos, float* dgrid,
+                         void* stream);
+
 /* Host-side introspection (no device needed).  Each writes at most `cap` elements and returns the element
  * count required (negative on error). */
 long icn_table_conv_fwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap);      /* [7][P_out]     */

@@ -55,6 +55,21 @@ def p2p_terms(pred, target, r):
     return ((v - t[:, :, :3]) ** 2).mean(), np.mean(cos), np.mean(lap_err)
 
 
+def p2p_pos_grad(pred, target, r):
+    """d mse_pos / d pred, (B,3,5n,2n): 2 (v - t) / (B N 3) at every pixel; a pole is the mean of its 5 corner pixels
+    px[c*n, 0] / px[(c+1)*n-1, 2n-1] (losses.py:23-31,49-51), so each of them also receives a fifth of the pole's term."""
+    pred, target = np.asarray(pred, np.float64), np.asarray(target, np.float64)
+    n = 2 ** r
+    B = pred.shape[0]
+    v = grid_to_vertices(pred, r)                                   # (B, N, 3)
+    d = 2.0 * (v - target.transpose(0, 2, 1)[:, :, :3]) / v.size    # (B, N, 3)
+    g = d[:, :-2].transpose(0, 2, 1).reshape(B, 3, 5 * n, 2 * n).copy()
+    for c in range(5):
+        g[:, :, c * n, 0] += d[:, -2] / 5.0
+        g[:, :, (c + 1) * n - 1, 2 * n - 1] += d[:, -1] / 5.0
+    return g
+
+
 def p2p_loss(pred, target, r, f_pos, f_nor, f_lap):
     a, b, c = p2p_terms(pred, target, r)
     return f_pos * a + f_nor * b + f_lap * c

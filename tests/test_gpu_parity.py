@@ -354,3 +354,79 @@ def test_training_step_runs_and_decreases_loss():
     x, t = data.synthetic_batch(4, 4, seed=1, device='cuda')
     losses_seen = [float(tr.step(x, t)) for _ in range(8)]
     assert all(np.isfinite(losses_seen)) and losses_seen[-1] < losses_seen[0]
+
+
+# ---- point-to-point loss on the HIP path (icn_p2p_loss_*) vs the numpy oracle (oracle/loss_ref.py) ---------------------
+def _loss_case(r, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    n = 2 ** r
+    pred = torch.randn(B, 3, 5 * n, 2 * n, generator=g)
+    target = torch.randn(B, 9, 10 * n * n + 2, generator=g)
+    return pred, target
+
+
+@pytest.mark.parametrize('r,B', [(0, 3), (1, 2), (2, 2), (3, 2)])
+def test_hip_loss_terms_match_numpy_oracle(r, B):
+    """r = 0: all 12 vertices are five-valent and every pixel is a pole corner."""
+    from geniconet_amd.losses import P2P_Loss
+    from oracle import loss_ref
+    pred, target = _loss_case(r, B, 31 + r)
+    crit = P2P_Loss(r, 0.7, 0.2, 0.1).cuda()
+    with torch.no_grad():
+        total = crit(pred.cuda().contiguous(memory_format=torch.channels_last), target.cuda())
+    want = loss_ref.p2p_terms(pred.numpy(), target.numpy(), r)
+    got = [float(crit.last_loss_mse), float(crit.last_loss_cos), float(crit.last_loss_lap)]
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
+    assert abs(float(total) - loss_ref.p2p_loss(pred.numpy(), target.numpy(), r, 0.7, 0.2, 0.1)) <= 2e-5 * abs(float(total))
+
+
+@pytest.mark.parametrize('r,B', [(0, 2), (2, 3), (4, 1)])
+def test_hip_loss_gradient_matches_oracle(r, B):
+    from geniconet_amd.losses import P2P_Loss
+    from oracle import loss_ref
+    pred, target = _loss_case(r, B, 47 + r)
+    crit = P2P_Loss(r, 0.7, 0.0, 0.0).cuda()
+    x = pred.cuda().requires_grad_()
+    (3.0 * crit(x, target.cuda())).backward()                      # upstream gradient 3
+    want = 3.0 * 0.7 * loss_ref.p2p_pos_grad(pred.numpy(), target.numpy(), r)
+    assert rel_l2(x.grad.cpu().numpy(), want) < 1e-5
+
+
+def test_hip_loss_agrees_with_torch_formulation_which_takes_over_for_other_factors():
+    """With a gradient needed through the normal / Laplacian terms the torch formulation runs (gradients flow); its term
+    values are the HIP kernel's."""
+    from geniconet_amd.losses import P2P_Loss
+    pred, target = _loss_case(3, 2, 5)
+    crit = P2P_Loss(3, 1.0, 0.5, 0.25).cuda()
+    x = pred.cuda().requires_grad_()
+    assert not crit._hip_path(x, target.cuda())
+    crit(x, target.cuda()).backward()
+    assert x.grad is not None and float(x.grad.abs().sum()) > 0
+    torch_terms = [float(crit.last_loss_mse), float(crit.last_loss_cos), float(crit.last_loss_lap), float(crit.last_loss_total)]
+    with torch.no_grad():
+        assert crit._hip_path(pred.cuda(), target.cuda())
+        crit(pred.cuda(), target.cuda())
+    hip_terms = [float(crit.last_loss_mse), float(crit.last_loss_cos), float(crit.last_loss_lap), float(crit.last_loss_total)]
+    for a, b in zip(hip_terms, torch_terms):
+        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (hip_terms, torch_terms)
+
+
+def test_hip_loss_full_size_scaling_property():
+    """I5 / batch 36 (the bench shape): scaling positions by s scales the position term by s^2 and, with the Laplacian
+    targets scaled alike, the Laplacian term by s^2; the normal term does not move."""
+    from geniconet_amd.losses import P2P_Loss
+    pred, target = _loss_case(5, 36, 9)
+    crit = P2P_Loss(5, 1.0, 0.0, 0.0).cuda()
+    x, t = pred.cuda(), target.cuda()
+    with torch.no_grad():
+        crit(x, t)
+        a = [float(crit.last_loss_mse), float(crit.last_loss_cos), float(crit.last_loss_lap)]
+        t2 = t.clone()
+        t2[:, 0:3] *= 2.0
+        t2[:, 6:9] *= 2.0
+        crit(2.0 * x, t2)
+        b = [float(crit.last_loss_mse), float(crit.last_loss_cos), float(crit.last_loss_lap)]
+    assert abs(b[0] - 4 * a[0]) <= 1e-5 * abs(4 * a[0])
+    assert abs(b[1] - a[1]) <= 1e-5 * abs(a[1])
+    assert abs(b[2] - 4 * a[2]) <= 1e-5 * abs(4 * a[2])
