@@ -9,8 +9,9 @@ Loss values are kept as device tensors; `.item()` (a host sync in the reference 
 losses.py:72,81,129) only happens when get_last_losses() is called.
 
 On ROCm fp32 tensors Point2Point_Loss runs as two HIP kernels (libicn's icn_p2p_loss_*) whenever only the position term
-needs a gradient -- the reference's training configuration -- or none is needed; the torch formulation below is what
-runs otherwise (other factors with gradients, other dtypes, CPU tensors as used by the CPU restatement in bench.py).
+needs a gradient -- the auto-encoder's training configuration, factors 1/0/0 (run.py:690-692) -- or none is needed.  The
+torch formulation below is what runs otherwise: the VAE's 0.6/0.2/0.2 (run.py:694-696) needs gradients through the normal
+and Laplacian terms; other dtypes; CPU tensors as used by the CPU restatement in bench.py.
 """
 import os
 
@@ -24,7 +25,7 @@ _NO_HIP_LOSS = os.environ.get('ICN_NO_HIP_LOSS', '') == '1'
 class _P2PLossFn(torch.autograd.Function):
     """Point2Point_Loss on the HIP path (icn_p2p_loss_* in include/icn.h): one kernel evaluates the three terms, one more
     the gradient of the position term.  Only used when no other term needs a gradient (factor_nor = factor_lap = 0, the
-    configuration the reference trains with) or when no gradient is needed at all."""
+    auto-encoder's configuration, run.py:690-692) or when no gradient is needed at all."""
 
     @staticmethod
     def forward(ctx, inputs, target, r, f_pos, f_nor, f_lap):

@@ -120,8 +120,9 @@ int icn_head_bwd(const float* dy, const float* y, const float* x, const float* w
  *   target (B, 9, V)   V = P + 2: rows 0:3 positions, 3:6 normals, 6:9 Laplacians (data.py:64-69)
  *   terms  [4]         mse(v, pos) | mean(1 - cos(normal(v), nor)) | mse(lap(v), lap) | f_pos*[0] + f_nor*[1] + f_lap*[2]
  * All three terms are always evaluated (the reference reports them every iteration, losses.py:72-81).  The backward entry
- * point covers the position term only -- the configuration the reference trains with (factor_nor = factor_lap = 0); with
- * other factors the caller differentiates its own formulation.  upstream: device scalar dLoss/dterms[3].
+ * point covers the position term only: that is the auto-encoder's training configuration (factors 1 / 0 / 0, run.py:690-692).
+ * The VAE trains with 0.6 / 0.2 / 0.2 (run.py:694-696), which needs gradients through the normal and Laplacian terms; those
+ * are not provided here and the caller differentiates its own formulation.  upstream: device scalar dLoss/dterms[3].
  * ws: icn_p2p_loss_workspace_floats(B, r) floats.  Deterministic (fixed two-level sums). */
 size_t icn_p2p_loss_workspace_floats(int B, int r);
 int icn_p2p_loss_fwd(const float* grid, const float* target, int B, int r, float f_pos, float f_nor, float f_lap, float* terms,

@@ -24,7 +24,8 @@ def timed(fn, iters=20):
 
 
 R, B = 5, 36
-p = models.default_params('ico2ico', subdivisions=R)
+MODEL = sys.argv[1] if len(sys.argv) > 1 else 'ico2ico'           # or ico2ico_vae (factors 0.6 / 0.2 / 0.2)
+p = models.default_params(MODEL, subdivisions=R)
 tr = Trainer(p, torch.device('cuda', 0), seed=0)
 x, t = data.synthetic_batch(B, R, seed=1, device='cuda')
 out = torch.randn(B, 3, 5 * 2 ** R, 2 ** (R + 1), device='cuda').contiguous(memory_format=torch.channels_last)
@@ -32,18 +33,28 @@ crit = tr.criterion
 print('criterion:', type(crit).__name__, 'factors pos/nor/lap =', crit.factor_pos, crit.factor_nor, crit.factor_lap)
 
 
+VAE = MODEL == 'ico2ico_vae'
+mu = torch.randn(B, 512, 20, 8, device='cuda')
+
+
+def arg(o):
+    return (o, mu, mu) if VAE else o
+
+
 def fwd():
     with torch.no_grad():
-        return crit(out, t)
+        return crit(arg(out), t)
 
 
 def fwd_bwd():
     o = out.detach().requires_grad_()
-    crit(o, t).backward()
+    crit(arg(o), t).backward()
 
 
 print('loss forward only      : %7.1f us' % timed(fwd))
 print('loss forward + backward: %7.1f us' % timed(fwd_bwd))
+if VAE:
+    sys.exit(0)
 tr.step(x.contiguous(memory_format=torch.channels_last), t)
 
 
