@@ -46,7 +46,8 @@ SIGNATURES = {
     'icn_head_bwd': (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     'icn_p2p_loss_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),
     'icn_p2p_loss_fwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_float] * 3 + [_c_float_p] * 2 + [ctypes.c_void_p]),
-    'icn_p2p_loss_bwd_pos': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 2 + [ctypes.c_float, _c_float_p, ctypes.c_void_p]),
+    'icn_p2p_loss_bwd_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),
+    'icn_p2p_loss_bwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 2 + [ctypes.c_float] * 3 + [_c_float_p] * 2 + [ctypes.c_void_p]),
     'icn_table_conv_fwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t]),
     'icn_table_conv_bwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t, _intp]),
     'icn_table_upsample': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, _f32p, ctypes.c_size_t, _intp]),

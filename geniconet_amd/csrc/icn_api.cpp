@@ -624,12 +624,19 @@ int icn_p2p_loss_fwd(const float* grid, const float* target, int B, int r, float
     }
 }
 
-int icn_p2p_loss_bwd_pos(const float* grid, const float* target, const float* upstream, int B, int r, float f_pos, float* dgrid,
-                         void* stream) {
+size_t icn_p2p_loss_bwd_workspace_floats(int B, int r) {
+    return (B < 1 || r < 0 || r > 10) ? 0 : (size_t)6 * B * (icn::pixels(r) + 2);
+}
+
+int icn_p2p_loss_bwd(const float* grid, const float* target, const float* upstream, int B, int r, float f_pos, float f_nor,
+                     float f_lap, float* dgrid, float* ws, void* stream) {
     try {
-        if (!grid || !target || !upstream || !dgrid) throw std::invalid_argument("icn_p2p_loss_bwd_pos: null pointer");
-        if (B < 1 || r < 0 || r > 10) throw std::invalid_argument("icn_p2p_loss_bwd_pos: bad B / subdivisions");
-        icn::launch_p2p_loss_bwd_pos(grid, target, upstream, f_pos, dgrid, B, icn::pixels(r), 1 << r, static_cast<hipStream_t>(stream));
+        if (!grid || !target || !upstream || !dgrid) throw std::invalid_argument("icn_p2p_loss_bwd: null pointer");
+        if (B < 1 || r < 0 || r > 10) throw std::invalid_argument("icn_p2p_loss_bwd: bad B / subdivisions");
+        if ((size_t)B * (icn::pixels(r) + 2) >= (size_t)1 << 31) throw std::invalid_argument("icn_p2p_loss_bwd: B * vertices exceeds int32");
+        if ((f_nor != 0.f || f_lap != 0.f) && !ws) throw std::invalid_argument("icn_p2p_loss_bwd: workspace needed for the mesh terms");
+        icn::launch_p2p_loss_bwd(grid, target, vertex_faces(r), upstream, f_pos, f_nor, f_lap, dgrid, ws, B, icn::pixels(r), 1 << r,
+                                 static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());
         return 0;
     } catch (const std::exception& e) {

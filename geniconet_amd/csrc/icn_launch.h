@@ -104,6 +104,9 @@ void launch_p2p_loss_fwd(const float* grid, const float* target, const int32_t* 
                          float f_pos, float f_nor, float f_lap, hipStream_t s);
 void launch_p2p_loss_bwd_pos(const float* grid, const float* target, const float* upstream, float f_pos, float* dgrid, int B, int P,
                              int n, hipStream_t s);
+// all three terms (aux = 6 * B * (P + 2) floats; unused, may be null, when f_nor = f_lap = 0)
+void launch_p2p_loss_bwd(const float* grid, const float* target, const int32_t* vf, const float* upstream, float f_pos, float f_nor,
+                         float f_lap, float* dgrid, float* aux, int B, int P, int n, hipStream_t s);
 
 // ---- optional per-launch HIP-event timing of the MFMA kernels (bench.py's live roofline measurement) ----------
 enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA_64x64, PROF_GG_128x128, PROF_GG_128x64,

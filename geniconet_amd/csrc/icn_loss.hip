@@ -7,6 +7,16 @@
 //   terms[2] = mean_{b,i,c} (lap(v) - t_lap)^2      terms[3] = f_pos * terms[0] + f_nor * terms[1] + f_lap * terms[2]
 // target is (B, 9, V): rows 0:3 positions, 3:6 normals, 6:9 Laplacians (data.py:64-69).
 // Sums are two-level with fixed block size and a fixed tree (deterministic).
+//
+// Backward (d terms[3] / d grid), all in gather form over the incident-face table, so no atomics and no write conflicts
+// (derivation and finite-difference check: oracle/loss_ref.py p2p_grad):
+//   position : 2 f_pos (v - t_pos) / (3 B V)
+//   Laplacian: e_i = lap_i - t_lap,i, k_i = valence:  2 f_lap (sum_{i in ring(j)} e_i / k_i - e_j) / (3 B V)      (ring symmetric)
+//   normal   : w_i = sum of the face normals at i, u = w / |w|, c = u . t^ (t^ = t_nor / |t_nor|);
+//              h_i = d(1 - c_i) / d w_i = -(t^ - (u . t^) u) / |w_i|;  face (j, p, q): d/d v_j = (h_j + h_p + h_q) x (v_q - v_p);
+//              times f_nor / (B V).   Where a normalisation clamp is active (|w| <= 1e-10, |t_nor| <= 1e-8) h_i = 0.
+//   vertex -> grid: pixels directly; a pole is the mean of its 5 corner pixels, each gets a fifth of the pole's gradient.
+// k_p2p_bwd_prep stores e_i / k_i and h_i per vertex (6 floats), k_p2p_bwd gathers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -160,6 +170,96 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_bwd_pos(const float* __restr
     o[2] = w * d.z;
 }
 
+// per vertex: aux[0:3] = (lap - t_lap) / k,  aux[3:6] = h = d(1 - cos) / d w  (see the header comment)
+__global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_bwd_prep(const float* __restrict__ g, const float* __restrict__ target,
+                                                              const int32_t* __restrict__ vf, float* __restrict__ aux, int B, int P,
+                                                              int n) {
+    const int V = P + 2;
+    const long idx = (long)blockIdx.x * LOSS_BLOCK + threadIdx.x;
+    if (idx >= (long)B * V) return;
+    const int b = (int)(idx / V), i = (int)(idx % V);
+    const f3 v = vertex(g, b, i, P, n);
+    const float* t = target + (size_t)b * 9 * V + i;
+    const f3 tn = {t[(size_t)3 * V], t[(size_t)4 * V], t[(size_t)5 * V]};
+    const f3 tl = {t[(size_t)6 * V], t[(size_t)7 * V], t[(size_t)8 * V]};
+    f3 w = {0.f, 0.f, 0.f}, ring = {0.f, 0.f, 0.f};
+    int k = 0;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const int p = vf[((size_t)i * 6 + f) * 2], q = vf[((size_t)i * 6 + f) * 2 + 1];
+        if (p < 0) continue;
+        const f3 vp = vertex(g, b, p, P, n), vq = vertex(g, b, q, P, n);
+        w = w + cross(vp - v, vq - v);
+        ring = ring + vp;
+        ++k;
+    }
+    const float inv = 1.f / (float)k;
+    const f3 e = f3{ring.x * inv, ring.y * inv, ring.z * inv} - v - tl;
+    f3 h = {0.f, 0.f, 0.f};
+    const float wl = sqrtf(dot(w, w)), tl2 = sqrtf(dot(tn, tn));
+    if (wl > 1e-10f && tl2 > 1e-8f) {
+        const f3 u = {w.x / wl, w.y / wl, w.z / wl}, th = {tn.x / tl2, tn.y / tl2, tn.z / tl2};
+        const float c = dot(u, th);
+        h = {-(th.x - c * u.x) / wl, -(th.y - c * u.y) / wl, -(th.z - c * u.z) / wl};
+    }
+    float* a = aux + (size_t)idx * 6;
+    a[0] = e.x * inv; a[1] = e.y * inv; a[2] = e.z * inv;
+    a[3] = h.x; a[4] = h.y; a[5] = h.z;
+}
+
+__device__ __forceinline__ f3 aux3(const float* __restrict__ aux, int b, int x, int V, int off) {
+    const float* a = aux + ((size_t)b * V + x) * 6 + off;
+    return {a[0], a[1], a[2]};
+}
+
+// gradient of the weighted loss with respect to vertex x of sample b (cp, cl, cn: the three terms' constant factors)
+__device__ __forceinline__ f3 vertex_grad(const float* __restrict__ g, const float* __restrict__ target,
+                                          const int32_t* __restrict__ vf, const float* __restrict__ aux, int b, int x, int P, int n,
+                                          float cp, float cl, float cn) {
+    const int V = P + 2;
+    const f3 v = vertex(g, b, x, P, n);
+    const float* t = target + (size_t)b * 9 * V + x;
+    f3 d = {cp * (v.x - t[0]), cp * (v.y - t[(size_t)V]), cp * (v.z - t[(size_t)2 * V])};
+    const f3 ex = aux3(aux, b, x, V, 0), hx = aux3(aux, b, x, V, 3);
+    f3 gl = {0.f, 0.f, 0.f}, gn = {0.f, 0.f, 0.f};
+    int k = 0;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const int p = vf[((size_t)x * 6 + f) * 2], q = vf[((size_t)x * 6 + f) * 2 + 1];
+        if (p < 0) continue;
+        gl = gl + aux3(aux, b, p, V, 0);
+        const f3 G = hx + aux3(aux, b, p, V, 3) + aux3(aux, b, q, V, 3);
+        gn = gn + cross(G, vertex(g, b, q, P, n) - vertex(g, b, p, P, n));
+        ++k;
+    }
+    const float kf = (float)k;
+    d = d + f3{cl * (gl.x - kf * ex.x), cl * (gl.y - kf * ex.y), cl * (gl.z - kf * ex.z)};
+    return d + f3{cn * gn.x, cn * gn.y, cn * gn.z};
+}
+
+__global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_bwd(const float* __restrict__ g, const float* __restrict__ target,
+                                                         const int32_t* __restrict__ vf, const float* __restrict__ aux,
+                                                         const float* __restrict__ upstream, float cp, float cl, float cn,
+                                                         float* __restrict__ dg, int B, int P, int n) {
+    const long idx = (long)blockIdx.x * LOSS_BLOCK + threadIdx.x;
+    if (idx >= (long)B * P) return;
+    const int b = (int)(idx / P), j = (int)(idx % P);
+    f3 d = vertex_grad(g, target, vf, aux, b, j, P, n, cp, cl, cn);
+    const int chart = 2 * n * n;
+    int pole = -1;
+    if (j % chart == 0) pole = 0;
+    else if ((j + 1) % chart == 0) pole = 1;
+    if (pole >= 0) {
+        const f3 dp = vertex_grad(g, target, vf, aux, b, P + pole, P, n, cp, cl, cn);
+        d = d + f3{dp.x / 5.f, dp.y / 5.f, dp.z / 5.f};
+    }
+    const float up = upstream[0];
+    float* o = dg + ((size_t)b * P + j) * 3;
+    o[0] = up * d.x;
+    o[1] = up * d.y;
+    o[2] = up * d.z;
+}
+
 }  // namespace
 
 int p2p_loss_blocks(int B, int P) { return (int)(((long)B * (P + 2) + LOSS_BLOCK - 1) / LOSS_BLOCK); }
@@ -178,6 +278,17 @@ void launch_p2p_loss_bwd_pos(const float* grid, const float* target, const float
     const float scale = (float)(2.0 * (double)f_pos / ((double)B * (P + 2) * 3.0));
     hipLaunchKernelGGL(k_p2p_bwd_pos, dim3((unsigned)((total + LOSS_BLOCK - 1) / LOSS_BLOCK)), dim3(LOSS_BLOCK), 0, s, grid, target,
                        upstream, scale, dgrid, B, P, n);
+}
+
+void launch_p2p_loss_bwd(const float* grid, const float* target, const int32_t* vf, const float* upstream, float f_pos, float f_nor,
+                         float f_lap, float* dgrid, float* aux, int B, int P, int n, hipStream_t s) {
+    if (f_nor == 0.f && f_lap == 0.f) return launch_p2p_loss_bwd_pos(grid, target, upstream, f_pos, dgrid, B, P, n, s);
+    const double nv = (double)B * (P + 2);
+    const long tv = (long)B * (P + 2), tp = (long)B * P;
+    hipLaunchKernelGGL(k_p2p_bwd_prep, dim3((unsigned)((tv + LOSS_BLOCK - 1) / LOSS_BLOCK)), dim3(LOSS_BLOCK), 0, s, grid, target, vf, aux,
+                       B, P, n);
+    hipLaunchKernelGGL(k_p2p_bwd, dim3((unsigned)((tp + LOSS_BLOCK - 1) / LOSS_BLOCK)), dim3(LOSS_BLOCK), 0, s, grid, target, vf, aux,
+                       upstream, (float)(2.0 * f_pos / (3.0 * nv)), (float)(2.0 * f_lap / (3.0 * nv)), (float)(f_nor / nv), dgrid, B, P, n);
 }
 
 }  // namespace icn

@@ -8,10 +8,9 @@ imports from the absent `PythonFunctions/mesh/utils.py` (losses.py:7) are restat
 Loss values are kept as device tensors; `.item()` (a host sync in the reference on every iteration,
 losses.py:72,81,129) only happens when get_last_losses() is called.
 
-On ROCm fp32 tensors Point2Point_Loss runs as two HIP kernels (libicn's icn_p2p_loss_*) whenever only the position term
-needs a gradient -- the auto-encoder's training configuration, factors 1/0/0 (run.py:690-692) -- or none is needed.  The
-torch formulation below is what runs otherwise: the VAE's 0.6/0.2/0.2 (run.py:694-696) needs gradients through the normal
-and Laplacian terms; other dtypes; CPU tensors as used by the CPU restatement in bench.py.
+On ROCm fp32 tensors Point2Point_Loss runs on HIP kernels (libicn's icn_p2p_loss_*), forward and backward, for any
+factors; the torch formulation below is what runs for other dtypes and for CPU tensors (as used by the CPU restatement in
+bench.py), and it is what the HIP kernels are tested against besides the numpy oracle.  The KLD term stays on torch ops.
 """
 import os
 
@@ -23,9 +22,9 @@ _NO_HIP_LOSS = os.environ.get('ICN_NO_HIP_LOSS', '') == '1'
 
 
 class _P2PLossFn(torch.autograd.Function):
-    """Point2Point_Loss on the HIP path (icn_p2p_loss_* in include/icn.h): one kernel evaluates the three terms, one more
-    the gradient of the position term.  Only used when no other term needs a gradient (factor_nor = factor_lap = 0, the
-    auto-encoder's configuration, run.py:690-692) or when no gradient is needed at all."""
+    """Point2Point_Loss on the HIP path (icn_p2p_loss_* in include/icn.h): one kernel evaluates the three terms; the
+    gradient is one kernel for the auto-encoder's factors 1/0/0 (run.py:690-692) and two for factors that weigh the normal
+    and Laplacian terms (the VAE's 0.6/0.2/0.2, run.py:694-696)."""
 
     @staticmethod
     def forward(ctx, inputs, target, r, f_pos, f_nor, f_lap):
@@ -49,16 +48,17 @@ class _P2PLossFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gtotal, _gterms):
         B, r, f_pos, f_nor, f_lap = ctx.cfg
-        if f_nor != 0 or f_lap != 0:
-            raise RuntimeError('_P2PLossFn: the HIP backward covers the position term only')
         L = _lib.lib()
         grid, tgt = ctx.saved_tensors
         dgrid = torch.empty_like(grid)
         up = gtotal.contiguous().to(torch.float32)
+        ws = None
+        if f_nor != 0 or f_lap != 0:
+            ws = torch.empty(L.icn_p2p_loss_bwd_workspace_floats(B, r), dtype=torch.float32, device=grid.device)
         with torch.cuda.device(grid.device):
-            rc = L.icn_p2p_loss_bwd_pos(grid.data_ptr(), tgt.data_ptr(), up.data_ptr(), B, r, f_pos, dgrid.data_ptr(),
-                                        torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, 'icn_p2p_loss_bwd_pos')
+            rc = L.icn_p2p_loss_bwd(grid.data_ptr(), tgt.data_ptr(), up.data_ptr(), B, r, f_pos, f_nor, f_lap, dgrid.data_ptr(),
+                                    ws.data_ptr() if ws is not None else None, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, 'icn_p2p_loss_bwd')
         return dgrid.permute(0, 3, 1, 2), None, None, None, None, None
 
 
@@ -106,8 +106,7 @@ class Point2Point_Loss(torch.nn.Module):
         self.last_loss_mse = self.last_loss_cos = self.last_loss_lap = self.last_loss_total = 0
 
     def _hip_path(self, inputs, target):
-        """HIP kernels when they cover what is asked: ROCm fp32 tensors of the expected shapes, and no gradient needed
-        through the normal / Laplacian terms (their factors are 0, or nothing requires grad)."""
+        """HIP kernels for ROCm fp32 tensors of the expected shapes."""
         if _NO_HIP_LOSS or not (inputs.is_cuda and target.is_cuda) or inputs.dtype != torch.float32 or target.dtype != torch.float32:
             return False
         n = 2 ** self.subdivisions
@@ -115,8 +114,7 @@ class Point2Point_Loss(torch.nn.Module):
             return False
         if tuple(target.shape) != (inputs.shape[0], 9, 10 * n * n + 2):
             return False
-        needs_grad = torch.is_grad_enabled() and inputs.requires_grad
-        return not needs_grad or (self.factor_nor == 0 and self.factor_lap == 0)
+        return True
 
     def forward(self, inputs, target):
         if self._hip_path(inputs, target):

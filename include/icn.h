@@ -119,16 +119,18 @@ int icn_head_bwd(const float* dy, const float* y, const float* x, const float* w
  *                      (ico_utils.py:10-24, losses.py:47-51)
  *   target (B, 9, V)   V = P + 2: rows 0:3 positions, 3:6 normals, 6:9 Laplacians (data.py:64-69)
  *   terms  [4]         mse(v, pos) | mean(1 - cos(normal(v), nor)) | mse(lap(v), lap) | f_pos*[0] + f_nor*[1] + f_lap*[2]
- * All three terms are always evaluated (the reference reports them every iteration, losses.py:72-81).  The backward entry
- * point covers the position term only: that is the auto-encoder's training configuration (factors 1 / 0 / 0, run.py:690-692).
- * The VAE trains with 0.6 / 0.2 / 0.2 (run.py:694-696), which needs gradients through the normal and Laplacian terms; those
- * are not provided here and the caller differentiates its own formulation.  upstream: device scalar dLoss/dterms[3].
- * ws: icn_p2p_loss_workspace_floats(B, r) floats.  Deterministic (fixed two-level sums). */
+ * All three terms are always evaluated (the reference reports them every iteration, losses.py:72-81).
+ * icn_p2p_loss_bwd: dgrid (B, P, 3) = upstream * d terms[3] / d grid for any factors -- the auto-encoder's 1 / 0 / 0
+ * (run.py:690-692; one kernel, ws may be null) as well as the VAE's 0.6 / 0.2 / 0.2 (run.py:694-696; two kernels, gather form,
+ * no atomics).  Where a normalisation clamp of the normal term is active (|vertex normal| <= 1e-10 or |target normal| <= 1e-8)
+ * that vertex contributes no normal-term gradient.  upstream: device scalar dLoss/dterms[3].
+ * ws: icn_p2p_loss_workspace_floats / icn_p2p_loss_bwd_workspace_floats (B, r) floats.  Deterministic (fixed two-level sums). */
 size_t icn_p2p_loss_workspace_floats(int B, int r);
 int icn_p2p_loss_fwd(const float* grid, const float* target, int B, int r, float f_pos, float f_nor, float f_lap, float* terms,
                      float* ws, void* stream);
-int icn_p2p_loss_bwd_pos(const float* grid, const float* target, const float* upstream, int B, int r, float f_pos, float* dgrid,
-                         void* stream);
+size_t icn_p2p_loss_bwd_workspace_floats(int B, int r);
+int icn_p2p_loss_bwd(const float* grid, const float* target, const float* upstream, int B, int r, float f_pos, float f_nor,
+                     float f_lap, float* dgrid, float* ws, void* stream);
 
 /* Host-side introspection (no device needed).  Each writes at most `cap` elements and returns the element
  * count required (negative on error). */

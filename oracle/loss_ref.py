@@ -70,6 +70,57 @@ def p2p_pos_grad(pred, target, r):
     return g
 
 
+def p2p_grad(pred, target, r, f_pos, f_nor, f_lap):
+    """d p2p_loss / d pred, (B,3,5n,2n), analytic (float64; checked against finite differences of p2p_loss in
+    tests/test_oracle_properties.py).  Generic inputs only: the eps clamps of the normalisations are assumed inactive.
+      position : 2 (v - a) / (3 B N)
+      Laplacian: with e_i = lap_i - l_i and k_i the valence, 2 (sum_{i in ring(j)} e_i / k_i - e_j) / (3 B N)
+      normal   : w_i = sum of the normals n_f of the faces at i, u = w / |w|, c = u . t / |t|;
+                 h_i = d(1 - c_i) / d w_i = -(t^ - (u . t^) u) / |w_i|;  a face (a, b, c) with n = (b - a) x (c - a) passes
+                 G = h_a + h_b + h_c back as  d/da = G x (c - b),  d/db = G x (a - c),  d/dc = G x (b - a);  all / (B N)
+    then vertex -> grid: pixels directly, each pole a fifth to each of its 5 corner pixels (losses.py:23-31,49-51)."""
+    pred, target = np.asarray(pred, np.float64), np.asarray(target, np.float64)
+    f = faces_from_lattice(r)
+    n = 2 ** r
+    B = pred.shape[0]
+    v = grid_to_vertices(pred, r)
+    t = target.transpose(0, 2, 1)
+    N = v.shape[1]
+    dv = f_pos * 2.0 * (v - t[:, :, :3]) / (3.0 * B * N)
+    ring = [set() for _ in range(N)]
+    for a, b, c in f:
+        ring[a].update((b, c)); ring[b].update((a, c)); ring[c].update((a, b))
+    for bi in range(B):
+        e = laplacian(v[bi], f) - t[bi, :, 6:9]
+        k = np.array([len(s_) for s_ in ring], np.float64)
+        ek = e / k[:, None]
+        gl = -e.copy()
+        for j in range(N):
+            for i in ring[j]:
+                gl[j] += ek[i]
+        dv[bi] += f_lap * 2.0 * gl / (3.0 * B * N)
+        fn = np.cross(v[bi][f[:, 1]] - v[bi][f[:, 0]], v[bi][f[:, 2]] - v[bi][f[:, 0]], axis=1)
+        w = np.zeros_like(v[bi])
+        for kk in range(3):
+            np.add.at(w, f[:, kk], fn)
+        wl = np.linalg.norm(w, axis=1, keepdims=True)
+        u = w / wl
+        th = t[bi, :, 3:6] / np.linalg.norm(t[bi, :, 3:6], axis=1, keepdims=True)
+        h = -(th - (u * th).sum(1, keepdims=True) * u) / wl
+        G = h[f[:, 0]] + h[f[:, 1]] + h[f[:, 2]]
+        va, vb, vc = v[bi][f[:, 0]], v[bi][f[:, 1]], v[bi][f[:, 2]]
+        gn = np.zeros_like(v[bi])
+        np.add.at(gn, f[:, 0], np.cross(G, vc - vb))
+        np.add.at(gn, f[:, 1], np.cross(G, va - vc))
+        np.add.at(gn, f[:, 2], np.cross(G, vb - va))
+        dv[bi] += f_nor * gn / (B * N)
+    g = dv[:, :-2].transpose(0, 2, 1).reshape(B, 3, 5 * n, 2 * n).copy()
+    for c in range(5):
+        g[:, :, c * n, 0] += dv[:, -2] / 5.0
+        g[:, :, (c + 1) * n - 1, 2 * n - 1] += dv[:, -1] / 5.0
+    return g
+
+
 def p2p_loss(pred, target, r, f_pos, f_nor, f_lap):
     a, b, c = p2p_terms(pred, target, r)
     return f_pos * a + f_nor * b + f_lap * c

@@ -119,3 +119,25 @@ def test_tap_order_matches_lattice_offsets_in_chart_interior():
                 p = (c * n + i) * 2 * n + j
                 for t, (da, db) in enumerate(ico_ref.TAPS):
                     assert tt[t, p] == (c * n + i + da) * 2 * n + j + db
+
+
+def test_loss_gradient_oracle_is_pinned_by_finite_differences():
+    """oracle/loss_ref.p2p_grad (analytic; the checker of the HIP loss backward) against central differences of
+    p2p_loss, VAE factors (reference run.py:694-696), r = 1: 42 vertices, ten of them pole corners."""
+    import numpy as np
+    from oracle import loss_ref
+    rng = np.random.default_rng(4)
+    r, B, fac = 1, 1, (0.6, 0.2, 0.2)
+    n = 2 ** r
+    pred = rng.standard_normal((B, 3, 5 * n, 2 * n))
+    tgt = rng.standard_normal((B, 9, 10 * n * n + 2))
+    g = loss_ref.p2p_grad(pred, tgt, r, *fac)
+    num = np.zeros_like(pred)
+    eps = 1e-6
+    for idx in np.ndindex(pred.shape):
+        p, q = pred.copy(), pred.copy()
+        p[idx] += eps
+        q[idx] -= eps
+        num[idx] = (loss_ref.p2p_loss(p, tgt, r, *fac) - loss_ref.p2p_loss(q, tgt, r, *fac)) / (2 * eps)
+    assert np.linalg.norm(g - num) <= 1e-6 * np.linalg.norm(num)
+    assert np.allclose(loss_ref.p2p_grad(pred, tgt, r, 1.0, 0.0, 0.0), loss_ref.p2p_pos_grad(pred, tgt, r), rtol=1e-12, atol=0)
