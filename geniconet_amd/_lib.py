@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libicn.so')
 
 OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT = 0, 1, 2
 CORNER_MODES = {'zeros': 0, 'average': 1}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses
 _i32p = ctypes.POINTER(ctypes.c_int32)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ICN_ABI_VERSION 1
+#define ICN_ABI_VERSION 2
 
 #define ICN_CORNER_ZEROS 0
 #define ICN_CORNER_AVERAGE 1
