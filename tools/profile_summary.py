@@ -14,11 +14,23 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    return name.split('(')[0].replace('void ', '')[:70]
+    return name.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')[:70]
+
+
+def newest_run(directory, suffix):
+    """Files `<pid>_<suffix>` of the most recent rocprofv3 run under `directory`.  gpurun merges a box's output INTO the
+    local gpurun_out/ and never removes anything, so a directory that was profiled twice holds both runs side by side;
+    summarising across them would mix measurements of different code (it did, once)."""
+    files = glob.glob(os.path.join(directory, '**', '*' + suffix), recursive=True)
+    if not files:
+        return []
+    latest = max(files, key=os.path.getmtime)
+    pid = os.path.basename(latest).split('_')[0]
+    return [f for f in files if os.path.basename(f).split('_')[0] == pid and os.path.dirname(f) == os.path.dirname(latest)]
 
 
 # ---- 1. kernel stats of the bench command
-stats = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)
+stats = newest_run(os.path.join(src, 'stats'), 'kernel_stats.csv')
 bench = json.loads(open(os.path.join(src, 'bench_stats.json')).read().strip().splitlines()[-1])
 steps_total = bench['steps'] + bench['warmup']
 rows = list(csv.DictReader(open(stats[0])))
@@ -37,10 +49,10 @@ pmc = collections.defaultdict(dict)
 dur = collections.defaultdict(list)
 for d in sorted(glob.glob(os.path.join(src, 'pmc_*/'))):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(d + '**/*counter_collection.csv', recursive=True):
+    for f in newest_run(d, 'counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
-    for f in glob.glob(d + '**/*kernel_trace.csv', recursive=True):
+    for f in newest_run(d, 'kernel_trace.csv'):
         for r in csv.DictReader(open(f)):
             dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
     for k, cs in agg.items():
@@ -67,4 +79,5 @@ for k, cs in pmc.items():
     out[k] = e
 json.dump(out, open(os.path.join(dst, rnd + '_pmc_per_kernel.json'), 'w'), indent=1, sort_keys=True)
 json.dump(bench, open(os.path.join(dst, rnd + '_bench_under_rocprof.json'), 'w'), indent=1)
+print('stats from', os.path.relpath(stats[0], root))
 print('wrote', sorted(os.listdir(dst)))
