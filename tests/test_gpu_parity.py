@@ -435,3 +435,37 @@ def test_hip_loss_full_size_scaling_property():
     assert abs(b[0] - 4 * a[0]) <= 1e-5 * abs(4 * a[0])
     assert abs(b[1] - a[1]) <= 1e-5 * abs(a[1])
     assert abs(b[2] - 4 * a[2]) <= 1e-5 * abs(4 * a[2])
+
+
+# ---- inference halves (reference models.py:234-252,302-340, run.py:360-367,499-536) ------------------------
+@pytest.mark.parametrize('train_mode_bn', [False, True], ids=['eval', 'bn_train_mode'])
+def test_inference_halves_compose_to_the_full_model(train_mode_bn):
+    """decoder-half(encoder-half(x)) == full model(x), halves restored from the full model by the reference's key filter;
+    also with BatchNorm in training mode, as experiment_test runs it (run.py:516)."""
+    from geniconet_amd import models
+
+    def restore(half, saved):
+        md = half.state_dict()
+        half.load_state_dict({k: v for k, v in saved.items() if k in md})
+        return half.cuda().train(train_mode_bn)
+
+    R, B = 3, 2
+    n = 2 ** R
+    x = torch.randn(B, 3, 5 * n, 2 * n, generator=torch.Generator().manual_seed(8)).cuda()
+    with torch.no_grad():
+        p = models.default_params('ico2ico', subdivisions=R)
+        torch.manual_seed(0)
+        full = models.ico2ico(p).cuda().train(train_mode_bn)
+        saved = full.state_dict()
+        enc, dec = restore(models.ico2enc(p), saved), restore(models.enc2ico(p), saved)
+        assert rel_l2(dec(enc(x)).cpu().numpy(), full(x).cpu().numpy()) < 1e-6
+
+        p = models.default_params('ico2ico_vae', subdivisions=R)
+        torch.manual_seed(0)
+        full = models.ico2ico_vae(p).cuda().train(train_mode_bn)
+        saved = full.state_dict()
+        enc, dec = restore(models.ico2enc_vae(p), saved), restore(models.enc2ico_vae(p), saved)
+        mu_f, lv_f = full.encode(x)
+        mu_h, lv_h = enc(x)
+        assert rel_l2(mu_h.cpu().numpy(), mu_f.cpu().numpy()) < 1e-6 and rel_l2(lv_h.cpu().numpy(), lv_f.cpu().numpy()) < 1e-6
+        assert rel_l2(dec(mu_h)[0].cpu().numpy(), full.decode(mu_f).cpu().numpy()) < 1e-6

@@ -115,3 +115,29 @@ def test_sample_format_round_trip(tmp_path):
     xi, lbl = data.load_sample(path, r)
     assert np.array_equal(lbl, tgt[0].numpy()) and np.array_equal(xi, x[0].numpy())
     assert list(np.load(path).keys()) == ['data']                          # generate.py:203 / data.py:66
+
+
+def test_inference_halves_load_from_a_full_checkpoint_by_key_filter():
+    """the encoder / decoder halves (reference models.py:234-252,302-340) are restored from a checkpoint of
+    the full model exactly as the reference does it, run.py:360-367: keep the saved keys the half has, then a STRICT
+    load_state_dict -- so every key of a half must exist in the full model under the same name."""
+    import torch
+    from geniconet_amd import models
+    for name, enc_cls, dec_cls in (('ico2ico', models.ico2enc, models.enc2ico),
+                                   ('ico2ico_vae', models.ico2enc_vae, models.enc2ico_vae)):
+        p = models.default_params(name, subdivisions=3)               # the VAE's latent head strides down from level R - 2
+        torch.manual_seed(1)
+        full = getattr(models, name)(p)
+        saved = {k: v.clone() for k, v in full.state_dict().items()}
+        covered = set()
+        for cls in (enc_cls, dec_cls):
+            torch.manual_seed(2)                                       # different initial weights than the checkpoint
+            half = cls(p)
+            model_dict = half.state_dict()
+            filtered = {k: v for k, v in saved.items() if k in model_dict}
+            assert set(filtered) == set(model_dict), (name, cls.__name__, sorted(set(model_dict) - set(filtered))[:5])
+            half.load_state_dict(filtered)                             # strict, like the reference
+            for k, v in half.state_dict().items():
+                assert torch.equal(v, saved[k]), k
+            covered |= set(model_dict)
+        assert covered == set(saved), (name, sorted(set(saved) - covered)[:5])   # nothing of the checkpoint is orphaned
