@@ -11,6 +11,9 @@ averaged by bucketed all-reduce over RCCL overlapped with backward (torch Distri
 initial weights by broadcast from rank 0, optimiser/scheduler replicated.
 """
 import contextlib
+import glob
+import os
+import re
 
 import torch
 import torch.distributed as dist
@@ -85,3 +88,53 @@ class Trainer:
             return self.criterion(self.model(img), lbl)
         finally:
             self.model.train(was_training)
+
+
+# ---- checkpoints in the reference's format (run.py:317-372) ---------------------------------------------------------------
+def _natural_key(path):
+    """natsort-like ordering (the reference sorts its 'EB<epoch>' files with natsort, run.py:322,346)."""
+    return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.basename(path))]
+
+
+def checkpoint_path(log_dir, model_name, epoch):
+    """<logDir>/savedModel/<modelName>_E<epoch>.pt; `epoch` is an int or the reference's 'B<int>' for a best model
+    (run.py:327,331)."""
+    return os.path.join(log_dir, 'savedModel', '%s_E%s.pt' % (model_name, epoch))
+
+
+def save_checkpoint(trainer, log_dir, epoch, val_loss=None, misc=None, model_name=None):
+    """Write the dict the reference's saveModel writes (run.py:330-340): model_state_dict, optimizer_state_dict, epoch
+    (the integer part of 'B<int>', ico_utils.py:67-71), loss, misc.  Like the reference it never overwrites: returns the
+    path, or None when the file already exists.  Rank 0 only under DDP; the state dict is the bare model's (no 'module.'
+    prefix)."""
+    if trainer.world > 1 and dist.get_rank() != 0:
+        return None
+    name = model_name or trainer.params['model_name']
+    path = checkpoint_path(log_dir, name, epoch)
+    if os.path.exists(path):
+        return None
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({'model_state_dict': trainer.model.state_dict(), 'optimizer_state_dict': trainer.optimizer.state_dict(),
+                'epoch': epoch if isinstance(epoch, int) else int(str(epoch)[1:]), 'loss': val_loss, 'misc': misc}, path)
+    return path
+
+
+def load_checkpoint(model, log_dir, model_name, epoch=0, optimizer=None):
+    """The reference's loadModel (run.py:342-372): epoch 0 = the newest '<name>_EB<int>.pt' best model, else
+    '<name>_E<epoch>.pt'; tensors are mapped to the CPU first; only the saved keys the model has are kept and then loaded
+    STRICTLY (so an encoder / decoder half restores from a full model's file); the optimizer state is restored when an
+    optimizer is given.  Returns the checkpoint dict (epoch, loss, misc ...) or None when no file exists."""
+    if epoch == 0:
+        paths = sorted(glob.glob(os.path.join(log_dir, 'savedModel', model_name + '_EB*[0-9]*.pt')), key=_natural_key)
+        path = paths[-1] if paths else checkpoint_path(log_dir, model_name, epoch)
+    else:
+        path = checkpoint_path(log_dir, model_name, epoch)
+    if not os.path.exists(path):
+        return None
+    ckpt = torch.load(path, map_location='cpu', weights_only=False)
+    have = model.state_dict()
+    model.load_state_dict({k: v for k, v in ckpt['model_state_dict'].items() if k in have})
+    if optimizer is not None:
+        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+    return ckpt
+

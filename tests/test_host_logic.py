@@ -141,3 +141,49 @@ def test_inference_halves_load_from_a_full_checkpoint_by_key_filter():
                 assert torch.equal(v, saved[k]), k
             covered |= set(model_dict)
         assert covered == set(saved), (name, sorted(set(saved) - covered)[:5])   # nothing of the checkpoint is orphaned
+
+
+def test_checkpoints_use_the_reference_format_and_resume_exactly(tmp_path):
+    """run.py:317-372: {'model_state_dict', 'optimizer_state_dict', 'epoch', 'loss', 'misc'} at
+    <logDir>/savedModel/<name>_E<epoch>.pt, best models as 'EB<int>', never overwritten, key-filtered strict load.
+    Resuming (model + Adam state) continues bit-identically; run on the CPU restatement of the network."""
+    import copy
+    import torch
+    from geniconet_amd import data, models, train
+    from oracle import models_ref
+    p = models.default_params('ico2ico', subdivisions=3)        # three stride-2 blocks: R >= 3
+    for k in ('lr_base', 'lr_max'):                     # the reference does not checkpoint its scheduler; leave it out here
+        p['ico2ico'].pop(k, None)
+
+    def trainer(seed):
+        torch.manual_seed(seed)
+        net = models_ref.ico2ico(R=3).train()
+        return train.Trainer(p, 'cpu', model=net, criterion=train.build_criterion(p, 'cpu'), channels_last=False)
+
+    x, t = data.synthetic_batch(2, 3, seed=5)
+    a = trainer(0)
+    a.step(x, t)
+    a.step(x, t)
+    path = train.save_checkpoint(a, str(tmp_path), 'B3', val_loss=0.25, misc={'note': 1})
+    assert path == str(tmp_path / 'savedModel' / 'ico2ico_EB3.pt')
+    assert train.save_checkpoint(a, str(tmp_path), 'B3') is None                    # never overwrites (run.py:335-340)
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    assert sorted(ck) == ['epoch', 'loss', 'misc', 'model_state_dict', 'optimizer_state_dict']
+    assert ck['epoch'] == 3 and ck['loss'] == 0.25 and ck['misc'] == {'note': 1}
+    train.save_checkpoint(a, str(tmp_path), 'B12')
+    train.save_checkpoint(a, str(tmp_path), 7)                                      # a plain epoch file is not a "best"
+    a.step(x, t)
+    want = copy.deepcopy(a.model.state_dict())
+
+    b = trainer(99)                                                                 # different weights, fresh Adam
+    got = train.load_checkpoint(b.model, str(tmp_path), 'ico2ico', epoch=3, optimizer=None)
+    assert got is None                                                              # 'E3' does not exist, only 'EB3'
+    got = train.load_checkpoint(b.model, str(tmp_path), 'ico2ico', epoch=0, optimizer=b.optimizer)
+    assert got['epoch'] == 12                                                       # newest best, natural order: B12 > B3
+    b.step(x, t)
+    for k, v in b.model.state_dict().items():
+        assert torch.equal(v, want[k]), k
+
+    half = models.ico2enc(p)                                                        # product encoder half, same keys
+    assert train.load_checkpoint(half, str(tmp_path), 'ico2ico', epoch='B3') is not None
+    assert torch.equal(half.state_dict()['encoder.0.weight'], ck['model_state_dict']['encoder.0.weight'])
