@@ -229,6 +229,17 @@ def _latent_head(corner_mode, subdivisions):
                          nn.BatchNorm2d(VAE_LATENT_CHANNELS))
 
 
+def _latent_heads(mu, logvar, h):
+    """(mu(h), logvar(h)): the two latent heads are `Sequential(IcoConvS2S, BatchNorm2d)` over the same tensor (reference
+    models.py:288-292), so their convolutions run as a pair (one launch per pass) when nobody hooked the pieces."""
+    plain = all(isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[0], IcoConvS2S)
+                and not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks) for m in (mu, logvar))
+    if not plain:
+        return mu(h), logvar(h)
+    a, b = fused.conv_pair(h, mu[0], logvar[0])
+    return mu[1](a), logvar[1](b)
+
+
 class ico2ico_vae(VAE):
     """Variational autoencoder   -- reference models.py:254-300."""
 
@@ -253,8 +264,8 @@ class ico2ico_vae(VAE):
         return _latent_head(self.params['ico']['corner_mode'], _levels(self.params))
 
     def encode(self, input):
-        h = self.encoder(input)
-        return self.mu_hook(self.mu(h)), self.logvar_hook(self.logvar(h))
+        m, lv = _latent_heads(self.mu, self.logvar, self.encoder(input))
+        return self.mu_hook(m), self.logvar_hook(lv)
 
     def decode(self, z):
         return fused.head(self.decoder(self.reparameterize_hook(z)), self.final_layer)
@@ -272,8 +283,7 @@ class ico2enc_vae(VAE):
         self.logvar = ico2ico_vae.createLogvar(self)
 
     def encode(self, input):
-        h = self.encoder(input)
-        return self.mu(h), self.logvar(h)
+        return _latent_heads(self.mu, self.logvar, self.encoder(input))
 
     def forward(self, x):
         return self.encode(x)
