@@ -141,7 +141,7 @@ class _HeadFn(torch.autograd.Function):
             _lib.check(L.icn_head_fwd(xp.data_ptr(), w2.data_ptr(), bias.contiguous().data_ptr(), y.data_ptr(), M, Cin, Cout,
                                       _stream()), 'icn_head_fwd')
         ctx.save_for_backward(xp, w2, y)
-        ctx.wshape = weight.shape
+        ctx.wshape, ctx.wstride = weight.shape, weight.stride()
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -161,7 +161,9 @@ class _HeadFn(torch.autograd.Function):
             _lib.check(L.icn_head_bwd(gyp.data_ptr(), y.data_ptr(), xp.data_ptr(), w2.data_ptr(),
                                       dx.data_ptr() if dx is not None else None, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), M,
                                       Cin, Cout, _stream()), 'icn_head_bwd')
-        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dw.reshape(ctx.wshape), db
+        # the gradient in the parameter's own layout (a channels_last (Cout, Cin, 1, 1) weight has strides (Cin, 1, Cin, Cin)):
+        # DistributedDataParallel with gradient_as_bucket_view can then alias it instead of warning and copying
+        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dw.as_strided(ctx.wshape, ctx.wstride), db
 
 
 def can_fuse_head(x, seq):

@@ -73,3 +73,20 @@ def test_two_rank_gradients_equal_single_process_full_batch(tmp_path):
     for k in a['w_end']:
         assert torch.equal(a['w_end'][k], b['w_end'][k]), k
     assert all(abs(x) < 1e9 for x in a['losses'])
+
+
+@pytest.mark.timeout(600)
+def test_four_ranks_agree_and_finish(tmp_path):
+    """world_size 4 (the scaling runs go to 8): same wiring; every rank ends with identical weights and the gradients on
+    all ranks equal rank 0's.  Guards against collectives that only line up for two ranks."""
+    world = 4
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(str(tmp_path / ('rank%d.pt' % r))) for r in range(world)]
+    for o in outs[1:]:
+        for k in outs[0]['w0']:
+            assert torch.equal(outs[0]['w0'][k], o['w0'][k]), k
+        for k in outs[0]['grads']:
+            assert torch.equal(outs[0]['grads'][k], o['grads'][k]), k
+        for k in outs[0]['w_end']:
+            assert torch.equal(outs[0]['w_end'][k], o['w_end'][k]), k
+
