@@ -1425,17 +1425,33 @@ __global__ void k_spmm_ell(const float* __restrict__ in, float* __restrict__ out
         float accv[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) accv[v] = 0.f;
-        for (int e = 0; e < W; ++e) {
-            const int32_t j = idx[(size_t)r * W + e];
-            if (j < 0) break;   // rows are left-packed
-            const float w = coef[(size_t)r * W + e];
-            const float* p = in + ((size_t)b * Pin + j) * C + c;
-            if (VEC == 4) {
-                const f32x4 x = ld4(p);
+        // Entries in groups of six: first all indices and coefficients, then all row loads, then the sums -- three
+        // levels of independent loads instead of a chain of W dependent ones.  Absent entries (rows are left-packed,
+        // -1 padded) add +0, in the same order as before, so results are unchanged.
+        for (int e0 = 0; e0 < W; e0 += 6) {
+            int32_t j[6];
+            float w[6];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) accv[v] += w * x[v];
+            for (int k = 0; k < 6; ++k) {
+                const bool in_row = e0 + k < W;
+                j[k] = in_row ? idx[(size_t)r * W + e0 + k] : -1;
+                w[k] = in_row ? coef[(size_t)r * W + e0 + k] : 0.f;
+            }
+            if (VEC == 4) {
+                f32x4 x[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    x[k] = j[k] >= 0 ? ld4(in + ((size_t)b * Pin + j[k]) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (j[k] >= 0) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) accv[v] += w[k] * x[k][v];
+                    }
             } else {
-                accv[0] += w * p[0];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (j[k] >= 0) accv[0] += w[k] * in[((size_t)b * Pin + j[k]) * C + c];
             }
         }
         float* o = out + br * C + c;
