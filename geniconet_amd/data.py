@@ -7,6 +7,9 @@ vertex order with the two poles last.  Network input = data[:3, :-2].reshape(3, 
 Synthetic meshes (there is no dataset offline): a smoothly perturbed icosphere
 v = u * (1 + 0.25 * sum_k a_k sin(w_k . u + p_k)), clipped to (-0.95, 0.95) so it lies inside tanh's range.
 """
+import os
+import re
+
 import numpy as np
 import torch
 
@@ -51,3 +54,55 @@ def synthetic_batch(batch, subdivisions, seed, device='cpu'):
     lap = losses.compute_laplacian_batch(v, nbr.clamp_min(0), nbr_w)
     target = torch.cat((v, normals, lap), dim=2).transpose(1, 2).contiguous()              # (B, 9, N)
     return target_to_input(target, subdivisions).contiguous(), target
+
+
+def _natural_key(name):
+    """Order of natsort.natsorted, which the reference lists its files with (data.py:18)."""
+    return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', name)]
+
+
+def list_samples(directory, ext='.npz'):
+    """Files of one data directory in the reference's order (data.py:7-21, dataPthLvl 1)."""
+    return [os.path.join(directory, f) for f in sorted(os.listdir(directory), key=_natural_key) if f.endswith(ext)]
+
+
+class IcoDataset:
+    """Every sample of a directory resident on the device as ONE (N, 9, V) tensor.
+
+    The reference preloads its `.npz` files into host RAM (data.py:72-80, loadIcoFile :64-69) and feeds batches through a
+    DataLoader with 2 x cpu_count workers and a host-to-device copy per step (run.py:52,70-75,241-242,714).  An MI355X holds
+    288 GB: ModelNet10 at I5 is ~2 GB, so the samples are uploaded once and a batch is an index_select on the device -- no
+    workers, no per-step copies.  Batching follows the DataLoader the reference builds: `batch_size` samples, optional
+    shuffle per epoch, the last batch may be short (drop_last=False)."""
+
+    def __init__(self, files, subdivisions, device='cpu'):
+        if isinstance(files, str):
+            files = list_samples(files)
+        if not files:
+            raise ValueError('IcoDataset: no samples')
+        self.files, self.subdivisions = list(files), subdivisions
+        self.targets = torch.from_numpy(np.stack([load_sample(f, subdivisions)[1] for f in self.files])).to(device)
+
+    def __len__(self):
+        return self.targets.shape[0]
+
+    def subset(self, indices):
+        """A view-like dataset of the given sample indices (the reference splits with torch.utils.data.Subset, run.py:69-74)."""
+        other = object.__new__(IcoDataset)
+        other.subdivisions = self.subdivisions
+        other.files = [self.files[int(i)] for i in indices]
+        other.targets = self.targets[torch.as_tensor(list(indices), device=self.targets.device, dtype=torch.long)]
+        return other
+
+    def batches(self, batch_size, shuffle=False, generator=None):
+        """Yield (input (B,3,5n,2n), target (B,9,V)) on the dataset's device; `generator` (a CPU torch.Generator) seeds the
+        shuffle.  Inputs are channels_last on a ROCm device (the chart layout of the kernels)."""
+        n = len(self)
+        order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
+        order = order.to(self.targets.device)
+        for lo in range(0, n, batch_size):
+            lbl = self.targets.index_select(0, order[lo:lo + batch_size])
+            img = target_to_input(lbl, self.subdivisions)
+            img = img.contiguous(memory_format=torch.channels_last) if img.is_cuda else img.contiguous()
+            yield img, lbl
+

@@ -138,3 +138,39 @@ def load_checkpoint(model, log_dir, model_name, epoch=0, optimizer=None):
         optimizer.load_state_dict(ckpt['optimizer_state_dict'])
     return ckpt
 
+
+# ---- epoch loops (run.py:233-316) over a device-resident dataset (data.IcoDataset) -----------------------------------------
+def train_epoch(trainer, dataset, batch_size, shuffle=True, generator=None):
+    """One pass of run.py:233-278 (train()): model in train mode, one Trainer.step per batch.  Returns the per-batch losses
+    as one device tensor (a single host sync when the caller reads it, instead of one per iteration)."""
+    trainer.model.train()
+    losses_ = [trainer.step(img, lbl) for img, lbl in dataset.batches(batch_size, shuffle, generator)]
+    return torch.stack(losses_)
+
+
+@torch.no_grad()
+def validate(trainer, dataset, batch_size):
+    """run.py:280-315 (validate()): eval mode, no grad, the unweighted mean over batches of the criterion's total loss."""
+    return float(torch.stack([trainer.evaluate(img, lbl) for img, lbl in dataset.batches(batch_size)]).mean())
+
+
+def fit(trainer, trn, val, epochs, batch_size, log_dir=None, model_name=None, seed=0, first_epoch=1, best_loss=float('inf')):
+    """The reference's epoch loop: train, validate, keep the best models.  A checkpoint '<name>_EB<epoch>.pt' is written
+    whenever the validation loss does not exceed the best so far, and all but the newest six are deleted (saveBestModel,
+    run.py:317-329).  Returns a list of (epoch, mean training loss, validation loss)."""
+    name = model_name or trainer.params['model_name']
+    gen = torch.Generator().manual_seed(seed)
+    history = []
+    for epoch in range(first_epoch, first_epoch + epochs):
+        trn_loss = float(train_epoch(trainer, trn, batch_size, True, gen).mean())
+        val_loss = validate(trainer, val, batch_size)
+        history.append((epoch, trn_loss, val_loss))
+        if log_dir is not None and val_loss <= best_loss:
+            if trainer.world == 1 or dist.get_rank() == 0:
+                old = sorted(glob.glob(os.path.join(log_dir, 'savedModel', name + '_EB*[0-9]*.pt')), key=_natural_key)
+                for path in old[:max(0, len(old) - 5)]:
+                    os.remove(path)
+            save_checkpoint(trainer, log_dir, 'B%d' % epoch, val_loss=val_loss, model_name=name)
+            best_loss = val_loss
+    return history
+

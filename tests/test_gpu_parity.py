@@ -486,3 +486,24 @@ def test_inference_halves_compose_to_the_full_model(train_mode_bn):
         mu_h, lv_h = enc(x)
         assert rel_l2(mu_h.cpu().numpy(), mu_f.cpu().numpy()) < 1e-6 and rel_l2(lv_h.cpu().numpy(), lv_f.cpu().numpy()) < 1e-6
         assert rel_l2(dec(mu_h)[0].cpu().numpy(), full.decode(mu_f).cpu().numpy()) < 1e-6
+
+
+def test_device_resident_dataset_feeds_the_hip_path(tmp_path):
+    """data.IcoDataset on the device + train.train_epoch / validate: the first batch's loss is the one Trainer.step gives on
+    the same tensors (twin trainer, same seed), inputs arrive channels_last, validation runs in eval mode."""
+    from geniconet_amd import data, models, train
+    R = 3
+    _, t = data.synthetic_batch(6, R, seed=21)
+    for k in range(6):
+        data.save_sample(str(tmp_path / ('s%d.npz' % k)), t[k].numpy())
+    ds = data.IcoDataset(str(tmp_path), R, device='cuda')
+    assert ds.targets.is_cuda and len(ds) == 6
+    img, lbl = next(iter(ds.batches(4)))
+    assert img.is_contiguous(memory_format=torch.channels_last) and torch.equal(lbl.cpu(), t[:4])
+    p = models.default_params('ico2ico', subdivisions=R)
+    a, b = train.Trainer(p, 'cuda', seed=7), train.Trainer(p, 'cuda', seed=7)
+    want = float(b.step(img, lbl))
+    got = train.train_epoch(a, ds, 4, shuffle=False)
+    assert got.shape == (2,) and abs(float(got[0]) - want) <= 1e-6 * abs(want)
+    v = train.validate(a, ds.subset([4, 5]), 2)
+    assert np.isfinite(v) and a.model.training

@@ -187,3 +187,53 @@ def test_checkpoints_use_the_reference_format_and_resume_exactly(tmp_path):
     half = models.ico2enc(p)                                                        # product encoder half, same keys
     assert train.load_checkpoint(half, str(tmp_path), 'ico2ico', epoch='B3') is not None
     assert torch.equal(half.state_dict()['encoder.0.weight'], ck['model_state_dict']['encoder.0.weight'])
+
+
+def test_device_resident_dataset_and_epoch_loops(tmp_path):
+    """SURVEY 8 f4 / run.py:233-329: samples listed in natural order (data.py:18), preloaded once, batched like the
+    reference's DataLoader (shuffle per epoch, short last batch); validate = mean over batches of the total loss in eval
+    mode; fit keeps '<name>_EB<epoch>.pt' checkpoints of the best validation losses.  CPU, oracle network."""
+    import numpy as np
+    import torch
+    from geniconet_amd import data, models, train
+    from oracle import models_ref
+    R = 3
+    x, t = data.synthetic_batch(7, R, seed=3)
+    names = ['m1', 'm2', 'm10', 'm3', 'm11', 'm4', 'm20']
+    d = tmp_path / 'trn'
+    d.mkdir()
+    for k, nme in enumerate(names):
+        data.save_sample(str(d / (nme + '.npz')), t[k].numpy())
+    (d / 'notes.txt').write_text('ignored')
+    ds = data.IcoDataset(str(d), R)
+    order = [names.index(n_) for n_ in ('m1', 'm2', 'm3', 'm4', 'm10', 'm11', 'm20')]
+    assert [os.path.basename(f) for f in ds.files] == ['m1.npz', 'm2.npz', 'm3.npz', 'm4.npz', 'm10.npz', 'm11.npz', 'm20.npz']
+    assert len(ds) == 7 and torch.equal(ds.targets, t[order])
+    got = list(ds.batches(3))
+    assert [b[0].shape[0] for b in got] == [3, 3, 1]                           # drop_last=False
+    assert torch.equal(torch.cat([b[1] for b in got]), t[order])
+    for img, lbl in got:                                                       # input = target[:3, :-2] on the grid
+        ref_img, ref_lbl = data.load_sample(ds.files[0], R)
+        assert img.shape[1:] == ref_img.shape and torch.equal(img, data.target_to_input(lbl, R))
+    g = torch.Generator().manual_seed(1)
+    seen = torch.cat([b[1] for b in ds.batches(3, shuffle=True, generator=g)])
+    assert not torch.equal(seen, t[order])
+    assert sorted(float(v) for v in seen[:, 0, 0]) == sorted(float(v) for v in t[:, 0, 0])   # a permutation of the samples
+
+    p = models.default_params('ico2ico', subdivisions=R)
+    torch.manual_seed(0)
+    tr = train.Trainer(p, 'cpu', model=models_ref.ico2ico(R=R).train(), criterion=train.build_criterion(p, 'cpu'),
+                       channels_last=False)
+    trn, val = ds.subset([0, 1, 2, 3, 4]), ds.subset([5, 6])
+    manual = np.mean([float(tr.evaluate(i_, l_)) for i_, l_ in val.batches(1)])
+    assert abs(train.validate(tr, val, 1) - manual) < 1e-7 and tr.model.training
+    hist = train.fit(tr, trn, val, epochs=3, batch_size=2, log_dir=str(tmp_path), seed=4)
+    assert [h[0] for h in hist] == [1, 2, 3] and all(np.isfinite(h[1]) and np.isfinite(h[2]) for h in hist)
+    best, saved = float('inf'), []
+    for epoch, _, v in hist:
+        if v <= best:
+            best = v
+            saved.append('ico2ico_EB%d.pt' % epoch)
+    assert sorted(os.listdir(tmp_path / 'savedModel')) == sorted(saved) and saved
+    ck = train.load_checkpoint(tr.model, str(tmp_path), 'ico2ico', epoch=0)
+    assert abs(ck['loss'] - best) < 1e-12
