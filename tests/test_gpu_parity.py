@@ -130,6 +130,52 @@ def test_conv_pair_falls_back_outside_its_limits():
         assert rel_l2(p_.detach().cpu().numpy(), h_.detach().cpu().numpy()) < 1e-6
 
 
+def test_tensors_beyond_2gib_take_the_fallback_kernels_and_agree_with_half_batches():
+    """Maximum sizes: the LDS-DMA kernels address their operands through 32-bit buffer offsets, so a tensor of 2 GiB or
+    more is routed to the register-staged kernels (per pass: what counts is the tensor that pass gathers from -- x for the
+    forward and the weight gradient, dy for the input gradient).  r = 7, 128 -> 128 channels, batch 36: 3.0 GB each; a
+    convolution acts on each sample independently, so the result must equal the two 1.5 GB half-batches run through the DMA kernels (forward,
+    input gradient; the weight gradient is the sum of the halves')."""
+    from geniconet_amd.ico_conv import ico_conv
+    r, B, cin, cout = 7, 36, 128, 128                  # input AND output 3.0 GB: all three passes gather from a >= 2 GiB tensor
+    n = 2 ** r
+    g = torch.Generator(device='cuda').manual_seed(12)
+    x = torch.randn(B, 5 * n, 2 * n, cin, device='cuda', generator=g).permute(0, 3, 1, 2)        # channels_last storage
+    assert x.numel() * 4 >= 2 ** 31 and (x.numel() // 2) * 4 < 2 ** 31
+    w = (torch.randn(cout, cin, 7, device='cuda', generator=g) / (7 * cin) ** 0.5).requires_grad_()
+    b = torch.randn(cout, device='cuda', generator=g).requires_grad_()
+    gy = torch.randn(B, 5 * n, 2 * n, cout, device='cuda', generator=g).permute(0, 3, 1, 2)
+
+    def run(xs, gys):
+        xs = xs.detach().requires_grad_()
+        y = ico_conv(xs, w, b, r, 1, 'average')
+        dx, dw, db = torch.autograd.grad(y, (xs, w, b), gys)
+        return y.detach(), dx, dw, db
+
+    def close(a, ref):
+        return float((a - ref).norm() / ref.norm()) < 1e-5
+
+    from geniconet_amd import _lib
+
+    def kernels(fn, *a):
+        _lib.profile_start(64)
+        out = fn(*a)
+        return out, {e['kernel'].split('<')[0] for e in _lib.profile_stop()}
+
+    (y, dx, dw, db), big = kernels(run, x, gy)
+    assert big == {'k_gather_gemm', 'k_wgrad'}, big                     # register-staged fallbacks only
+    h = B // 2
+    dw_sum, db_sum = torch.zeros_like(dw), torch.zeros_like(db)
+    for lo in (0, h):
+        (yh, dxh, dwh, dbh), half = kernels(run, x[lo:lo + h], gy[lo:lo + h])
+        assert half == {'k_conv_dma', 'k_wgrad_dma'}, half              # the production kernels
+        assert close(y[lo:lo + h], yh) and close(dx[lo:lo + h], dxh)
+        dw_sum += dwh
+        db_sum += dbh
+        del yh, dxh
+    assert close(dw, dw_sum) and close(db, db_sum)
+
+
 def test_register_staged_fallback_kernels_stay_correct():
     """k_gather_gemm and the non-DMA k_wgrad serve only tensors beyond 2 GiB and tiles with fewer than 4 K-steps, so the
     normal suite hardly reaches them.  ICN_DEBUG=48 routes every convolution to them; the switch is read once per process,
