@@ -13,6 +13,7 @@ Rank 0 prints ONE JSON line, with
   cpu_baseline : the CPU restatement of the same step (oracle/) timed on this host's cores (N=1 only).
 """
 import argparse
+import faulthandler
 import json
 import os
 import sys
@@ -30,6 +31,9 @@ from geniconet_amd.train import Trainer  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
 # algorithmic work per mesh per TRAINING step (SURVEY.md 8d / BASELINE.md): 3 x forward conv FLOPs
 TRAIN_GFLOP_PER_MESH = {('ico2ico', 5): 31.49, ('ico2ico_vae', 5): 35.46, ('ico2ico', 6): 125.96}
+# fused-ideal HBM bytes per mesh per training step: every conv reads its input and writes its output once
+TRAIN_MB_PER_MESH = {('ico2ico', 5): 175.9, ('ico2ico_vae', 5): 179.7, ('ico2ico', 6): 702.9}
+PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 CONFIGS = {
     'ae': dict(model='ico2ico', R=5, batch=36, workload='ico2ico AE training, I5, batch 36 per GPU (BASELINE configs[1])'),
     'vae': dict(model='ico2ico_vae', R=5, batch=36, workload='ico2ico_vae training, I5, batch 36 per GPU (configs[3])'),
@@ -49,42 +53,52 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, budget_s=20.0):
+def cpu_baseline(cfg, budget_s=12.0):
     """The CPU restatement (oracle/) of the same training step on this host's cores: the only runnable 'reference
-    CPU path' (upstream icocnn is absent; parity unpinned).  detect_anomaly off (conservative for the GPU/CPU ratio).
-    Bounded sample: the batch is sized from a 2-mesh calibration step so that the timed work is about budget_s."""
+    CPU path' (upstream icocnn is absent; parity unpinned).  Headline: detect_anomaly off (faster, so conservative for the
+    GPU/CPU ratio); `with_anomaly`: the same steps inside torch.autograd.detect_anomaly(), as the reference trains
+    (run.py:237).  Bounded sample: the batch is sized from a 2-mesh calibration step so that 3 timed steps take about
+    budget_s in each mode."""
     from geniconet_amd.train import build_criterion
     from oracle import models_ref
     cores = min(usable_cores(), int(os.environ.get('ICN_CPU_THREADS', 64)))
     torch.set_num_threads(cores)
     p = models.default_params(cfg['model'], subdivisions=cfg['R'])
 
-    def trainer():
+    def trainer(anomaly=False):
         torch.manual_seed(0)
         net = getattr(models_ref, cfg['model'])(R=cfg['R']).train()
-        return Trainer(p, 'cpu', model=net, criterion=build_criterion(p, 'cpu'), channels_last=False)
+        return Trainer(p, 'cpu', model=net, criterion=build_criterion(p, 'cpu'), channels_last=False, anomaly=anomaly)
     tr = trainer()
     x, t = data.synthetic_batch(2, cfg['R'], seed=1234)
     tr.step(x, t)
     t0 = time.perf_counter()
     tr.step(x, t)
     per_mesh = (time.perf_counter() - t0) / 2
-    batch = int(max(2, min(cfg['batch'], budget_s / 2 / max(per_mesh, 1e-4))))
+    steps = 3
+    batch = int(max(2, min(cfg['batch'], budget_s / steps / max(per_mesh, 1e-4))))
     x, t = data.synthetic_batch(batch, cfg['R'], seed=1234)
-    tr = trainer()
-    tr.step(x, t)                                   # warm-up at the sample's batch size
-    steps, t0 = 0, time.perf_counter()
-    while steps < 3 and (steps == 0 or time.perf_counter() - t0 < budget_s / 2):
-        tr.step(x, t)
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {'value': round(batch * steps / dt, 3), 'unit': 'meshes/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d timed training step(s) of batch %d at I%d after 1 warm-up (batch sized for ~%ds of CPU work), '
-                      'torch CPU restatement (oracle/), %d threads, detect_anomaly off'
+
+    def timed(anomaly):
+        import warnings
+        tr = trainer(anomaly)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')                # detect_anomaly announces itself on every entry
+            tr.step(x, t)                                   # warm-up at the sample's batch size
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tr.step(x, t)
+            return batch * steps / (time.perf_counter() - t0)
+    off, on = timed(False), timed(True)
+    return {'value': round(off, 3), 'unit': 'meshes/s', 'cores': cores, 'kind': 'port',
+            'with_anomaly': round(on, 3),
+            'sample': '%d timed training steps of batch %d at I%d after 1 warm-up (batch sized for ~%ds of CPU work per mode), '
+                      'torch CPU restatement (oracle/), %d threads; value: detect_anomaly off, with_anomaly: on (run.py:237)'
                       % (steps, batch, cfg['R'], int(budget_s), cores)}
 
 
 def main():
+    faulthandler.enable()      # a native crash leaves every rank's Python stack on stderr
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -107,6 +121,9 @@ def main():
     rehearsal = os.environ.get('ICN_BENCH_REHEARSAL', '') == '1'
     if rehearsal:
         local = 0
+        if world > 6:
+            raise SystemExit('bench.py: the one-GPU rehearsal is limited to 6 ranks (process cap of a GPU box)')
+        faulthandler.dump_traceback_later(int(os.environ.get('ICN_BENCH_WATCHDOG', 300)), exit=True)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
@@ -141,7 +158,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_stop() if events else []
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    el = torch.tensor([elapsed], device='cpu' if rehearsal else device, dtype=torch.float64)   # gloo: host tensors only
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el)
@@ -155,11 +172,14 @@ def main():
             dom = max(prof, key=lambda e: e['total_ms'])
             # HBM bytes per launch of that kernel from the latest committed PMC passes (tools/profile_round.sh:
             # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH doubled per the gfx950 note)
-            traffic = None
+            traffic, traffic_source = None, None
             try:
                 import glob
                 latest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel.json')))[-1]
                 traffic = json.load(open(latest)).get('icn::' + dom['kernel'], {}).get('hbm_bytes_per_launch')
+                if traffic is not None:
+                    traffic_source = ('not measured by this run: looked up in the committed ' + os.path.relpath(latest, ROOT)
+                                      + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)')
             except (IndexError, OSError, ValueError):
                 pass
             per_launch_ms = dom['total_ms'] / dom['launches']
@@ -167,7 +187,7 @@ def main():
             mfma_ms = sum(e['total_ms'] for e in prof)
             roofline = {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                 'kernel': dom['kernel'], 'launches_per_step': dom['launches'] / args.steps,
                 'avg_launch_us': round(per_launch_ms * 1e3, 2),
                 'algorithmic_gflop_per_launch': round(dom['total_flops'] / dom['launches'] / 1e9, 3),
@@ -178,6 +198,10 @@ def main():
                 'step_tflops': round(value * TRAIN_GFLOP_PER_MESH[(cfg['model'], cfg['R'])] / 1e3, 2),
                 'step_frac_of_mfma_peak': round(value * TRAIN_GFLOP_PER_MESH[(cfg['model'], cfg['R'])] / 1e3
                                                 / PEAK_FP32_MFMA_TFLOPS / world, 4),
+                # the HBM side of the same step (SURVEY 8d asks for both fractions; the binding one is MFMA)
+                'achieved_hbm': round(value * TRAIN_MB_PER_MESH[(cfg['model'], cfg['R'])] / 1e3 / world, 1),
+                'peak_hbm': PEAK_HBM_GBPS, 'unit_hbm': 'GB/s',
+                'frac_hbm': round(value * TRAIN_MB_PER_MESH[(cfg['model'], cfg['R'])] / 1e3 / world / PEAK_HBM_GBPS, 4),
             }
         out = {
             'metric': 'meshes/sec training throughput, ico2ico I5 batch=36' if args.config == 'ae'

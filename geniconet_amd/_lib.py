@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, 'libicn.so')
 
 OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT = 0, 1, 2
 CORNER_MODES = {'zeros': 0, 'average': 1}
-ABI_VERSION = 2
+ABI_VERSION = 3
+LAP_MODES = {'mean-v': 0, 'v-mean': 1, 'sum-kv': 2, 'kv-sum': 3}   # ICN_LAP_* of include/icn.h
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses
 _i32p = ctypes.POINTER(ctypes.c_int32)
@@ -45,9 +46,15 @@ SIGNATURES = {
     'icn_head_fwd': (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     'icn_head_bwd': (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     'icn_p2p_loss_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),
-    'icn_p2p_loss_fwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_float] * 3 + [_c_float_p] * 2 + [ctypes.c_void_p]),
+    'icn_p2p_loss_fwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_float] * 3 + [ctypes.c_int] + [_c_float_p] * 2 + [ctypes.c_void_p]),
     'icn_p2p_loss_bwd_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),
-    'icn_p2p_loss_bwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 2 + [ctypes.c_float] * 3 + [_c_float_p] * 2 + [ctypes.c_void_p]),
+    'icn_p2p_loss_bwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 2 + [ctypes.c_float] * 3 + [ctypes.c_int] + [_c_float_p] * 2 + [ctypes.c_void_p]),
+    'icn_kld_workspace_floats': (ctypes.c_size_t, [ctypes.c_size_t]),
+    'icn_kld_fwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_size_t] + [_c_float_p] * 2 + [ctypes.c_void_p]),
+    'icn_kld_bwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_size_t] + [_c_float_p] * 2 + [ctypes.c_void_p]),
+    'icn_reparam_fwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_size_t] + [_c_float_p] + [ctypes.c_void_p]),
+    'icn_reparam_bwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_size_t] + [_c_float_p] * 2 + [ctypes.c_void_p]),
+    'icn_set_debug_flags': (ctypes.c_int, [ctypes.c_int]),
     'icn_table_conv_fwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t]),
     'icn_table_conv_bwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t, _intp]),
     'icn_table_upsample': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, _f32p, ctypes.c_size_t, _intp]),
@@ -153,7 +160,7 @@ def table_upsample_pairs(r_in):
     return out.reshape(2, -1)
 
 
-def profile_start(max_launches=100000):
+def profile_start(max_launches=4096):
     check(lib().icn_profile_start(max_launches), 'icn_profile_start')
 
 

@@ -166,9 +166,11 @@ const UpTables& up_tables(int r_in, int mode) {
 
 // ---- profiling state (off by default) ------------------------------------------------------------------
 struct ProfRec { int kind; double flops; hipEvent_t e0, e1; };
-std::vector<ProfRec> g_prof;          // pre-created events
+std::vector<ProfRec> g_prof;          // pre-created events, reused by every start / stop
 size_t g_prof_used = 0;
 bool g_prof_on = false, g_prof_open = false;
+std::mutex g_prof_mu;                 // held from prof_mark_begin to prof_mark_end: launches may come from the forward
+                                      // thread and from the autograd thread
 
 void check_conv(const void* a, const void* b, const void* c, int B, int Cin, int Cout, int r_in, int stride) {
     if (!a || !b || !c) throw std::invalid_argument("icn: null tensor pointer");
@@ -324,7 +326,7 @@ void conv_bwd_data_impl(const float* dy0, const float* dy1, const float* w0, con
         icn::GatherGemmArgs v = a;
         v.dst = vout; v.idx = t.vidx; v.dcode = t.d_virt.code; v.n_slots = t.d_virt.n_slots; v.perm = t.vorder; v.mask32 = t.vmask32;
         v.M = B * t.nvp; v.Pd = t.nvp; v.E = 1;
-        v.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.nv;
+        v.algo_flops = 0.0;   // the main launch above already carries the layer's algorithmic FLOPs; this one adds time only
         icn::launch_gather_gemm_auto(v, s);
         icn::launch_row_scatter_add(vout, dx, t.vq, B, t.nv, t.nvp, t.Pin, Cin, s);
     }
@@ -361,7 +363,9 @@ const char* const PROF_NAMES[PROF_KINDS] = {"k_conv_dma<128, 128>", "k_conv_dma<
                                             "k_wgrad_dma<64, 128>", "k_wgrad_dma<64, 64>", "k_wgrad<128, 128>", "k_wgrad<128, 64>",
                                             "k_wgrad<64, 128>", "k_wgrad<64, 64>"};
 void prof_mark_begin(int kind, double flops, hipStream_t s) {
-    if (!g_prof_on || g_prof_used >= g_prof.size()) return;
+    if (!g_prof_on) return;
+    g_prof_mu.lock();
+    if (!g_prof_on || g_prof_used >= g_prof.size()) { g_prof_mu.unlock(); return; }
     ProfRec& r = g_prof[g_prof_used];
     r.kind = kind;
     r.flops = flops;
@@ -369,10 +373,11 @@ void prof_mark_begin(int kind, double flops, hipStream_t s) {
     g_prof_open = true;
 }
 void prof_mark_end(hipStream_t s) {
-    if (!g_prof_open) return;
+    if (!g_prof_open) return;         // only true between a successful begin and this call, on the thread holding the mutex
     (void)hipEventRecord(g_prof[g_prof_used].e1, s);
     ++g_prof_used;
     g_prof_open = false;
+    g_prof_mu.unlock();
 }
 }  // namespace icn
 
@@ -381,6 +386,7 @@ extern "C" {
 int icn_profile_start(int max_launches) {
     try {
         if (max_launches < 1) throw std::invalid_argument("icn_profile_start: max_launches must be positive");
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         while ((int)g_prof.size() < max_launches) {
             ProfRec r{};
             ICN_HIP(hipEventCreate(&r.e0));
@@ -397,7 +403,10 @@ int icn_profile_start(int max_launches) {
 
 int icn_profile_stop(icn_profile_entry* out, int cap) {
     try {
-        g_prof_on = false;
+        {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_prof_on = false;
+        }
         ICN_HIP(hipDeviceSynchronize());
         icn_profile_entry acc[icn::PROF_KINDS];
         for (int k = 0; k < icn::PROF_KINDS; ++k) acc[k] = icn_profile_entry{icn::PROF_NAMES[k], 0, 0.0, 0.0};
@@ -609,13 +618,14 @@ size_t icn_p2p_loss_workspace_floats(int B, int r) {
     return (B < 1 || r < 0 || r > 10) ? 0 : (size_t)3 * icn::p2p_loss_blocks(B, icn::pixels(r));
 }
 
-int icn_p2p_loss_fwd(const float* grid, const float* target, int B, int r, float f_pos, float f_nor, float f_lap, float* terms,
-                     float* ws, void* stream) {
+int icn_p2p_loss_fwd(const float* grid, const float* target, int B, int r, float f_pos, float f_nor, float f_lap, int lap_mode,
+                     float* terms, float* ws, void* stream) {
     try {
         if (!grid || !target || !terms || !ws) throw std::invalid_argument("icn_p2p_loss_fwd: null pointer");
         if (B < 1 || r < 0 || r > 10) throw std::invalid_argument("icn_p2p_loss_fwd: bad B / subdivisions");
         if ((size_t)B * (icn::pixels(r) + 2) >= (size_t)1 << 31) throw std::invalid_argument("icn_p2p_loss_fwd: B * vertices exceeds int32");
-        icn::launch_p2p_loss_fwd(grid, target, vertex_faces(r), ws, terms, B, icn::pixels(r), 1 << r, f_pos, f_nor, f_lap,
+        if (lap_mode < 0 || lap_mode > 3) throw std::invalid_argument("icn_p2p_loss_fwd: lap_mode must be a combination of ICN_LAP_*");
+        icn::launch_p2p_loss_fwd(grid, target, vertex_faces(r), ws, terms, B, icn::pixels(r), 1 << r, f_pos, f_nor, f_lap, lap_mode,
                                  static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());
         return 0;
@@ -629,20 +639,70 @@ size_t icn_p2p_loss_bwd_workspace_floats(int B, int r) {
 }
 
 int icn_p2p_loss_bwd(const float* grid, const float* target, const float* upstream, int B, int r, float f_pos, float f_nor,
-                     float f_lap, float* dgrid, float* ws, void* stream) {
+                     float f_lap, int lap_mode, float* dgrid, float* ws, void* stream) {
     try {
         if (!grid || !target || !upstream || !dgrid) throw std::invalid_argument("icn_p2p_loss_bwd: null pointer");
         if (B < 1 || r < 0 || r > 10) throw std::invalid_argument("icn_p2p_loss_bwd: bad B / subdivisions");
         if ((size_t)B * (icn::pixels(r) + 2) >= (size_t)1 << 31) throw std::invalid_argument("icn_p2p_loss_bwd: B * vertices exceeds int32");
         if ((f_nor != 0.f || f_lap != 0.f) && !ws) throw std::invalid_argument("icn_p2p_loss_bwd: workspace needed for the mesh terms");
-        icn::launch_p2p_loss_bwd(grid, target, vertex_faces(r), upstream, f_pos, f_nor, f_lap, dgrid, ws, B, icn::pixels(r), 1 << r,
-                                 static_cast<hipStream_t>(stream));
+        if (lap_mode < 0 || lap_mode > 3) throw std::invalid_argument("icn_p2p_loss_bwd: lap_mode must be a combination of ICN_LAP_*");
+        icn::launch_p2p_loss_bwd(grid, target, vertex_faces(r), upstream, f_pos, f_nor, f_lap, lap_mode, dgrid, ws, B, icn::pixels(r),
+                                 1 << r, static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());
         return 0;
     } catch (const std::exception& e) {
         return fail(e.what());
     }
 }
+
+// ---- KL term and reparameterisation of the VAE -----------------------------------------------------------------------
+size_t icn_kld_workspace_floats(size_t n) { return n < 1 ? 0 : (size_t)icn::kld_blocks(n); }
+
+int icn_kld_fwd(const float* mu, const float* logvar, size_t n, float* out, float* ws, void* stream) {
+    try {
+        if (!mu || !logvar || !out || !ws || n < 1) throw std::invalid_argument("icn_kld_fwd: bad arguments");
+        icn::launch_kld_fwd(mu, logvar, n, out, ws, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_kld_bwd(const float* mu, const float* logvar, const float* upstream, size_t n, float* dmu, float* dlogvar, void* stream) {
+    try {
+        if (!mu || !logvar || !upstream || !dmu || !dlogvar || n < 1) throw std::invalid_argument("icn_kld_bwd: bad arguments");
+        icn::launch_kld_bwd(mu, logvar, upstream, n, dmu, dlogvar, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_reparam_fwd(const float* mu, const float* logvar, const float* eps, size_t n, float* z, void* stream) {
+    try {
+        if (!mu || !logvar || !eps || !z || n < 1) throw std::invalid_argument("icn_reparam_fwd: bad arguments");
+        icn::launch_reparam_fwd(mu, logvar, eps, n, z, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_reparam_bwd(const float* dz, const float* logvar, const float* eps, size_t n, float* dmu, float* dlogvar, void* stream) {
+    try {
+        if (!dz || !logvar || !eps || !dmu || !dlogvar || n < 1) throw std::invalid_argument("icn_reparam_bwd: bad arguments");
+        icn::launch_reparam_bwd(dz, logvar, eps, n, dmu, dlogvar, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_set_debug_flags(int flags) { return icn::set_debug_flags(flags); }
 
 // ---- fused BatchNorm + ReLU ---------------------------------------------------------------------------------
 size_t icn_bn_workspace_floats(int M, int C) { return (M < 1 || C < 1) ? 0 : (size_t)icn::bn_chunks(M) * 3 * C; }

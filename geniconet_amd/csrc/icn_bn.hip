@@ -20,7 +20,9 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f),
 constexpr int BN_MAX_CHUNKS = 512;
 
 // partial[chunk][k][C], k < NS: per-channel sums of NS quantities over the chunk's rows.
-//   MODE 0 (forward stats of x):                 k0 = sum x,        k1 = sum x^2
+//   MODE 0 (forward stats of x):                 k0 = sum (x - x0), k1 = sum (x - x0)^2       x0 = row 0 of x (per channel)
+//          The shift keeps var = E[(x-x0)^2] - E[x-x0]^2 free of cancellation when |mean| >> std (torch uses Welford;
+//          a plain E[x^2] - mean^2 in fp32 loses the variance of e.g. x = 100 + randn).
 //   MODE 1 (backward of relu(bn(x))):            k0 = sum g,        k1 = sum g * xhat         g = dy * (y > 0)
 //   MODE 2 (backward of relu(bn_a(a)+bn_b(b))):  k0 = sum g,        k1 = sum g * ahat,  k2 = sum g * bhat
 template <int MODE>
@@ -39,11 +41,13 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
     f32x4 mean_a{}, inv_a{}, mean_b{}, inv_b{};
     if (MODE >= 1) { mean_a = ldv(stat_a + c); inv_a = ldv(stat_a + C + c); }
     if (MODE == 2) { mean_b = ldv(stat_b + c); inv_b = ldv(stat_b + C + c); }
+    f32x4 shift{};
+    if (MODE == 0) shift = ldv(p0 + c);
     if (stripe < stripes) {
         for (int r = r0 + stripe; r < r1; r += stripes) {
             const size_t o = (size_t)r * C + c;
             if (MODE == 0) {
-                const f32x4 x = ldv(p0 + o);
+                const f32x4 x = ldv(p0 + o) - shift;
                 s[0] += x;
                 s[1] += x * x;
             } else {
@@ -99,16 +103,18 @@ __device__ __forceinline__ double chunk_sum(const float* __restrict__ partial, i
 }
 
 // forward finalize: mean / invstd of the batch, running statistics (momentum, unbiased variance); 16 channels per block
-__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ partial, int chunks, int M, int C, float eps,
-                                                          float momentum, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float* __restrict__ stat) {
+__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ x, const float* __restrict__ partial, int chunks,
+                                                          int M, int C, float eps, float momentum,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float* __restrict__ stat) {
     __shared__ double red[16][16];
     const int c = blockIdx.x * 16 + threadIdx.x % 16, slice = threadIdx.x / 16;
     const double s = chunk_sum(partial, chunks, 2, 0, C, c, slice, red);
     const double s2 = chunk_sum(partial, chunks, 2, 1, C, c, slice, red);
     if (slice != 0 || c >= C) return;
-    const double mean = s / M;
-    double var = s2 / M - mean * mean;
+    const double ms = s / M;                              // mean of x - x0 (x0 = first row: the shift of k_bn_partial<0>)
+    const double mean = (double)x[c] + ms;
+    double var = s2 / M - ms * ms;
     if (var < 0.0) var = 0.0;
     stat[c] = (float)mean;
     stat[C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -175,7 +181,7 @@ void launch_bn_stats(const float* x, int M, int C, float eps, float momentum, fl
                      float* ws, hipStream_t s) {
     const int chunks = bn_chunks(M), rows = (M + chunks - 1) / chunks;
     hipLaunchKernelGGL(k_bn_partial<0>, dim3(chunks), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, rows);
-    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 15) / 16), dim3(256), 0, s, ws, chunks, M, C, eps, momentum, running_mean,
+    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 15) / 16), dim3(256), 0, s, x, ws, chunks, M, C, eps, momentum, running_mean,
                        running_var, stat);
 }
 

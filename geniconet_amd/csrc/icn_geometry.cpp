@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <map>
 #include <stdexcept>
 
@@ -292,6 +293,177 @@ void build_upsample_pairs(int r_in, std::vector<int32_t>& out) {
                 out[q] = vid(c, a0 / 2, b0 / 2);
                 out[(size_t)Pf + q] = vid(c, a1 / 2, b1 / 2);
             }
+}
+
+namespace {
+
+using AlphaKey = std::array<int, NTAPS>;        // coefficient vector in thousandths (exact for 1, 0.5, 0.1, 0.02 ...)
+
+// composite row of fine pixel p: coarse pixel -> coefficient per original tap, and per tap the expansion of its source
+struct CompRow {
+    std::map<int32_t, std::array<double, NTAPS>> by_pixel;
+    std::array<std::map<int32_t, double>, NTAPS> by_tap;
+};
+
+void composite_rows(int r_in, int corner_mode, std::vector<CompRow>& rows) {
+    const int n = 1 << r_in, nf = 2 * n, Pf = 10 * nf * nf;
+    std::vector<int32_t> fwd;
+    build_conv_fwd(r_in + 1, 1, corner_mode, fwd);
+    Ell uf, ub;
+    build_upsample(r_in, corner_mode, uf, ub);
+    rows.assign(Pf, CompRow{});
+    auto add_fine = [&](CompRow& row, int t, int32_t q, double w) {       // w * up[q] into tap t
+        for (int e = 0; e < uf.width; ++e) {
+            const int32_t s = uf.idx[(size_t)q * uf.width + e];
+            if (s < 0) continue;
+            const double c = w * (double)uf.coef[(size_t)q * uf.width + e];
+            auto it = row.by_pixel.find(s);
+            if (it == row.by_pixel.end()) it = row.by_pixel.emplace(s, std::array<double, NTAPS>{}).first;
+            it->second[t] += c;
+            row.by_tap[t][s] += c;
+        }
+    };
+    for (int p = 0; p < Pf; ++p)
+        for (int t = 0; t < NTAPS; ++t) {
+            const int32_t q = fwd[(size_t)t * Pf + p];
+            if (q >= 0) {
+                add_fine(rows[p], t, q, 1.0);
+            } else if (q <= IDX_POLE) {                                      // mean of the 5 FINE corner pixels of the pole
+                for (int c = 0; c < 5; ++c) add_fine(rows[p], t, corner_pixel(nf, IDX_POLE - q, c), 0.2);
+            }
+        }
+}
+
+AlphaKey alpha_key(const std::array<double, NTAPS>& a) {
+    AlphaKey k;
+    for (int t = 0; t < NTAPS; ++t) k[t] = (int)(a[t] * 1000.0 + (a[t] >= 0 ? 0.5 : -0.5));
+    return k;
+}
+
+inline int parity_class(int nf, int p) { return (((p / (2 * nf)) % nf) & 1) * 2 + (p % (2 * nf) & 1); }
+
+// The regular coefficient vectors per parity class of the fine pixel, taken from interior pixels of a level-3 -> 4 upsample
+// (they do not depend on the level): templates[cls] = sorted keys; class 1 (row even, column odd) is the coarse-site class.
+const std::array<std::vector<AlphaKey>, 4>& upconv_templates() {
+    static const std::array<std::vector<AlphaKey>, 4> tpl = [] {
+        std::array<std::vector<AlphaKey>, 4> out;
+        std::vector<CompRow> rows;
+        composite_rows(3, CORNER_AVERAGE, rows);
+        const int nf = 16;
+        for (int di = 0; di < 2; ++di)
+            for (int dj = 0; dj < 2; ++dj) {
+                const int I = 8 + di, J = 14 + dj;                         // interior of chart 0, away from seams and poles
+                const int p = I * 2 * nf + J, cls = parity_class(nf, p);
+                for (auto& e : rows[p].by_pixel) out[cls].push_back(alpha_key(e.second));
+                std::sort(out[cls].begin(), out[cls].end());
+            }
+        if (out[1].size() != 7 || out[0].size() != 4 || out[2].size() != 4 || out[3].size() != 4)
+            throw std::logic_error("icn: unexpected upsample-conv templates");
+        return out;
+    }();
+    return tpl;
+}
+
+}  // namespace
+
+void build_upconv_fwd(int r_in, int corner_mode, UpconvTable& out) {
+    check_args(r_in, 1, corner_mode);
+    if (r_in > 9) throw std::invalid_argument("icn: subdivisions out of range for upsample + conv");
+    const int n = 1 << r_in, nf = 2 * n;
+    out = UpconvTable{};
+    out.Pc = 10 * n * n;
+    out.Pf = 10 * nf * nf;
+    const auto& tpl = upconv_templates();
+    // virtual tap ids: site class first (7), then parity classes 0, 2, 3 (4 each)
+    const int cls_order[4] = {1, 0, 2, 3};
+    int vt_base[4];
+    out.alpha.assign((size_t)UPCONV_TAPS * NTAPS, 0.f);
+    for (int k = 0, v = 0; k < 4; ++k) {
+        const int cls = cls_order[k];
+        vt_base[cls] = v;
+        for (auto& key : tpl[cls]) {
+            for (int t = 0; t < NTAPS; ++t) out.alpha[(size_t)v * NTAPS + t] = (float)(key[t] / 1000.0);
+            ++v;
+        }
+    }
+    for (int t = 0; t < NTAPS; ++t) out.alpha[(size_t)(UPCONV_REGULAR + t) * NTAPS + t] = 1.f;
+
+    std::vector<CompRow> rows;
+    composite_rows(r_in, corner_mode, rows);
+    // segment of every fine pixel: 0 site, 1..3 midpoint classes, 4 irregular
+    std::vector<int> seg(out.Pf, 4);
+    for (int p = 0; p < out.Pf; ++p) {
+        const int cls = parity_class(nf, p);
+        const auto& want = tpl[cls];
+        if (rows[p].by_pixel.size() != want.size()) continue;
+        std::vector<AlphaKey> have;
+        for (auto& e : rows[p].by_pixel) have.push_back(alpha_key(e.second));
+        std::sort(have.begin(), have.end());
+        if (have == want) seg[p] = cls == 1 ? 0 : cls == 0 ? 1 : cls;      // classes 2, 3 keep their number
+    }
+    std::vector<int> order(out.Pf);
+    for (int p = 0; p < out.Pf; ++p) order[p] = p;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return seg[x] < seg[y]; });
+    out.pix.assign(order.begin(), order.end());
+    int cnt[5] = {0, 0, 0, 0, 0};
+    for (int p = 0; p < out.Pf; ++p) ++cnt[seg[p]];
+    const int seg_cls[4] = {1, 0, 2, 3};
+    int off = 0;
+    for (int sg = 0; sg < 5; ++sg) {
+        if (cnt[sg] == 0) continue;
+        uint32_t mask = 0;
+        if (sg == 4) mask = ((1u << NTAPS) - 1u) << UPCONV_REGULAR;
+        else mask = ((1u << tpl[seg_cls[sg]].size()) - 1u) << vt_base[seg_cls[sg]];
+        out.seg_cnt[out.nseg] = cnt[sg];
+        out.seg_off[out.nseg] = off;
+        out.seg_mask[out.nseg] = mask;
+        off += cnt[sg];
+        ++out.nseg;
+    }
+    out.code.assign((size_t)UPCONV_TAPS * out.Pf, IDX_ZERO);
+    std::map<std::vector<std::pair<int32_t, int>>, int> slot_of;            // entry list (pixel, coef in 1e-6) -> slot
+    std::vector<std::vector<std::pair<int32_t, double>>> slot_entries;
+    for (int pos = 0; pos < out.Pf; ++pos) {
+        const int p = out.pix[pos];
+        if (seg[p] != 4) {
+            const int cls = parity_class(nf, p);
+            for (auto& e : rows[p].by_pixel) {
+                const AlphaKey key = alpha_key(e.second);
+                const int v = vt_base[cls] + (int)(std::lower_bound(tpl[cls].begin(), tpl[cls].end(), key) - tpl[cls].begin());
+                out.code[(size_t)v * out.Pf + pos] = e.first;
+            }
+            continue;
+        }
+        for (int t = 0; t < NTAPS; ++t) {
+            const auto& ent = rows[p].by_tap[t];
+            if (ent.empty()) continue;
+            int32_t code;
+            if (ent.size() == 1 && std::abs(ent.begin()->second - 1.0) < 1e-9) {
+                code = ent.begin()->first;
+            } else {
+                std::vector<std::pair<int32_t, int>> key;
+                for (auto& e : ent) key.push_back({e.first, (int)(e.second * 1e6 + 0.5)});
+                auto it = slot_of.find(key);
+                if (it == slot_of.end()) {
+                    it = slot_of.emplace(key, (int)slot_entries.size()).first;
+                    slot_entries.emplace_back(ent.begin(), ent.end());
+                }
+                code = -2 - it->second;
+            }
+            out.code[(size_t)(UPCONV_REGULAR + t) * out.Pf + pos] = code;
+        }
+    }
+    out.n_slots = (int)slot_entries.size();
+    size_t E = 1;
+    for (auto& l : slot_entries) E = std::max(E, l.size());
+    out.E = (int)E;
+    out.slot_idx.assign((size_t)out.n_slots * E, IDX_ZERO);
+    out.slot_coef.assign((size_t)out.n_slots * E, 0.f);
+    for (int sl = 0; sl < out.n_slots; ++sl)
+        for (size_t e = 0; e < slot_entries[sl].size(); ++e) {
+            out.slot_idx[(size_t)sl * E + e] = slot_entries[sl][e].first;
+            out.slot_coef[(size_t)sl * E + e] = (float)slot_entries[sl][e].second;
+        }
 }
 
 void build_bwd_row_order(int r_in, int stride, const std::vector<int32_t>& bwd_idx, int E,

@@ -77,6 +77,37 @@ void build_upsample(int r_in, int corner_mode, Ell& fwd, Ell& bwd);
 // N / S pole) whose mean is fine pixel q (equal at coarse sites).
 void build_upsample_pairs(int r_in, std::vector<int32_t>& out);
 
+// Composite table of  conv_stride1(upsample(x))  -- the first two operators of every decoder block of the reference
+// (models.py:58-60: conv00(upsample00(x)), conv10(upsample10(x))) -- as ONE gather-GEMM over the COARSE tensor.
+// The upsample is linear (copy at coarse sites, mean of the two edge endpoints elsewhere), so
+//     y[p] = bias + sum_t W_t up[nbr_t(p)] = bias + sum_{s in S(p)} (sum_t alpha_{p,s}[t] W_t) x[s]
+// and away from the 12 singular vertices the coefficient vectors alpha only depend on the parity class of the fine pixel p:
+// a coarse-site pixel reads 7 coarse pixels, an edge-midpoint pixel only the 4 corners of the two triangles on its edge.
+// That is 19 "virtual taps" (7 + 3 x 4) with effective weights W_eff[v] = sum_t alpha[v][t] W_t, and on average
+// 4.75 instead of 7 K-blocks per output pixel (0.68 of the multiply-adds of the unfused pair of operators), without the
+// 4x larger upsampled tensor ever existing.  Rows are ordered class-major (all samples' site pixels, then the three
+// midpoint classes, then the irregular rows) so that a GEMM tile only runs the virtual taps of its class.
+// Irregular rows (within two steps of a pole or of a five-valent corner pixel; a few hundred per sample) keep the 7
+// original taps, W_eff[19 + t] = W_t, and gather the upsampled neighbour value itself from a small side buffer
+// (slot = sum_e coef_e x[pixel_e], filled by the call's prologue).
+constexpr int UPCONV_REGULAR = 19;             // virtual taps 0..18
+constexpr int UPCONV_TAPS = UPCONV_REGULAR + NTAPS;   // + the 7 original taps (irregular rows)
+constexpr int UPCONV_MAX_SEG = 5;
+struct UpconvTable {
+    int Pc = 0, Pf = 0;                    // coarse / fine pixels per sample
+    std::vector<float> alpha;              // [UPCONV_TAPS][NTAPS]
+    int nseg = 0;                          // row segments (classes) in order; empty classes are dropped
+    int seg_cnt[UPCONV_MAX_SEG] = {};      // fine pixels per sample in the segment
+    int seg_off[UPCONV_MAX_SEG] = {};      // first list position of the segment (prefix sum of seg_cnt)
+    uint32_t seg_mask[UPCONV_MAX_SEG] = {};// virtual taps the segment's rows use
+    std::vector<int32_t> pix;              // [Pf] list position -> fine pixel (class-major)
+    std::vector<int32_t> code;             // [UPCONV_TAPS][Pf] by list position: >= 0 coarse pixel, IDX_ZERO, -2 - slot
+    int n_slots = 0, E = 1;
+    std::vector<int32_t> slot_idx;         // [n_slots][E] coarse pixels (IDX_ZERO padded)
+    std::vector<float> slot_coef;          // [n_slots][E]
+};
+void build_upconv_fwd(int r_in, int corner_mode, UpconvTable& out);
+
 // Row permutation + per-32-row tap masks for stride-2 bwd-data (rows grouped by lattice parity class so
 // that all-empty taps can be skipped tile-wise).  perm[k] = input pixel handled by row k.
 void build_bwd_row_order(int r_in, int stride, const std::vector<int32_t>& bwd_idx, int E,

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <stdexcept>
 #include <type_traits>
@@ -279,21 +280,39 @@ __global__ __launch_bounds__(256) void k_gather_gemm(
     }
 }
 
-static int dbg_flags() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ICN_DEBUG"); v = e ? atoi(e) : 0; }
+// developer routing flags: initial value from ICN_DEBUG, changed at run time by icn_set_debug_flags (tests)
+static std::atomic<int> g_dbg{-1};
+int debug_flags() {
+    int v = g_dbg.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("ICN_DEBUG");
+        v = e ? atoi(e) : 0;
+        g_dbg.store(v, std::memory_order_relaxed);
+    }
     return v;
+}
+int set_debug_flags(int flags) {
+    const int old = debug_flags();
+    g_dbg.store(flags < 0 ? 0 : flags, std::memory_order_relaxed);
+    return old;
+}
+static int dbg_flags() { return debug_flags(); }
+static int current_device_bit() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev & 63;
 }
 
 template <int BM, int BN>
 static void launch_gather_gemm(const GatherGemmArgs& a, hipStream_t s) {
     const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     const size_t lds = (size_t)2 * (BM + BN) * BK * 4 + (size_t)7 * a.E * BM * 4;
-    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in (idempotent, so a race is harmless)
-    if (!attr_set) {
+    // > 64 KiB of dynamic LDS needs the opt-in, once per DEVICE (idempotent, so a race is harmless)
+    static std::atomic<uint64_t> attr_devices{0};
+    if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gather_gemm<BM, BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
     }
     prof_mark_begin(BM == 64 ? (BN == 128 ? PROF_GG_64x128 : PROF_GG_64x64) : (BN == 128 ? PROF_GG_128x128 : PROF_GG_128x64),
                     a.algo_flops, s);
@@ -702,11 +721,11 @@ static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
     int grid = std::min(ntiles, 256 * occ);              // (more blocks than slots: measured, no difference -- DESIGN 4.2)
     if (grid >= 8) grid -= grid % 8;                     // keep a block's tiles in one residue class mod 8 (one XCD)
     const size_t lds = conv_dma_lds(BM, BN, a.perm != nullptr, a.bias != nullptr);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_devices{0};        // LDS opt-in, once per device
+    if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_dma<BM, BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
     }
     const int Ks = a.src2 ? a.K / 2 : a.K;
     const unsigned src_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.Ps * Ks * 4);

@@ -98,15 +98,27 @@ void launch_head_fwd(const float* x, const float* w, const float* bias, float* y
 void launch_head_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
                      int M, int Cin, int Cout, hipStream_t s);
 
+// lap_mode: Laplacian convention, bit 0 = v - mean(ring) instead of mean(ring) - v, bit 1 = times the valence (sum form)
 // ---- point-to-point loss (icn_loss.hip): terms[4] = {pos, nor, lap, weighted total}; partial = 3 * p2p_loss_blocks floats
 int p2p_loss_blocks(int B, int P);
 void launch_p2p_loss_fwd(const float* grid, const float* target, const int32_t* vf, float* partial, float* terms, int B, int P, int n,
-                         float f_pos, float f_nor, float f_lap, hipStream_t s);
+                         float f_pos, float f_nor, float f_lap, int lap_mode, hipStream_t s);
 void launch_p2p_loss_bwd_pos(const float* grid, const float* target, const float* upstream, float f_pos, float* dgrid, int B, int P,
                              int n, hipStream_t s);
 // all three terms (aux = 6 * B * (P + 2) floats; unused, may be null, when f_nor = f_lap = 0)
 void launch_p2p_loss_bwd(const float* grid, const float* target, const int32_t* vf, const float* upstream, float f_pos, float f_nor,
-                         float f_lap, float* dgrid, float* aux, int B, int P, int n, hipStream_t s);
+                         float f_lap, int lap_mode, float* dgrid, float* aux, int B, int P, int n, hipStream_t s);
+
+// ---- KL term + reparameterisation of the VAE (icn_loss.hip); partial = kld_blocks(n) floats
+int kld_blocks(size_t n);
+void launch_kld_fwd(const float* mu, const float* logvar, size_t n, float* out, float* partial, hipStream_t s);
+void launch_kld_bwd(const float* mu, const float* logvar, const float* upstream, size_t n, float* dmu, float* dlogvar, hipStream_t s);
+void launch_reparam_fwd(const float* mu, const float* logvar, const float* eps, size_t n, float* z, hipStream_t s);
+void launch_reparam_bwd(const float* dz, const float* logvar, const float* eps, size_t n, float* dmu, float* dlogvar, hipStream_t s);
+
+// developer routing flags (ICN_DEBUG / icn_set_debug_flags): 16 = convs on k_gather_gemm, 32 = wgrads on k_wgrad
+int debug_flags();
+int set_debug_flags(int flags);
 
 // ---- optional per-launch HIP-event timing of the MFMA kernels (bench.py's live roofline measurement) ----------
 enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA_64x64, PROF_GG_128x128, PROF_GG_128x64,

@@ -1,6 +1,8 @@
 // Point-to-point loss of the training step on the HIP path (reference losses.py:10-85 Point2Point_Loss; mesh helpers as
 // restated in geniconet_amd/losses.py: vertex normals = area-weighted face-normal sums, generate.py:20-43; Laplacian =
-// uniform umbrella mean(1-ring) - v).  HBM/L2-bound, a few tens of microseconds; replaces ~25 torch launches per step.
+// uniform umbrella mean(1-ring) - v by default -- upstream's mesh.utils.compute_laplacian is absent, so its sign and
+// normalisation are a parameter: lap_mode bit 0 = opposite sign (v - mean), bit 1 = valence-weighted (sum(ring) - k v)).
+// HBM/L2-bound, a few tens of microseconds; replaces ~25 torch launches per step.
 //
 //   v[b, i]   i < P: network output pixel i (channels-last (B, P, 3));  i = P, P + 1: N / S pole = mean of 5 corner pixels
 //   terms[0] = mean_{b,i,c} (v - t_pos)^2           terms[1] = mean_{b,i} (1 - cos(unit vertex normal, t_nor))
@@ -11,12 +13,13 @@
 // Backward (d terms[3] / d grid), all in gather form over the incident-face table, so no atomics and no write conflicts
 // (derivation and finite-difference check: oracle/loss_ref.py p2p_grad):
 //   position : 2 f_pos (v - t_pos) / (3 B V)
-//   Laplacian: e_i = lap_i - t_lap,i, k_i = valence:  2 f_lap (sum_{i in ring(j)} e_i / k_i - e_j) / (3 B V)      (ring symmetric)
+//   Laplacian: lap_i = c_i (mean(ring_i) - v_i), c_i = +-1 or +-k_i (lap_mode), e_i = lap_i - t_lap,i, k_i = valence:
+//              2 f_lap (sum_{i in ring(j)} c_i e_i / k_i - c_j e_j) / (3 B V)                                    (ring symmetric)
 //   normal   : w_i = sum of the face normals at i, u = w / |w|, c = u . t^ (t^ = t_nor / |t_nor|);
 //              h_i = d(1 - c_i) / d w_i = -(t^ - (u . t^) u) / |w_i|;  face (j, p, q): d/d v_j = (h_j + h_p + h_q) x (v_q - v_p);
 //              times f_nor / (B V).   Where a normalisation clamp is active (|w| <= 1e-10, |t_nor| <= 1e-8) h_i = 0.
 //   vertex -> grid: pixels directly; a pole is the mean of its 5 corner pixels, each gets a fifth of the pole's gradient.
-// k_p2p_bwd_prep stores e_i / k_i and h_i per vertex (6 floats), k_p2p_bwd gathers.
+// k_p2p_bwd_prep stores c_i e_i / k_i and h_i per vertex (6 floats), k_p2p_bwd gathers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -55,6 +58,12 @@ __device__ __forceinline__ f3 vertex(const float* __restrict__ g, int b, int j, 
 
 constexpr int LOSS_BLOCK = 256;
 
+// factor c_i of the Laplacian convention: lap_i = c_i (mean(ring_i) - v_i)
+__device__ __forceinline__ float lap_factor(int lap_mode, int k) {
+    const float w = (lap_mode & 2) ? (float)k : 1.f;
+    return (lap_mode & 1) ? -w : w;
+}
+
 // fixed-order block sum of three values; result valid in thread 0
 __device__ __forceinline__ void block_sum3(float& a, float& b, float& c) {
     __shared__ float red[3][LOSS_BLOCK / 64];
@@ -76,7 +85,7 @@ __device__ __forceinline__ void block_sum3(float& a, float& b, float& c) {
 
 __global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_fwd(const float* __restrict__ g, const float* __restrict__ target,
                                                          const int32_t* __restrict__ vf, float* __restrict__ partial, int B, int P,
-                                                         int n) {
+                                                         int n, int lap_mode) {
     const int V = P + 2;
     const long idx = (long)blockIdx.x * LOSS_BLOCK + threadIdx.x;
     float e_pos = 0.f, e_nor = 0.f, e_lap = 0.f;
@@ -105,9 +114,9 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_fwd(const float* __restrict_
         // F.cosine_similarity(u, tn, eps = 1e-8): each norm clamped separately
         const float cs = dot(u, tn) / (fmaxf(sqrtf(dot(u, u)), 1e-8f) * fmaxf(sqrtf(dot(tn, tn)), 1e-8f));
         e_nor = 1.f - cs;
-        const float inv = 1.f / (float)k;
-        const f3 lp = f3{ring.x * inv, ring.y * inv, ring.z * inv} - v;
-        const f3 dl = lp - tl;
+        const float inv = 1.f / (float)k, cf = lap_factor(lap_mode, k);
+        const f3 um = f3{ring.x * inv, ring.y * inv, ring.z * inv} - v;
+        const f3 dl = f3{cf * um.x, cf * um.y, cf * um.z} - tl;
         e_lap = dot(dl, dl);
     }
     block_sum3(e_pos, e_nor, e_lap);
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_bwd_pos(const float* __restr
 // per vertex: aux[0:3] = (lap - t_lap) / k,  aux[3:6] = h = d(1 - cos) / d w  (see the header comment)
 __global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_bwd_prep(const float* __restrict__ g, const float* __restrict__ target,
                                                               const int32_t* __restrict__ vf, float* __restrict__ aux, int B, int P,
-                                                              int n) {
+                                                              int n, int lap_mode) {
     const int V = P + 2;
     const long idx = (long)blockIdx.x * LOSS_BLOCK + threadIdx.x;
     if (idx >= (long)B * V) return;
@@ -193,8 +202,9 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_bwd_prep(const float* __rest
         ring = ring + vp;
         ++k;
     }
-    const float inv = 1.f / (float)k;
-    const f3 e = f3{ring.x * inv, ring.y * inv, ring.z * inv} - v - tl;
+    const float inv = 1.f / (float)k, cf = lap_factor(lap_mode, k);
+    const f3 um = f3{ring.x * inv, ring.y * inv, ring.z * inv} - v;
+    const f3 e = f3{cf * um.x, cf * um.y, cf * um.z} - tl;
     f3 h = {0.f, 0.f, 0.f};
     const float wl = sqrtf(dot(w, w)), tl2 = sqrtf(dot(tn, tn));
     if (wl > 1e-10f && tl2 > 1e-8f) {
@@ -203,7 +213,8 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_bwd_prep(const float* __rest
         h = {-(th.x - c * u.x) / wl, -(th.y - c * u.y) / wl, -(th.z - c * u.z) / wl};
     }
     float* a = aux + (size_t)idx * 6;
-    a[0] = e.x * inv; a[1] = e.y * inv; a[2] = e.z * inv;
+    const float ci = cf * inv;
+    a[0] = e.x * ci; a[1] = e.y * ci; a[2] = e.z * ci;
     a[3] = h.x; a[4] = h.y; a[5] = h.z;
 }
 
@@ -265,9 +276,9 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_p2p_bwd(const float* __restrict_
 int p2p_loss_blocks(int B, int P) { return (int)(((long)B * (P + 2) + LOSS_BLOCK - 1) / LOSS_BLOCK); }
 
 void launch_p2p_loss_fwd(const float* grid, const float* target, const int32_t* vf, float* partial, float* terms, int B, int P, int n,
-                         float f_pos, float f_nor, float f_lap, hipStream_t s) {
+                         float f_pos, float f_nor, float f_lap, int lap_mode, hipStream_t s) {
     const int nb = p2p_loss_blocks(B, P);
-    hipLaunchKernelGGL(k_p2p_fwd, dim3(nb), dim3(LOSS_BLOCK), 0, s, grid, target, vf, partial, B, P, n);
+    hipLaunchKernelGGL(k_p2p_fwd, dim3(nb), dim3(LOSS_BLOCK), 0, s, grid, target, vf, partial, B, P, n, lap_mode);
     const double nv = (double)B * (P + 2);
     hipLaunchKernelGGL(k_p2p_finalize, dim3(1), dim3(LOSS_BLOCK), 0, s, partial, nb, nv * 3.0, nv, f_pos, f_nor, f_lap, terms);
 }
@@ -281,14 +292,98 @@ void launch_p2p_loss_bwd_pos(const float* grid, const float* target, const float
 }
 
 void launch_p2p_loss_bwd(const float* grid, const float* target, const int32_t* vf, const float* upstream, float f_pos, float f_nor,
-                         float f_lap, float* dgrid, float* aux, int B, int P, int n, hipStream_t s) {
+                         float f_lap, int lap_mode, float* dgrid, float* aux, int B, int P, int n, hipStream_t s) {
     if (f_nor == 0.f && f_lap == 0.f) return launch_p2p_loss_bwd_pos(grid, target, upstream, f_pos, dgrid, B, P, n, s);
     const double nv = (double)B * (P + 2);
     const long tv = (long)B * (P + 2), tp = (long)B * P;
     hipLaunchKernelGGL(k_p2p_bwd_prep, dim3((unsigned)((tv + LOSS_BLOCK - 1) / LOSS_BLOCK)), dim3(LOSS_BLOCK), 0, s, grid, target, vf, aux,
-                       B, P, n);
+                       B, P, n, lap_mode);
     hipLaunchKernelGGL(k_p2p_bwd, dim3((unsigned)((tp + LOSS_BLOCK - 1) / LOSS_BLOCK)), dim3(LOSS_BLOCK), 0, s, grid, target, vf, aux,
                        upstream, (float)(2.0 * f_pos / (3.0 * nv)), (float)(2.0 * f_lap / (3.0 * nv)), (float)(f_nor / nv), dgrid, B, P, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// KL term of the VAE loss (reference losses.py:105) and the reparameterisation (models.py:89-92): elementwise over the
+// n = B * D latent values; the sum is two-level with a fixed tree (deterministic).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KLD_MAX_BLOCKS = 1024;
+
+__global__ __launch_bounds__(LOSS_BLOCK) void k_kld_partial(const float* __restrict__ mu, const float* __restrict__ lv, size_t n,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[LOSS_BLOCK / 64];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * LOSS_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * LOSS_BLOCK) {
+        const float m = mu[i], l = lv[i];
+        s += 1.f + l - m * m - __expf(l);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(LOSS_BLOCK) void k_kld_finalize(const float* __restrict__ partial, int nblocks, double scale,
+                                                              float* __restrict__ out) {
+    __shared__ double red[LOSS_BLOCK];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nblocks; k += LOSS_BLOCK) s += (double)partial[k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = LOSS_BLOCK / 2; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] * scale);
+}
+
+__global__ __launch_bounds__(LOSS_BLOCK) void k_kld_bwd(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                         const float* __restrict__ upstream, float inv_n, size_t n,
+                                                         float* __restrict__ dmu, float* __restrict__ dlv) {
+    const float w = upstream[0] * inv_n;
+    for (size_t i = (size_t)blockIdx.x * LOSS_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * LOSS_BLOCK) {
+        dmu[i] = w * mu[i];
+        dlv[i] = 0.5f * w * (__expf(lv[i]) - 1.f);
+    }
+}
+
+__global__ __launch_bounds__(LOSS_BLOCK) void k_reparam_fwd(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                             const float* __restrict__ eps, size_t n, float* __restrict__ z) {
+    for (size_t i = (size_t)blockIdx.x * LOSS_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * LOSS_BLOCK)
+        z[i] = eps[i] * __expf(0.5f * lv[i]) + mu[i];
+}
+
+__global__ __launch_bounds__(LOSS_BLOCK) void k_reparam_bwd(const float* __restrict__ dz, const float* __restrict__ lv,
+                                                             const float* __restrict__ eps, size_t n, float* __restrict__ dmu,
+                                                             float* __restrict__ dlv) {
+    for (size_t i = (size_t)blockIdx.x * LOSS_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * LOSS_BLOCK) {
+        const float g = dz[i];
+        dmu[i] = g;
+        dlv[i] = g * eps[i] * 0.5f * __expf(0.5f * lv[i]);
+    }
+}
+
+static int ew_blocks(size_t n) { return (int)std::min((size_t)KLD_MAX_BLOCKS, (n + LOSS_BLOCK - 1) / LOSS_BLOCK); }
+
+int kld_blocks(size_t n) { return ew_blocks(n); }
+
+void launch_kld_fwd(const float* mu, const float* logvar, size_t n, float* out, float* partial, hipStream_t s) {
+    const int nb = ew_blocks(n);
+    hipLaunchKernelGGL(k_kld_partial, dim3(nb), dim3(LOSS_BLOCK), 0, s, mu, logvar, n, partial);
+    hipLaunchKernelGGL(k_kld_finalize, dim3(1), dim3(LOSS_BLOCK), 0, s, partial, nb, -0.5 / (double)n, out);
+}
+
+void launch_kld_bwd(const float* mu, const float* logvar, const float* upstream, size_t n, float* dmu, float* dlogvar, hipStream_t s) {
+    hipLaunchKernelGGL(k_kld_bwd, dim3(ew_blocks(n)), dim3(LOSS_BLOCK), 0, s, mu, logvar, upstream, (float)(1.0 / (double)n), n, dmu,
+                       dlogvar);
+}
+
+void launch_reparam_fwd(const float* mu, const float* logvar, const float* eps, size_t n, float* z, hipStream_t s) {
+    hipLaunchKernelGGL(k_reparam_fwd, dim3(ew_blocks(n)), dim3(LOSS_BLOCK), 0, s, mu, logvar, eps, n, z);
+}
+
+void launch_reparam_bwd(const float* dz, const float* logvar, const float* eps, size_t n, float* dmu, float* dlogvar, hipStream_t s) {
+    hipLaunchKernelGGL(k_reparam_bwd, dim3(ew_blocks(n)), dim3(LOSS_BLOCK), 0, s, dz, logvar, eps, n, dmu, dlogvar);
 }
 
 }  // namespace icn

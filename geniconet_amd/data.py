@@ -35,7 +35,31 @@ def load_sample(path, subdivisions):
     return lbl2[:3, :-2].reshape(3, -1, 2 * n), lbl2
 
 
-def synthetic_batch(batch, subdivisions, seed, device='cpu'):
+def laplacian_rows(positions, subdivisions, laplacian='mean-v'):
+    """(B, 3, N) vertex positions -> (B, 3, N) Laplacian rows under the convention `laplacian` (losses.LAPLACIAN_MODES)."""
+    nbr = torch.from_numpy(geometry.vertex_neighbours(subdivisions).copy()).to(positions.device)
+    valid = nbr >= 0
+    nbr_w = valid.to(positions.dtype) / valid.sum(1, keepdim=True).to(positions.dtype)
+    return losses.compute_laplacian_batch(positions.transpose(1, 2), nbr.clamp_min(0), nbr_w, laplacian).transpose(1, 2)
+
+
+def detect_laplacian_convention(target, subdivisions, tol=1e-3):
+    """Which convention of losses.LAPLACIAN_MODES reproduces rows 6:9 of `target` (B, 9, N) from its rows 0:3?  Returns
+    (name or None, {name: relative L2 error}).  The reference's datasets carry Laplacians written by the absent
+    mesh.utils.compute_laplacian (generate.py:197): this is how its sign / normalisation is recovered from the data."""
+    t = torch.as_tensor(target, dtype=torch.float64)
+    if t.dim() == 2:
+        t = t[None]
+    want = t[:, 6:9]
+    errs = {}
+    for name in losses.LAPLACIAN_MODES:
+        got = laplacian_rows(t[:, 0:3], subdivisions, name)
+        errs[name] = float((got - want).norm() / want.norm().clamp_min(1e-30))
+    best = min(errs, key=errs.get)
+    return (best if errs[best] < tol else None), errs
+
+
+def synthetic_batch(batch, subdivisions, seed, device='cpu', laplacian='mean-v'):
     """Seeded (input (B,3,5n,2n), target (B,9,N)) fp32 on `device`."""
     g = torch.Generator().manual_seed(seed)
     u = torch.from_numpy(geometry.get_icosahedral_grid(subdivisions)[0]).float()          # (N, 3)
@@ -51,7 +75,7 @@ def synthetic_batch(batch, subdivisions, seed, device='cpu'):
     valid = nbr >= 0
     nbr_w = valid.float() / valid.sum(1, keepdim=True).float()
     normals = losses.compute_vertex_normals(v, faces)
-    lap = losses.compute_laplacian_batch(v, nbr.clamp_min(0), nbr_w)
+    lap = losses.compute_laplacian_batch(v, nbr.clamp_min(0), nbr_w, laplacian)
     target = torch.cat((v, normals, lap), dim=2).transpose(1, 2).contiguous()              # (B, 9, N)
     return target_to_input(target, subdivisions).contiguous(), target
 
@@ -73,15 +97,46 @@ class IcoDataset:
     DataLoader with 2 x cpu_count workers and a host-to-device copy per step (run.py:52,70-75,241-242,714).  An MI355X holds
     288 GB: ModelNet10 at I5 is ~2 GB, so the samples are uploaded once and a batch is an index_select on the device -- no
     workers, no per-step copies.  Batching follows the DataLoader the reference builds: `batch_size` samples, optional
-    shuffle per epoch, the last batch may be short (drop_last=False)."""
+    shuffle per epoch, the last batch may be short (drop_last=False).
 
-    def __init__(self, files, subdivisions, device='cpu'):
+    `laplacian`: the convention the loss will be built with (losses.LAPLACIAN_MODES).  The first sample's rows 6:9 are
+    checked against it (detect_laplacian_convention): a dataset written with another sign / normalisation raises, naming
+    the convention that does match, instead of silently training the Laplacian term towards the wrong curvature;
+    laplacian=None skips the check."""
+
+    def __init__(self, files, subdivisions, device='cpu', laplacian='mean-v'):
         if isinstance(files, str):
             files = list_samples(files)
         if not files:
             raise ValueError('IcoDataset: no samples')
         self.files, self.subdivisions = list(files), subdivisions
         self.targets = torch.from_numpy(np.stack([load_sample(f, subdivisions)[1] for f in self.files])).to(device)
+        self._check_laplacian(laplacian)
+
+    @classmethod
+    def from_tensors(cls, targets, subdivisions, files=None, laplacian='mean-v'):
+        """A dataset over an in-memory (N, 9, V) tensor (synthetic meshes); same checks as the file form."""
+        if targets.dim() != 3 or targets.shape[1:] != (9, geometry.num_vertices(subdivisions)):
+            raise ValueError('IcoDataset.from_tensors: expected (N, 9, %d), got %s'
+                             % (geometry.num_vertices(subdivisions), tuple(targets.shape)))
+        self = object.__new__(cls)
+        self.subdivisions, self.targets = subdivisions, targets
+        self.files = list(files) if files is not None else ['sample%d' % i for i in range(targets.shape[0])]
+        self._check_laplacian(laplacian)
+        return self
+
+    def _check_laplacian(self, laplacian):
+        self.laplacian = laplacian
+        if laplacian is None:
+            return
+        losses.laplacian_code(laplacian)
+        found, errs = detect_laplacian_convention(self.targets[:1].detach().cpu(), self.subdivisions)
+        if found != laplacian and errs[laplacian] >= 1e-3:
+            raise ValueError(
+                'IcoDataset: rows 6:9 of %s are not the %r Laplacian of rows 0:3 (relative error %.3g); %s.  Build the '
+                'dataset and the loss with the same `laplacian=` (losses.LAPLACIAN_MODES), or pass laplacian=None to skip '
+                'this check.' % (self.files[0], laplacian, errs[laplacian],
+                                 'they match %r' % found if found else 'no known convention matches: %s' % errs))
 
     def __len__(self):
         return self.targets.shape[0]
@@ -89,7 +144,7 @@ class IcoDataset:
     def subset(self, indices):
         """A view-like dataset of the given sample indices (the reference splits with torch.utils.data.Subset, run.py:69-74)."""
         other = object.__new__(IcoDataset)
-        other.subdivisions = self.subdivisions
+        other.subdivisions, other.laplacian = self.subdivisions, self.laplacian
         other.files = [self.files[int(i)] for i in indices]
         other.targets = self.targets[torch.as_tensor(list(indices), device=self.targets.device, dtype=torch.long)]
         return other

@@ -113,16 +113,45 @@ def _args(bn):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum)
 
 
+# `num_batches_tracked += 1` of every fused BatchNorm (torch does it inside the module's forward): a model forward has 19 of
+# them, each a kernel launch of its own.  Inside `counters_deferred()` (the model's forward) they are collected and bumped
+# by ONE multi-tensor launch when the outermost scope closes; outside any scope the bump is immediate, as before.
+_pending_counters = []
+_defer_depth = 0
+
+
+class counters_deferred:
+    def __enter__(self):
+        global _defer_depth
+        _defer_depth += 1
+
+    def __exit__(self, *exc):
+        global _defer_depth
+        _defer_depth -= 1
+        if _defer_depth == 0 and _pending_counters:
+            todo = list(_pending_counters)
+            _pending_counters.clear()
+            torch._foreach_add_(todo, 1)
+        return False
+
+
+def _bump(bn):
+    if _defer_depth > 0:
+        _pending_counters.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked.add_(1)
+
+
 def bn_relu(a, bn):
     """relu(bn(a)) -- training-mode BatchNorm2d `bn` (its running statistics are updated)."""
-    bn.num_batches_tracked.add_(1)
+    _bump(bn)
     return _BnReluFn.apply(a, *_args(bn), None, None, None, None, None, 0.0, 0.0)
 
 
 def bn_add_relu(a, bn_a, b, bn_b):
     """relu(bn_a(a) + bn_b(b))."""
-    bn_a.num_batches_tracked.add_(1)
-    bn_b.num_batches_tracked.add_(1)
+    _bump(bn_a)
+    _bump(bn_b)
     return _BnReluFn.apply(a, *_args(bn_a), b, *_args(bn_b))
 
 
@@ -188,3 +217,42 @@ def head(x, seq):
     if can_fuse_head(x, seq):
         return _HeadFn.apply(x, seq[0].weight, seq[0].bias)
     return seq(x)
+
+
+class _ReparamFn(torch.autograd.Function):
+    """z = eps * exp(0.5 * logvar) + mu  (reference models.py:89-92) as one kernel per pass (icn_reparam_fwd / _bwd)
+    instead of exp, mul, mul, add and their four backward kernels."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        L = _lib.lib()
+        m, lv, e = _nhwc(mu), _nhwc(logvar), _nhwc(eps)
+        z = torch.empty_like(m)
+        with torch.cuda.device(m.device):
+            _lib.check(L.icn_reparam_fwd(m.data_ptr(), lv.data_ptr(), e.data_ptr(), m.numel(), z.data_ptr(), _stream()),
+                       'icn_reparam_fwd')
+        ctx.save_for_backward(lv, e)
+        return z.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gz):
+        L = _lib.lib()
+        lv, e = ctx.saved_tensors
+        g = _nhwc(gz)
+        dm, dlv = torch.empty_like(g), torch.empty_like(g)
+        with torch.cuda.device(g.device):
+            _lib.check(L.icn_reparam_bwd(g.data_ptr(), lv.data_ptr(), e.data_ptr(), g.numel(), dm.data_ptr(), dlv.data_ptr(),
+                                         _stream()), 'icn_reparam_bwd')
+        return dm.permute(0, 3, 1, 2), dlv.permute(0, 3, 1, 2), None
+
+
+def reparameterize(mu, logvar):
+    """randn_like(std) * std + mu with std = exp(0.5 * logvar) (reference models.py:89-92).  The noise is drawn by
+    torch.randn_like exactly as the reference draws it (same generator, same shape and strides as std); the arithmetic is
+    one HIP kernel for ROCm fp32 (B, C, H, W) tensors, the reference's torch expression otherwise."""
+    if (not _DISABLED and mu.is_cuda and logvar.is_cuda and mu.dtype == torch.float32 and logvar.dtype == torch.float32
+            and mu.dim() == 4 and mu.shape == logvar.shape and mu.numel() > 0):
+        return _ReparamFn.apply(mu, logvar, torch.randn_like(logvar))
+    std = torch.exp(0.5 * logvar)
+    return torch.randn_like(std) * std + mu

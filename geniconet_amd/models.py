@@ -174,7 +174,8 @@ class ico2ico(nn.Module):
         self.decoder, self.enc2icoConv = createenc2ico(mode, kind, R)
 
     def forward(self, x):
-        return fused.head(self.decoder(self.enc(self.encoder(x))), self.enc2icoConv)
+        with fused.counters_deferred():                  # one num_batches_tracked bump for the 19 BatchNorms
+            return fused.head(self.decoder(self.enc(self.encoder(x))), self.enc2icoConv)
 
 
 class ico2enc(nn.Module):
@@ -215,12 +216,12 @@ class VAE(nn.Module):
         raise NotImplementedError
 
     def reparameterize(self, mu, logvar):
-        std = torch.exp(0.5 * logvar)
-        return torch.randn_like(std) * std + mu
+        return fused.reparameterize(mu, logvar)
 
     def forward(self, x):
-        mu, logvar = self.encode(x)
-        return self.decode(self.reparameterize(mu, logvar)), mu, logvar
+        with fused.counters_deferred():
+            mu, logvar = self.encode(x)
+            return self.decode(self.reparameterize(mu, logvar)), mu, logvar
 
 
 def _latent_head(corner_mode, subdivisions):

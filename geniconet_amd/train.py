@@ -23,6 +23,33 @@ from . import losses, models
 GRAD_BUCKET_MB = 5   # ~4 buckets for the 18.5 MB (AE) / 24 MB (VAE) of fp32 gradients, decoder first
 
 
+def _host_staged_allreduce_hook(world):
+    """DDP communication hook for the one-GPU REHEARSAL only (several ranks share a device and talk over gloo, which has
+    no RCCL): a bucket is copied to pinned host memory, averaged by gloo's CPU all-reduce and copied back.  gloo's own
+    device-tensor path is avoided on purpose: with three or more processes on one device it took seconds to minutes per
+    step and once ended in a SIGSEGV right after the rendezvous.  Production (one rank per GPU, backend
+    'nccl' = RCCL) never takes this path: there DDP's built-in bucketed all-reduce runs on the device."""
+    staging = {}
+
+    def hook(_state, bucket):
+        buf = bucket.buffer()
+        key = (bucket.index(), buf.numel())
+        host = staging.get(key)
+        if host is None:
+            host = staging[key] = torch.empty(buf.numel(), dtype=buf.dtype, pin_memory=True)
+        host.copy_(buf)                                   # blocking copy: waits for the gradients on the current stream
+        fut = dist.all_reduce(host, async_op=True).get_future()
+
+        def finish(_f):
+            with torch.cuda.device(buf.device):
+                host.div_(world)
+                buf.copy_(host)
+            return buf
+        return fut.then(finish)
+    return hook
+
+
+
 def build_model(params, device):
     cls = getattr(models, params['model_name'])
     return cls(params).to(device)
@@ -32,10 +59,11 @@ def build_criterion(params, device):
     """run.py:432-444."""
     ico, loss_kind = params['ico'], params[params['model_name']]['loss']
     args = (ico['subdivisions'], ico['factor_pos'], ico['factor_nor'], ico['factor_lap'])
+    lap = ico.get('laplacian', 'mean-v')            # convention of the target's Laplacian rows (not a reference key)
     if loss_kind == 'p2p':
-        crit = losses.P2P_Loss(*args)
+        crit = losses.P2P_Loss(*args, laplacian=lap)
     elif loss_kind == 'p2pkld':
-        crit = losses.P2PKLD_Loss(*args, 1.)
+        crit = losses.P2PKLD_Loss(*args, 1., laplacian=lap)
     else:
         raise ValueError('loss for %s model not specified' % params['model_name'])
     return crit.to(device)
@@ -56,21 +84,39 @@ class Trainer:
         self.net = self.model
         if self.world > 1:
             ids = [self.device.index] if self.device.type == 'cuda' else None
+            # rehearsal on one GPU: ranks share a device over gloo -> stage every exchange through the host
+            staged = self.device.type == 'cuda' and dist.get_backend() == 'gloo'
+            if staged:
+                self._broadcast_initial_state_via_host()
             self.net = torch.nn.parallel.DistributedDataParallel(
                 self.model, device_ids=ids, bucket_cap_mb=GRAD_BUCKET_MB, gradient_as_bucket_view=True,
-                broadcast_buffers=False)
+                broadcast_buffers=False, init_sync=not staged)
+            if staged:
+                self.net.register_comm_hook(None, _host_staged_allreduce_hook(self.world))
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=cfg['lr'])               # run.py:446
         self.scheduler = None
         if 'lr_base' in cfg and 'lr_max' in cfg:                                               # run.py:448-450
             self.scheduler = torch.optim.lr_scheduler.CyclicLR(self.optimizer, cfg['lr_base'], cfg['lr_max'],
                                                                cycle_momentum=False)
         self.model.train()
+        self.last_output = None
 
-    def step(self, img, lbl):
-        """One batch of run.py:244-254.  Returns the loss tensor (no host sync)."""
+    def _broadcast_initial_state_via_host(self):
+        """Rank 0's parameters and buffers to every rank through CPU tensors (what DDP's init_sync does on the device)."""
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                host = t.detach().cpu()
+                dist.broadcast(host, src=0)
+                t.copy_(host)
+
+    def step(self, img, lbl, keep_output=False):
+        """One batch of run.py:244-254.  Returns the loss tensor (no host sync).  keep_output: leave the model's output
+        of this batch in self.last_output (the reference's train() keeps the last one for the VAE `misc`, run.py:274-276)."""
         ctx = torch.autograd.detect_anomaly() if self.anomaly else contextlib.nullcontext()
         with ctx:
             output = self.net(img)
+            if keep_output:
+                self.last_output = output
             loss = self.criterion(output, lbl)
             self.optimizer.zero_grad()
             loss.backward()
@@ -140,11 +186,20 @@ def load_checkpoint(model, log_dir, model_name, epoch=0, optimizer=None):
 
 
 # ---- epoch loops (run.py:233-316) over a device-resident dataset (data.IcoDataset) -----------------------------------------
-def train_epoch(trainer, dataset, batch_size, shuffle=True, generator=None):
+def train_epoch(trainer, dataset, batch_size, shuffle=True, generator=None, misc=None):
     """One pass of run.py:233-278 (train()): model in train mode, one Trainer.step per batch.  Returns the per-batch losses
-    as one device tensor (a single host sync when the caller reads it, instead of one per iteration)."""
+    as one device tensor (a single host sync when the caller reads it, instead of one per iteration).  For the VAE losses
+    ('p2pkld') the reference returns misc = {'trn_mean', 'trn_logvar'} = mu / logvar of the LAST batch (run.py:274-276),
+    which its checkpoints carry and enc2ico_vae.createSample reads (models.py:329-332): pass a dict as `misc` to receive
+    them."""
     trainer.model.train()
-    losses_ = [trainer.step(img, lbl) for img, lbl in dataset.batches(batch_size, shuffle, generator)]
+    want_misc = misc is not None and trainer.params[trainer.params['model_name']]['loss'] == 'p2pkld'
+    losses_ = []
+    for img, lbl in dataset.batches(batch_size, shuffle, generator):
+        losses_.append(trainer.step(img, lbl, keep_output=want_misc))
+    if want_misc and trainer.last_output is not None:
+        misc['trn_mean'], misc['trn_logvar'] = trainer.last_output[1].detach(), trainer.last_output[2].detach()
+        trainer.last_output = None
     return torch.stack(losses_)
 
 
@@ -154,15 +209,30 @@ def validate(trainer, dataset, batch_size):
     return float(torch.stack([trainer.evaluate(img, lbl) for img, lbl in dataset.batches(batch_size)]).mean())
 
 
-def fit(trainer, trn, val, epochs, batch_size, log_dir=None, model_name=None, seed=0, first_epoch=1, best_loss=float('inf')):
-    """The reference's epoch loop: train, validate, keep the best models.  A checkpoint '<name>_EB<epoch>.pt' is written
-    whenever the validation loss does not exceed the best so far, and all but the newest six are deleted (saveBestModel,
-    run.py:317-329).  Returns a list of (epoch, mean training loss, validation loss)."""
+def fit(trainer, trn, val, epochs, batch_size, log_dir=None, model_name=None, seed=0, first_epoch=1, best_loss=float('inf'),
+        save_epoch_freq=None):
+    """The reference's epoch loop (run.py:479-496): train, validate, keep the best models, anneal the KL factor.
+      * '<name>_EB<epoch>.pt' is written whenever the validation loss does not exceed the best so far, and all but the
+        newest six are deleted (saveBestModel, run.py:317-329);
+      * '<name>_E<epoch>.pt' every `save_epoch_freq` epochs (run.py:488-489; default: the model's 'save_epoch_freq' entry
+        of params when present) and once more after the last epoch (run.py:495-496; never overwrites);
+      * every checkpoint carries misc = {'trn_mean', 'trn_logvar'} of the epoch's last training batch for the VAE losses
+        (run.py:274-276), None for the auto-encoder;
+      * after each epoch criterion.update_factor(epoch, factor_step_size, factor_gamma) when the model's params hold both
+        keys (run.py:491-493: the VAE's KL factor x 0.9 every 25 epochs).
+    `epoch` counts from 1 as in the reference's calls (its loop variable + 1).  Returns a list of
+    (epoch, mean training loss, validation loss)."""
     name = model_name or trainer.params['model_name']
+    cfg = trainer.params[trainer.params['model_name']]
+    if save_epoch_freq is None:
+        save_epoch_freq = cfg.get('save_epoch_freq', 0)
     gen = torch.Generator().manual_seed(seed)
     history = []
+    misc, val_loss, epoch = None, None, first_epoch - 1
     for epoch in range(first_epoch, first_epoch + epochs):
-        trn_loss = float(train_epoch(trainer, trn, batch_size, True, gen).mean())
+        got = {}
+        trn_loss = float(train_epoch(trainer, trn, batch_size, True, gen, misc=got).mean())
+        misc = got or None
         val_loss = validate(trainer, val, batch_size)
         history.append((epoch, trn_loss, val_loss))
         if log_dir is not None and val_loss <= best_loss:
@@ -170,7 +240,12 @@ def fit(trainer, trn, val, epochs, batch_size, log_dir=None, model_name=None, se
                 old = sorted(glob.glob(os.path.join(log_dir, 'savedModel', name + '_EB*[0-9]*.pt')), key=_natural_key)
                 for path in old[:max(0, len(old) - 5)]:
                     os.remove(path)
-            save_checkpoint(trainer, log_dir, 'B%d' % epoch, val_loss=val_loss, model_name=name)
+            save_checkpoint(trainer, log_dir, 'B%d' % epoch, val_loss=val_loss, misc=misc, model_name=name)
             best_loss = val_loss
+        if log_dir is not None and save_epoch_freq and epoch % save_epoch_freq == 0:
+            save_checkpoint(trainer, log_dir, epoch, val_loss=val_loss, misc=misc, model_name=name)
+        if 'factor_step_size' in cfg and 'factor_gamma' in cfg and hasattr(trainer.criterion, 'update_factor'):
+            trainer.criterion.update_factor(epoch, cfg['factor_step_size'], cfg['factor_gamma'])
+    if log_dir is not None and epochs > 0:
+        save_checkpoint(trainer, log_dir, epoch, val_loss=val_loss, misc=misc, model_name=name)
     return history
-

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ICN_ABI_VERSION 2
+#define ICN_ABI_VERSION 3
 
 #define ICN_CORNER_ZEROS 0
 #define ICN_CORNER_AVERAGE 1
@@ -114,7 +114,11 @@ int icn_head_bwd(const float* dy, const float* y, const float* x, const float* w
                  int M, int Cin, int Cout, void* stream);
 
 /* Point-to-point loss of the training step (reference losses.py:10-85 Point2Point_Loss.forward; the absent mesh helpers as
- * restated from generate.py:20-43: area-weighted vertex normals; uniform Laplacian mean(1-ring) - v).
+ * restated from generate.py:20-43: area-weighted vertex normals; uniform Laplacian).
+ *   lap_mode           convention of the Laplacian rows (upstream's mesh.utils.compute_laplacian, generate.py:197, is absent,
+ *                      so sign and normalisation are the caller's choice): ICN_LAP_MEAN_MINUS_V (default of the Python
+ *                      surface) = mean(1-ring) - v; | ICN_LAP_FLIP = v - mean(1-ring); | ICN_LAP_VALENCE = times the valence,
+ *                      i.e. sum(1-ring) - k v (with FLIP: k v - sum)
  *   grid   (B, P, 3)   network output, channels-last; vertices = pixels, then N / S pole = mean of their 5 corner pixels
  *                      (ico_utils.py:10-24, losses.py:47-51)
  *   target (B, 9, V)   V = P + 2: rows 0:3 positions, 3:6 normals, 6:9 Laplacians (data.py:64-69)
@@ -125,12 +129,29 @@ int icn_head_bwd(const float* dy, const float* y, const float* x, const float* w
  * no atomics).  Where a normalisation clamp of the normal term is active (|vertex normal| <= 1e-10 or |target normal| <= 1e-8)
  * that vertex contributes no normal-term gradient.  upstream: device scalar dLoss/dterms[3].
  * ws: icn_p2p_loss_workspace_floats / icn_p2p_loss_bwd_workspace_floats (B, r) floats.  Deterministic (fixed two-level sums). */
+#define ICN_LAP_MEAN_MINUS_V 0
+#define ICN_LAP_FLIP 1
+#define ICN_LAP_VALENCE 2
 size_t icn_p2p_loss_workspace_floats(int B, int r);
-int icn_p2p_loss_fwd(const float* grid, const float* target, int B, int r, float f_pos, float f_nor, float f_lap, float* terms,
-                     float* ws, void* stream);
+int icn_p2p_loss_fwd(const float* grid, const float* target, int B, int r, float f_pos, float f_nor, float f_lap, int lap_mode,
+                     float* terms, float* ws, void* stream);
 size_t icn_p2p_loss_bwd_workspace_floats(int B, int r);
 int icn_p2p_loss_bwd(const float* grid, const float* target, const float* upstream, int B, int r, float f_pos, float f_nor,
-                     float f_lap, float* dgrid, float* ws, void* stream);
+                     float f_lap, int lap_mode, float* dgrid, float* ws, void* stream);
+
+/* KL term of the VAE loss (reference losses.py:105):  out[0] = mean_b(-0.5 * mean_d(1 + logvar - mu^2 - exp(logvar)))
+ * = -0.5 / n * sum over all n = B * D elements.  mu / logvar: n contiguous floats in the same element order.
+ * Deterministic two-level sum; ws >= icn_kld_workspace_floats(n) floats.
+ * icn_kld_bwd: dmu = upstream * mu / n,  dlogvar = upstream * 0.5 * (exp(logvar) - 1) / n   (upstream: device scalar). */
+size_t icn_kld_workspace_floats(size_t n);
+int icn_kld_fwd(const float* mu, const float* logvar, size_t n, float* out, float* ws, void* stream);
+int icn_kld_bwd(const float* mu, const float* logvar, const float* upstream, size_t n, float* dmu, float* dlogvar, void* stream);
+
+/* Reparameterisation of the VAE (reference models.py:89-92):  z = eps * exp(0.5 * logvar) + mu, n contiguous floats each;
+ * the caller draws eps (torch.randn_like in the reference).  Backward: dmu = dz, dlogvar = dz * eps * 0.5 * exp(0.5 * logvar)
+ * (dmu may alias dz's storage only if the caller no longer needs dz). */
+int icn_reparam_fwd(const float* mu, const float* logvar, const float* eps, size_t n, float* z, void* stream);
+int icn_reparam_bwd(const float* dz, const float* logvar, const float* eps, size_t n, float* dmu, float* dlogvar, void* stream);
 
 /* Host-side introspection (no device needed).  Each writes at most `cap` elements and returns the element
  * count required (negative on error). */
@@ -142,7 +163,8 @@ long icn_table_faces(int r, int32_t* out, size_t cap);                          
 
 /* Optional diagnostics: HIP-event timing of every MFMA kernel launch between start and stop, on the launch
  * stream.  `stop` synchronises the device and returns the number of entries written (one per kernel that ran).
- * total_flops is ALGORITHMIC: 2*7*Cin*Cout*B*P_out per launch.  Not thread-safe; off by default. */
+ * total_flops is ALGORITHMIC: 2*7*Cin*Cout*B*P_out per conv pass (the small virtual-row launch of a stride-1 bwd-data adds time,
+ * not FLOPs).  The 2 * max_launches events are created once and reused.  Off by default. */
 typedef struct icn_profile_entry {
     const char* kernel;
     long launches;
@@ -151,6 +173,10 @@ typedef struct icn_profile_entry {
 } icn_profile_entry;
 int icn_profile_start(int max_launches);
 int icn_profile_stop(icn_profile_entry* out, int cap);
+
+/* Developer routing flags (same bits as the ICN_DEBUG environment variable, which only sets the initial value):
+ * 16 = convolutions on the register-staged fallback kernel, 32 = weight gradients on it.  Returns the previous flags. */
+int icn_set_debug_flags(int flags);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,8 @@
 
 Follows /root/reference/losses.py:47-82 (Point2Point_Loss.forward), :105 (KLD), :137-142 (P2PKLD), with the
 absent mesh helpers restated as: vertex normals = /root/reference/generate.py:20-43 (mesh_vertexnormals,
-area-weighted), Laplacian = uniform umbrella mean(1-ring) - v (upstream unpinned).  float64 throughout.
+area-weighted), Laplacian = uniform umbrella mean(1-ring) - v (upstream unpinned; `lap_mode` restates the other
+conventions the product offers: bit 0 = v - mean, bit 1 = times the valence, i.e. sum(ring) - k v).  float64 throughout.
 """
 import numpy as np
 
@@ -27,7 +28,7 @@ def vertex_normals(v, f, eps=1e-10):                      # generate.py:20-43, o
     return vn / np.clip(np.sqrt((vn ** 2).sum(1)), eps, None)[:, None]
 
 
-def laplacian(v, f):
+def laplacian(v, f, lap_mode=0):
     n = v.shape[0]
     acc, deg = np.zeros_like(v), np.zeros(n)
     seen = set()
@@ -37,10 +38,13 @@ def laplacian(v, f):
                 seen.add((u, w)); seen.add((w, u))
                 acc[u] += v[w]; acc[w] += v[u]
                 deg[u] += 1; deg[w] += 1
-    return acc / deg[:, None] - v
+    lap = acc / deg[:, None] - v
+    if lap_mode & 2:
+        lap = lap * deg[:, None]
+    return -lap if lap_mode & 1 else lap
 
 
-def p2p_terms(pred, target, r):
+def p2p_terms(pred, target, r, lap_mode=0):
     """pred (B,3,5n,2n), target (B,9,N) -> (mse_pos, mean(1-cos), mse_lap)  (losses.py:66-80)."""
     pred, target = np.asarray(pred, np.float64), np.asarray(target, np.float64)
     f = faces_from_lattice(r)
@@ -51,7 +55,7 @@ def p2p_terms(pred, target, r):
         nrm, tn = vertex_normals(v[b], f), t[b, :, 3:6]
         den = np.maximum(np.linalg.norm(nrm, axis=1) * np.linalg.norm(tn, axis=1), 1e-8)   # CosineSimilarity eps
         cos.append(1 - (nrm * tn).sum(1) / den)
-        lap_err.append((laplacian(v[b], f) - t[b, :, 6:9]) ** 2)
+        lap_err.append((laplacian(v[b], f, lap_mode) - t[b, :, 6:9]) ** 2)
     return ((v - t[:, :, :3]) ** 2).mean(), np.mean(cos), np.mean(lap_err)
 
 
@@ -70,11 +74,12 @@ def p2p_pos_grad(pred, target, r):
     return g
 
 
-def p2p_grad(pred, target, r, f_pos, f_nor, f_lap):
+def p2p_grad(pred, target, r, f_pos, f_nor, f_lap, lap_mode=0):
     """d p2p_loss / d pred, (B,3,5n,2n), analytic (float64; checked against finite differences of p2p_loss in
     tests/test_oracle_properties.py).  Generic inputs only: the eps clamps of the normalisations are assumed inactive.
       position : 2 (v - a) / (3 B N)
-      Laplacian: with e_i = lap_i - l_i and k_i the valence, 2 (sum_{i in ring(j)} e_i / k_i - e_j) / (3 B N)
+      Laplacian: lap_i = c_i (mean(ring_i) - v_i) with c_i = +-1 or +-k_i (lap_mode), e_i = lap_i - l_i, k_i the valence:
+                 2 (sum_{i in ring(j)} c_i e_i / k_i - c_j e_j) / (3 B N)
       normal   : w_i = sum of the normals n_f of the faces at i, u = w / |w|, c = u . t / |t|;
                  h_i = d(1 - c_i) / d w_i = -(t^ - (u . t^) u) / |w_i|;  a face (a, b, c) with n = (b - a) x (c - a) passes
                  G = h_a + h_b + h_c back as  d/da = G x (c - b),  d/db = G x (a - c),  d/dc = G x (b - a);  all / (B N)
@@ -91,10 +96,11 @@ def p2p_grad(pred, target, r, f_pos, f_nor, f_lap):
     for a, b, c in f:
         ring[a].update((b, c)); ring[b].update((a, c)); ring[c].update((a, b))
     for bi in range(B):
-        e = laplacian(v[bi], f) - t[bi, :, 6:9]
+        e = laplacian(v[bi], f, lap_mode) - t[bi, :, 6:9]
         k = np.array([len(s_) for s_ in ring], np.float64)
-        ek = e / k[:, None]
-        gl = -e.copy()
+        cf = (k if lap_mode & 2 else np.ones_like(k)) * (-1.0 if lap_mode & 1 else 1.0)
+        ek = e * (cf / k)[:, None]
+        gl = -e * cf[:, None]
         for j in range(N):
             for i in ring[j]:
                 gl[j] += ek[i]
@@ -121,8 +127,8 @@ def p2p_grad(pred, target, r, f_pos, f_nor, f_lap):
     return g
 
 
-def p2p_loss(pred, target, r, f_pos, f_nor, f_lap):
-    a, b, c = p2p_terms(pred, target, r)
+def p2p_loss(pred, target, r, f_pos, f_nor, f_lap, lap_mode=0):
+    a, b, c = p2p_terms(pred, target, r, lap_mode)
     return f_pos * a + f_nor * b + f_lap * c
 
 
@@ -130,3 +136,9 @@ def kld(mu, logvar):                                      # losses.py:105
     mu = np.asarray(mu, np.float64).reshape(mu.shape[0], -1)
     lv = np.asarray(logvar, np.float64).reshape(logvar.shape[0], -1)
     return np.mean(-0.5 * np.mean(1 + lv - mu ** 2 - np.exp(lv), axis=1))
+
+
+def kld_grad(mu, logvar):
+    """d kld / d mu = mu / n,  d kld / d logvar = 0.5 (exp(logvar) - 1) / n,  n = number of elements."""
+    mu, lv = np.asarray(mu, np.float64), np.asarray(logvar, np.float64)
+    return mu / mu.size, 0.5 * (np.exp(lv) - 1.0) / lv.size

@@ -1,0 +1,347 @@
+"""GPU parity of the TRAINING path against the CPU oracle (round-2 additions; VERDICT r1 "close the parity-coverage holes"):
+a multi-step trajectory (Adam + CyclicLR, BatchNorm running statistics), whole-VAE gradients with a fixed eps, eval-mode /
+test-time forwards of the full models and of the four inference halves, the VAE loss (P2P + KLD) value and gradient, the
+KLD / reparameterisation kernels, every Laplacian convention, full-size steps (determinism), and BatchNorm with
+|mean| >> std.  Everything runs through the C ABI (libicn.so); the oracle is only the checker.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import loss_ref, models_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _product(ref, name, R):
+    from geniconet_amd import models
+    net = getattr(models, name)(models.default_params(name, subdivisions=R))
+    net.load_state_dict(ref.state_dict(), strict=True)
+    return net.cuda()
+
+
+def _zero_true_gradient(key):
+    """Conv biases in front of a train-mode BatchNorm: BN removes the mean, so their true gradient is exactly zero and both
+    sides only hold rounding noise there (which Adam then normalises to full-size steps)."""
+    return key.endswith('.bias') and ('.conv0' in key or '.conv1' in key or key in ('encoder.0.bias', 'mu.0.bias', 'logvar.0.bias'))
+
+
+# ---- (a) training trajectory: reference run.py:244-254 over several batches -------------------------------------------------
+@pytest.mark.parametrize('name', ['ico2ico', 'ico2ico_vae'])
+def test_training_trajectory_matches_the_oracle_trainer(name, monkeypatch):
+    """Product Trainer on the GPU vs the same Trainer class driving the oracle network on the CPU, from one state_dict:
+    forward -> loss -> zero_grad -> backward -> Adam -> CyclicLR for 3 batches (a different batch each step).
+    Bounds: per-step loss 1e-4 relative; BatchNorm running statistics 1e-4 rel-L2; the weight UPDATE of every tensor with a
+    non-zero true gradient 5e-2 rel-L2 (Adam divides by sqrt(v): elements whose gradient is at rounding-noise level move by
+    +-lr on either side, so the update w - w_init is what is compared; zero-initialised parameters ARE their update)."""
+    from geniconet_amd import data, models
+    from geniconet_amd.train import Trainer, build_criterion
+    R, B, STEPS = 3, 3, 3
+    p = models.default_params(name, subdivisions=R)
+    p[name].update(lr=1e-4, lr_base=1e-4, lr_max=1e-3)          # the reference's 1e-9 .. 1e-3 cycle moves nothing in 3 steps
+    torch.manual_seed(5)
+    ref = getattr(models_ref, name)(R=R).train()
+    init = copy.deepcopy(ref.state_dict())
+    gpu = Trainer(p, 'cuda', model=_product(ref, name, R))
+    cpu = Trainer(p, 'cpu', model=ref, criterion=build_criterion(p, 'cpu'), channels_last=False)
+    if name == 'ico2ico_vae':
+        # the same noise on both sides: the product draws it with torch.randn_like (as the reference does, models.py:91)
+        n = 2 ** (R - 3)
+        noise = [torch.randn(B, 512, 5 * n, 2 * n, generator=torch.Generator().manual_seed(70 + k)) for k in range(STEPS)]
+        draws = {'cuda': 0, 'cpu': 0}
+
+        def fixed_randn_like(t, **kw):
+            k = draws[t.device.type]
+            draws[t.device.type] += 1
+            return noise[k].to(t.device)
+        monkeypatch.setattr(torch, 'randn_like', fixed_randn_like)
+    for k in range(STEPS):
+        x, t = data.synthetic_batch(B, R, seed=40 + k)
+        lg = float(gpu.step(x.cuda().contiguous(memory_format=torch.channels_last), t.cuda()))
+        lc = float(cpu.step(x, t))
+        assert abs(lg - lc) <= 1e-4 * abs(lc), (k, lg, lc)
+    sg, sc = gpu.model.state_dict(), cpu.model.state_dict()
+    assert list(sg) == list(sc)
+    for key, vc in sc.items():
+        vg = sg[key].cpu()
+        if 'num_batches_tracked' in key:
+            assert int(vg) == int(vc) == STEPS, key
+        elif 'running' in key:
+            assert rel_l2(vg.numpy(), vc.numpy()) < 1e-4, key
+        elif not _zero_true_gradient(key):
+            du_g, du_c = (vg - init[key]).numpy(), (vc - init[key]).numpy()
+            assert np.linalg.norm(du_c) > 0, key
+            assert rel_l2(du_g, du_c) < 5e-2, (key, rel_l2(du_g, du_c))
+    assert abs(gpu.scheduler.get_last_lr()[0] - cpu.scheduler.get_last_lr()[0]) < 1e-12
+
+
+# ---- (b) whole-VAE gradients with a fixed eps ----------------------------------------------------------------------------------
+def test_vae_forward_and_gradients_with_fixed_noise(monkeypatch):
+    """ico2ico_vae.forward (encode -> reparameterise -> decode, reference models.py:89-97) and the gradient of the full VAE
+    objective 0.6/0.2/0.2 + KLD (run.py:694-696, losses.py:137-142) with respect to every parameter, against
+    oracle.models_ref.ico2ico_vae.forward(x, eps) + the torch formulation of the loss on the CPU."""
+    from geniconet_amd import data, models
+    from geniconet_amd.train import build_criterion
+    R, B = 3, 3
+    torch.manual_seed(21)
+    ref = models_ref.ico2ico_vae(R=R).train()
+    net = _product(ref, 'ico2ico_vae', R).train()
+    p = models.default_params('ico2ico_vae', subdivisions=R)
+    crit_g, crit_c = build_criterion(p, 'cuda'), build_criterion(p, 'cpu')
+    x, t = data.synthetic_batch(B, R, seed=9)
+    eps = torch.randn(B, 512, 5, 2, generator=torch.Generator().manual_seed(3))
+    out_r = ref(x, eps)
+    crit_c(out_r, t).backward()
+    monkeypatch.setattr(torch, 'randn_like', lambda s, **kw: eps.to(s.device))
+    out_g = net(x.cuda().contiguous(memory_format=torch.channels_last))
+    loss_g = crit_g(out_g, t.cuda())
+    loss_g.backward()
+    for k, (a, b) in enumerate(zip(out_g, out_r)):
+        assert rel_l2(a.detach().cpu().numpy(), b.detach().numpy()) < TOL, k
+    assert abs(float(loss_g) - float(crit_c.loss)) <= 1e-4 * abs(float(crit_c.loss))
+    gr = dict(ref.named_parameters())
+    floor = 1e-3 * max(float(q.grad.norm()) for q in gr.values())
+    errs = {k: float((q.grad.cpu() - gr[k].grad).norm()) / max(float(gr[k].grad.norm()), floor)
+            for k, q in net.named_parameters()}
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 2e-3, (worst, errs[worst])
+    assert set(errs) == set(gr) and len(errs) == 2 * 17 + 2 * 19 + 2          # every conv / BN / head parameter has a gradient
+
+
+# ---- (c) eval mode and the test-time path ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['ico2ico', 'ico2ico_vae'])
+def test_eval_mode_forward_matches_the_oracle(name):
+    """validate() (run.py:280-296) and app.py:1447-1454 run the model in eval mode: HIP convolutions + BatchNorm on running
+    statistics.  The statistics are made non-trivial by two training-mode batches on the oracle first.  Full models and the
+    four inference halves (reference models.py:234-252,302-340), the latter restored by the reference's key filter
+    (run.py:360-367); also Trainer.evaluate's loss, and experiment_test's variant with BatchNorm left in training mode
+    (run.py:516)."""
+    from geniconet_amd import data, models
+    from geniconet_amd.train import Trainer, build_criterion
+    R, B = 3, 3
+    torch.manual_seed(31)
+    ref = getattr(models_ref, name)(R=R).train()
+    with torch.no_grad():
+        for k in range(2):
+            ref(data.synthetic_batch(4, R, seed=60 + k)[0])
+    ref.eval()
+    net = _product(ref, name, R).eval()
+    x, t = data.synthetic_batch(B, R, seed=8)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last)
+    p = models.default_params(name, subdivisions=R)
+
+    def restore(half):
+        md = half.state_dict()
+        half.load_state_dict({k: v for k, v in ref.state_dict().items() if k in md})
+        return half.cuda().eval()
+
+    with torch.no_grad():
+        if name == 'ico2ico':
+            want = ref(x)
+            assert rel_l2(net(xg).cpu().numpy(), want.numpy()) < TOL
+            enc, dec = restore(models.ico2enc(p)), restore(models.enc2ico(p))
+            lat = enc(xg)
+            assert rel_l2(lat.cpu().numpy(), ref.encoder(x).numpy()) < TOL
+            assert rel_l2(dec(lat).cpu().numpy(), want.numpy()) < TOL
+            crit = build_criterion(p, 'cpu')
+            tr = Trainer(p, 'cuda', model=net)
+            got = float(tr.evaluate(xg, t.cuda()))
+            assert abs(got - float(crit(want, t))) <= 1e-4 * abs(got) and tr.model.training
+            tr.model.eval()
+        else:
+            mu_r, lv_r = ref.encode(x)
+            mu_g, lv_g = net.encode(xg)
+            assert rel_l2(mu_g.cpu().numpy(), mu_r.numpy()) < TOL and rel_l2(lv_g.cpu().numpy(), lv_r.numpy()) < TOL
+            z = torch.randn(B, 512, 5, 2, generator=torch.Generator().manual_seed(1))
+            want = ref.decode(z)
+            assert rel_l2(net.decode(z.cuda()).cpu().numpy(), want.numpy()) < TOL
+            enc, dec = restore(models.ico2enc_vae(p)), restore(models.enc2ico_vae(p))
+            mu_h, lv_h = enc(xg)
+            assert rel_l2(mu_h.cpu().numpy(), mu_r.numpy()) < TOL and rel_l2(lv_h.cpu().numpy(), lv_r.numpy()) < TOL
+            assert rel_l2(dec(z.cuda())[0].cpu().numpy(), want.numpy()) < TOL
+        # experiment_test leaves the freshly built model in training mode under no_grad (run.py:516): batch statistics
+        ref.train()
+        net.train()
+        if name == 'ico2ico':
+            assert rel_l2(net(xg).cpu().numpy(), ref(x).numpy()) < TOL
+        else:
+            mu_r, _ = ref.encode(x)
+            assert rel_l2(net.encode(xg)[0].cpu().numpy(), mu_r.numpy()) < TOL
+
+
+# ---- (d) VAE loss on the device ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('factor_kl', [1.0, 0.81])
+def test_p2pkld_loss_value_and_gradient_match_the_oracle(factor_kl):
+    """P2PKLD_Loss.forward (reference losses.py:137-142) = P2P(0.6, 0.2, 0.2) + factor_kl * KLD (losses.py:105): value, the
+    reported terms, and the gradients with respect to the reconstruction, mu and logvar, against oracle/loss_ref.py."""
+    from geniconet_amd.losses import P2PKLD_Loss
+    r, B = 3, 2
+    g = torch.Generator().manual_seed(17)
+    n = 2 ** r
+    pred = torch.randn(B, 3, 5 * n, 2 * n, generator=g)
+    target = torch.randn(B, 9, 10 * n * n + 2, generator=g)
+    mu, lv = torch.randn(B, 512, 5, 2, generator=g), 0.5 * torch.randn(B, 512, 5, 2, generator=g)
+    crit = P2PKLD_Loss(r, 0.6, 0.2, 0.2, factor_kl).cuda()
+    cl = torch.channels_last
+    xs = [pred.cuda().contiguous(memory_format=cl).requires_grad_(), mu.cuda().contiguous(memory_format=cl).requires_grad_(),
+          lv.cuda().contiguous(memory_format=cl).requires_grad_()]
+    loss = crit(tuple(xs), target.cuda())
+    (2.0 * loss).backward()
+    rec = loss_ref.p2p_loss(pred.numpy(), target.numpy(), r, 0.6, 0.2, 0.2)
+    kl = loss_ref.kld(mu.numpy(), lv.numpy())
+    assert abs(float(loss) - (rec + factor_kl * kl)) <= 2e-5 * abs(rec + factor_kl * kl)
+    got = crit.get_last_losses()
+    assert abs(got[0] - rec) <= 2e-5 * abs(rec) and abs(-got[3] - kl) <= 2e-5 * abs(kl) and abs(got[4] - float(loss)) < 1e-6
+    gm, gl = loss_ref.kld_grad(mu.numpy(), lv.numpy())
+    assert rel_l2(xs[0].grad.cpu().numpy(), 2.0 * loss_ref.p2p_grad(pred.numpy(), target.numpy(), r, 0.6, 0.2, 0.2)) < 5e-5
+    assert rel_l2(xs[1].grad.cpu().numpy(), 2.0 * factor_kl * gm) < 1e-5
+    assert rel_l2(xs[2].grad.cpu().numpy(), 2.0 * factor_kl * gl) < 1e-5
+
+
+def test_kld_and_reparameterise_kernels_against_torch():
+    """icn_kld_* and icn_reparam_* against the reference's torch expressions on the same device (losses.py:105,
+    models.py:89-92): contiguous and channels_last inputs, value and gradients; the KLD sum is deterministic."""
+    from geniconet_amd import fused, losses
+    g = torch.Generator(device='cuda').manual_seed(4)
+    for shape, cl in (((3, 512, 5, 2), True), ((36, 512, 20, 8), True), ((4, 8, 5, 2), False)):
+        mu = torch.randn(shape, device='cuda', generator=g)
+        lv = 0.7 * torch.randn(shape, device='cuda', generator=g)
+        if cl:
+            mu, lv = (t.contiguous(memory_format=torch.channels_last) for t in (mu, lv))
+        a = [mu.clone().requires_grad_(), lv.clone().requires_grad_()]
+        b = [mu.clone().requires_grad_(), lv.clone().requires_grad_()]
+        k1 = losses.kld(*a)
+        fm, fl = torch.flatten(b[0], 1), torch.flatten(b[1], 1)
+        k2 = torch.mean(-0.5 * torch.mean(1 + fl - fm.pow(2) - fl.exp(), dim=1), dim=0)
+        assert abs(float(k1) - float(k2)) <= 1e-5 * abs(float(k2))
+        assert float(losses.kld(*a)) == float(k1)                               # fixed two-level sum
+        (3 * k1).backward()
+        (3 * k2).backward()
+        for p_, q_ in zip(a, b):
+            assert rel_l2(p_.grad.cpu().numpy(), q_.grad.cpu().numpy()) < 1e-5
+        eps = torch.randn(shape, device='cuda', generator=g)
+        gz = torch.randn(shape, device='cuda', generator=g)
+        a = [mu.clone().requires_grad_(), lv.clone().requires_grad_()]
+        b = [mu.clone().requires_grad_(), lv.clone().requires_grad_()]
+        z1 = fused._ReparamFn.apply(a[0], a[1], eps)
+        z2 = eps * torch.exp(0.5 * b[1]) + b[0]
+        assert rel_l2(z1.detach().cpu().numpy(), z2.detach().cpu().numpy()) < 1e-6
+        z1.backward(gz)
+        z2.backward(gz)
+        for p_, q_ in zip(a, b):
+            assert rel_l2(p_.grad.cpu().numpy(), q_.grad.cpu().numpy()) < 1e-6
+    torch.manual_seed(11)
+    z_a = fused.reparameterize(mu, lv)
+    torch.manual_seed(11)
+    z_b = torch.randn_like(torch.exp(0.5 * lv)) * torch.exp(0.5 * lv) + mu      # the reference's expression, same generator
+    assert rel_l2(z_a.cpu().numpy(), z_b.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('mode', ['v-mean', 'sum-kv', 'kv-sum'])
+def test_hip_loss_laplacian_conventions(mode):
+    """The Laplacian convention is an option of the loss (upstream's is unknown): HIP value and gradient for the
+    non-default conventions against the numpy oracle."""
+    from geniconet_amd.losses import LAPLACIAN_MODES, P2P_Loss
+    r, B = 2, 2
+    g = torch.Generator().manual_seed(77)
+    n = 2 ** r
+    pred = torch.randn(B, 3, 5 * n, 2 * n, generator=g)
+    target = torch.randn(B, 9, 10 * n * n + 2, generator=g)
+    code = LAPLACIAN_MODES[mode]
+    crit = P2P_Loss(r, 0.3, 0.2, 0.5, laplacian=mode).cuda()
+    x = pred.cuda().requires_grad_()
+    loss = crit(x, target.cuda())
+    loss.backward()
+    want = loss_ref.p2p_terms(pred.numpy(), target.numpy(), r, code)
+    assert abs(float(crit.last_loss_lap) - want[2]) <= 2e-5 * want[2]
+    assert abs(float(loss) - loss_ref.p2p_loss(pred.numpy(), target.numpy(), r, 0.3, 0.2, 0.5, code)) <= 2e-5 * abs(float(loss))
+    assert rel_l2(x.grad.cpu().numpy(), loss_ref.p2p_grad(pred.numpy(), target.numpy(), r, 0.3, 0.2, 0.5, code)) < 5e-5
+
+
+# ---- (e) full-size steps: size-independent checks -------------------------------------------------------------------------------
+@pytest.mark.parametrize('cfg', [('ico2ico', 5, 36), ('ico2ico', 6, 8), ('ico2ico_vae', 5, 36)], ids=lambda c: '%s_I%d_b%d' % c)
+def test_full_size_training_step_is_finite_and_deterministic(cfg):
+    """BASELINE configs 1, 3 and 4 at their real sizes: two training steps through Trainer.step give a finite loss, finite
+    weights, running statistics inside the data's range, and -- every reduction on the path being fixed-order (wgrad slabs,
+    BatchNorm / loss / head two-level sums, no atomics) -- bit-identical results when repeated from the same state."""
+    from geniconet_amd import data, models
+    from geniconet_amd.train import Trainer
+    name, R, B = cfg
+    p = models.default_params(name, subdivisions=R)
+    x, t = data.synthetic_batch(B, R, seed=1234, device='cuda')
+    x = x.contiguous(memory_format=torch.channels_last)
+    runs = []
+    for _ in range(2):
+        tr = Trainer(p, 'cuda', seed=0)
+        torch.manual_seed(99)                                         # the VAE's noise
+        losses_ = [tr.step(x, t) for _ in range(2)]
+        runs.append(([float(v) for v in losses_], {k: v.clone() for k, v in tr.model.state_dict().items()}))
+        del tr
+    (la, sa), (lb, sb) = runs
+    assert all(np.isfinite(la)) and la == lb, (la, lb)
+    for k, v in sa.items():
+        assert bool(torch.isfinite(v).all()), k
+        assert torch.equal(v, sb[k]), k
+    assert int(sa['encoder.1.num_batches_tracked']) == 2
+    assert float(sa['encoder.1.running_var'].min()) > 0
+
+
+# ---- (f) BatchNorm with |mean| >> std -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mean,std', [(50.0, 0.1), (-300.0, 1.0), (1e3, 1e-2)])
+def test_fused_bn_with_large_mean_small_variance(mean, std):
+    """Batch variance from shifted sums (icn_bn.hip): x = mean + std * randn must give the statistics, outputs and gradients
+    of nn.BatchNorm2d (Welford) -- a plain E[x^2] - mean^2 in fp32 loses the variance here entirely."""
+    from geniconet_amd import fused
+    C = 64
+    torch.manual_seed(2)
+    bn, rf = torch.nn.BatchNorm2d(C).cuda().train(), torch.nn.BatchNorm2d(C).cuda().train()
+    x64 = mean + std * torch.randn(4, C, 40, 16, dtype=torch.float64)
+    x = x64.float().cuda().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(4, C, 40, 16, device='cuda')
+    a1, a2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    y1 = fused.bn_relu(a1, bn)
+    y2 = torch.relu(rf(a2))
+    y1.backward(gy)
+    y2.backward(gy)
+    # float64 truth of the fp32-rounded input
+    xd = x.double().cpu()
+    m64, v64 = xd.mean((0, 2, 3)), xd.var((0, 2, 3), unbiased=True)
+    assert rel_l2(bn.running_mean.cpu().numpy(), (0.1 * m64).numpy()) < 1e-6
+    assert rel_l2((bn.running_var.cpu() - 0.9).numpy(), (0.1 * v64).numpy()) < 1e-3
+    assert rel_l2(bn.running_var.cpu().numpy(), rf.running_var.cpu().numpy()) < 1e-4
+    yd = torch.relu((xd - m64[None, :, None, None]) / torch.sqrt(xd.var((0, 2, 3), unbiased=False) + 1e-5)[None, :, None, None])
+    err_fused, err_torch = rel_l2(y1.detach().cpu().numpy(), yd.numpy()), rel_l2(y2.detach().cpu().numpy(), yd.numpy())
+    assert err_fused < max(2 * err_torch, 1e-4), (err_fused, err_torch)
+    assert rel_l2(a1.grad.cpu().numpy(), a2.grad.cpu().numpy()) < max(20 * err_torch, 1e-3)
+
+
+# ---- register-staged fallback kernels, in-process (icn_set_debug_flags) ---------------------------------------------------------
+FALLBACK_CASES = [(2, 1, 64, 64, 2, 'average'), (3, 2, 128, 256, 2, 'average'), (4, 1, 128, 64, 2, 'average'),
+                  (4, 1, 64, 320, 1, 'average'), (5, 1, 128, 128, 1, 'average'), (3, 1, 256, 128, 2, 'zeros')]
+
+
+@pytest.fixture
+def fallback_routing():
+    from geniconet_amd import _lib
+    old = _lib.lib().icn_set_debug_flags(48)              # 16: convs on k_gather_gemm, 32: weight gradients on k_wgrad
+    yield
+    _lib.lib().icn_set_debug_flags(old)
+
+
+@pytest.mark.parametrize('case', FALLBACK_CASES, ids=lambda c: 'r%d_s%d_%dx%d_b%d_%s' % c)
+def test_register_staged_fallback_kernels_stay_correct(case, fallback_routing):
+    """k_gather_gemm and the non-DMA k_wgrad serve only tensors beyond 2 GiB and tiles with fewer than 4 K-steps, so the
+    normal suite hardly reaches them: route every convolution to them (asserted through the profiling hooks) and repeat a
+    few conv cases -- MFMA tiles of all shapes, stride 2, an odd width -- against the oracle."""
+    from geniconet_amd import _lib
+    from test_gpu_parity import conv_both
+    _lib.profile_start(64)
+    out = conv_both(*case, seed=11)
+    used = {e['kernel'].split('<')[0] for e in _lib.profile_stop()}
+    assert used == {'k_gather_gemm', 'k_wgrad'}, used
+    for k, (got, want) in out.items():
+        assert rel_l2(got.detach().cpu().numpy(), want.detach().numpy()) < TOL, k

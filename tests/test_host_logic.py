@@ -234,6 +234,73 @@ def test_device_resident_dataset_and_epoch_loops(tmp_path):
         if v <= best:
             best = v
             saved.append('ico2ico_EB%d.pt' % epoch)
-    assert sorted(os.listdir(tmp_path / 'savedModel')) == sorted(saved) and saved
+    saved.append('ico2ico_E3.pt')                                              # the final saveModel (run.py:495-496)
+    assert sorted(os.listdir(tmp_path / 'savedModel')) == sorted(saved) and len(saved) > 1
     ck = train.load_checkpoint(tr.model, str(tmp_path), 'ico2ico', epoch=0)
-    assert abs(ck['loss'] - best) < 1e-12
+    assert abs(ck['loss'] - best) < 1e-12 and ck['misc'] is None              # misc only for the VAE losses
+
+
+def test_fit_anneals_the_kl_factor_and_checkpoints_carry_the_vae_misc(tmp_path):
+    """run.py:479-496 for the VAE: criterion.update_factor(epoch + 1, factor_step_size, factor_gamma) after every epoch
+    (losses.py:116-118), misc = {'trn_mean', 'trn_logvar'} of the last training batch in every checkpoint (run.py:274-276;
+    read by enc2ico_vae.createSample, models.py:329-332), a '<name>_E<epoch>.pt' every save_epoch_freq epochs and at the
+    end.  CPU, oracle network."""
+    import torch
+    from geniconet_amd import data, models, train
+    from oracle import models_ref
+    R = 3
+    p = models.default_params('ico2ico_vae', subdivisions=R)
+    p['ico2ico_vae'].update(factor_step_size=2, factor_gamma=0.9, save_epoch_freq=2)
+    x, t = data.synthetic_batch(5, R, seed=11)
+    ds = data.IcoDataset.from_tensors(t, R)
+    torch.manual_seed(0)
+    tr = train.Trainer(p, 'cpu', model=models_ref.ico2ico_vae(R=R).train(), criterion=train.build_criterion(p, 'cpu'),
+                       channels_last=False)
+    assert tr.criterion.get_factor() == 1.0
+    hist = train.fit(tr, ds.subset([0, 1, 2]), ds.subset([3, 4]), epochs=5, batch_size=2, log_dir=str(tmp_path), seed=1)
+    assert len(hist) == 5
+    assert abs(tr.criterion.get_factor() - 0.9 ** 2) < 1e-12                    # epochs 2 and 4
+    files = sorted(os.listdir(tmp_path / 'savedModel'))
+    for f in ('ico2ico_vae_E2.pt', 'ico2ico_vae_E4.pt', 'ico2ico_vae_E5.pt'):
+        assert f in files, files
+    ck = torch.load(str(tmp_path / 'savedModel' / 'ico2ico_vae_E5.pt'), map_location='cpu', weights_only=False)
+    assert sorted(ck['misc']) == ['trn_logvar', 'trn_mean']
+    n = 2 ** (R - 3)
+    assert ck['misc']['trn_mean'].shape == (1, 512, 5 * n, 2 * n)              # last batch of 3 samples at batch size 2
+    assert ck['misc']['trn_logvar'].shape == ck['misc']['trn_mean'].shape
+    # the decoder half samples from it exactly as the reference does (models.py:329-332)
+    half = models.enc2ico_vae(p)
+    z = half.createSample(1, [ck['misc']])
+    assert z.shape == ck['misc']['trn_mean'].shape and torch.isfinite(z).all()
+
+
+@pytest.mark.parametrize('mode', ['mean-v', 'v-mean', 'sum-kv', 'kv-sum'])
+def test_laplacian_convention_is_an_option_checked_against_the_dataset(tmp_path, mode):
+    """Upstream's mesh.utils.compute_laplacian (generate.py:197 writes target rows 6:9 with it) is absent, so its sign and
+    normalisation cannot be known offline: the loss takes the convention as an option, the dataset recovers it from the
+    data and refuses a mismatch, and the CPU formulation agrees with the numpy oracle for every convention."""
+    r = 2
+    x, tgt = data.synthetic_batch(2, r, seed=5, laplacian=mode)
+    found, errs = data.detect_laplacian_convention(tgt, r)
+    assert found == mode and errs[mode] < 1e-5
+    for k in range(2):
+        data.save_sample(str(tmp_path / ('m%d.npz' % k)), tgt[k].numpy())
+    ds = data.IcoDataset(str(tmp_path), r, laplacian=mode)
+    assert ds.laplacian == mode and ds.subset([1]).laplacian == mode
+    other = 'v-mean' if mode != 'v-mean' else 'mean-v'
+    with pytest.raises(ValueError, match="they match '%s'" % mode):
+        data.IcoDataset(str(tmp_path), r, laplacian=other)
+    assert data.IcoDataset(str(tmp_path), r, laplacian=None).laplacian is None
+    with pytest.raises(ValueError, match='laplacian must be one of'):
+        losses.P2P_Loss(r, 1., 0., 0., laplacian='cotan')
+    torch.manual_seed(2)
+    n = 2 ** r
+    pred = torch.tanh(torch.randn(2, 3, 5 * n, 2 * n))
+    crit = losses.P2P_Loss(r, 0.6, 0.2, 0.2, laplacian=mode)
+    crit(pred, tgt)
+    code = losses.LAPLACIAN_MODES[mode]
+    np.testing.assert_allclose(crit.get_last_losses()[:3], loss_ref.p2p_terms(pred.numpy(), tgt.numpy(), r, code), rtol=2e-5)
+    p = models.default_params('ico2ico_vae', subdivisions=3)
+    p['ico']['laplacian'] = mode
+    from geniconet_amd import train
+    assert train.build_criterion(p, 'cpu').laplacian == mode

@@ -121,9 +121,11 @@ def test_tap_order_matches_lattice_offsets_in_chart_interior():
                     assert tt[t, p] == (c * n + i + da) * 2 * n + j + db
 
 
-def test_loss_gradient_oracle_is_pinned_by_finite_differences():
+@pytest.mark.parametrize('lap_mode', [0, 1, 2, 3])
+def test_loss_gradient_oracle_is_pinned_by_finite_differences(lap_mode):
     """oracle/loss_ref.p2p_grad (analytic; the checker of the HIP loss backward) against central differences of
-    p2p_loss, VAE factors (reference run.py:694-696), r = 1: 42 vertices, ten of them pole corners."""
+    p2p_loss, VAE factors (reference run.py:694-696), r = 1: 42 vertices, ten of them pole corners; every Laplacian
+    convention the product offers."""
     import numpy as np
     from oracle import loss_ref
     rng = np.random.default_rng(4)
@@ -131,13 +133,22 @@ def test_loss_gradient_oracle_is_pinned_by_finite_differences():
     n = 2 ** r
     pred = rng.standard_normal((B, 3, 5 * n, 2 * n))
     tgt = rng.standard_normal((B, 9, 10 * n * n + 2))
-    g = loss_ref.p2p_grad(pred, tgt, r, *fac)
+    g = loss_ref.p2p_grad(pred, tgt, r, *fac, lap_mode)
     num = np.zeros_like(pred)
     eps = 1e-6
     for idx in np.ndindex(pred.shape):
         p, q = pred.copy(), pred.copy()
         p[idx] += eps
         q[idx] -= eps
-        num[idx] = (loss_ref.p2p_loss(p, tgt, r, *fac) - loss_ref.p2p_loss(q, tgt, r, *fac)) / (2 * eps)
+        num[idx] = (loss_ref.p2p_loss(p, tgt, r, *fac, lap_mode) - loss_ref.p2p_loss(q, tgt, r, *fac, lap_mode)) / (2 * eps)
     assert np.linalg.norm(g - num) <= 1e-6 * np.linalg.norm(num)
+    mu, lv = rng.standard_normal((2, 4, 5, 2)), 0.3 * rng.standard_normal((2, 4, 5, 2))
+    gm, gl = loss_ref.kld_grad(mu, lv)
+    for arr, grad, which in ((mu, gm, 0), (lv, gl, 1)):
+        idx = (1, 2, 3, 1)
+        a, b = arr.copy(), arr.copy()
+        a[idx] += eps
+        b[idx] -= eps
+        fd = (loss_ref.kld(*((a, lv) if which == 0 else (mu, a))) - loss_ref.kld(*((b, lv) if which == 0 else (mu, b)))) / (2 * eps)
+        assert abs(fd - grad[idx]) <= 1e-6 * abs(fd) + 1e-12
     assert np.allclose(loss_ref.p2p_grad(pred, tgt, r, 1.0, 0.0, 0.0), loss_ref.p2p_pos_grad(pred, tgt, r), rtol=1e-12, atol=0)
