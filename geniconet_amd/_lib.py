@@ -36,6 +36,9 @@ SIGNATURES = {
     'icn_conv_pair_fwd': (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'icn_conv_pair_bwd_data': (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'icn_conv_pair_bwd_weight': (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'icn_upconv_supported': (ctypes.c_int, [ctypes.c_int] * 5),
+    'icn_upconv_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 5),
+    'icn_upconv_fwd': (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'icn_upsample_fwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'icn_upsample_bwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'icn_bn_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),
@@ -60,6 +63,7 @@ SIGNATURES = {
     'icn_table_upsample': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, _f32p, ctypes.c_size_t, _intp]),
     'icn_table_upsample_pairs': (ctypes.c_long, [ctypes.c_int, _i32p, ctypes.c_size_t]),
     'icn_table_faces': (ctypes.c_long, [ctypes.c_int, _i32p, ctypes.c_size_t]),
+    'icn_table_upconv': (ctypes.c_long, [ctypes.c_int, ctypes.c_int, _i32p, ctypes.c_size_t, _f32p, ctypes.c_size_t, _intp]),
 }
 
 
@@ -158,6 +162,26 @@ def table_upsample_pairs(r_in):
     out = np.empty(n, dtype=np.int32)
     L.icn_table_upsample_pairs(r_in, out.ctypes.data_as(_i32p), n)
     return out.reshape(2, -1)
+
+
+def table_upconv(r_in, corner_mode):
+    """Composite upsample + conv table (icn_table_upconv) as a dict of numpy arrays: seg (nseg, 3) = rows per sample / first
+    list position / virtual-tap mask, pix (Pf,), code (NV, Pf), alpha (NV, 7), slot_idx / slot_coef (n_slots, E)."""
+    L, m = lib(), corner_code(corner_mode)
+    meta = (ctypes.c_int * 7)()
+    n = L.icn_table_upconv(r_in, m, None, 0, None, 0, meta)
+    if n < 0:
+        check(-1, 'icn_table_upconv')
+    Pf, Pc, n_slots, E, nseg, NV, nf = list(meta)
+    ints, floats = np.empty(n, dtype=np.int32), np.empty(nf, dtype=np.float32)
+    L.icn_table_upconv(r_in, m, ints.ctypes.data_as(_i32p), n, floats.ctypes.data_as(_f32p), nf, meta)
+    o = 0
+    seg = ints[o:o + 3 * nseg].reshape(nseg, 3); o += 3 * nseg
+    pix = ints[o:o + Pf]; o += Pf
+    code = ints[o:o + NV * Pf].reshape(NV, Pf); o += NV * Pf
+    slot_idx = ints[o:o + n_slots * E].reshape(n_slots, E)
+    return dict(Pf=Pf, Pc=Pc, seg=seg, pix=pix, code=code, alpha=floats[:NV * 7].reshape(NV, 7), slot_idx=slot_idx,
+                slot_coef=floats[NV * 7:].reshape(n_slots, E))
 
 
 def profile_start(max_launches=4096):

@@ -75,7 +75,17 @@ struct UpTables {
     float *coef_f = nullptr, *coef_b = nullptr;
 };
 
+// device copy of an icn::UpconvTable (composite upsample + conv over the coarse tensor)
+struct UpconvDev {
+    int Pc = 0, Pf = 0, n_slots = 0, E = 1, nseg = 0;
+    int seg_cnt[icn::UPCONV_MAX_SEG] = {}, seg_off[icn::UPCONV_MAX_SEG] = {};
+    uint32_t seg_mask[icn::UPCONV_MAX_SEG] = {};
+    int32_t *pix = nullptr, *code = nullptr, *slot_idx = nullptr;
+    float *alpha = nullptr, *slot_coef = nullptr;
+};
+
 std::mutex g_mu;
+std::map<std::tuple<int, int, int>, UpconvDev> g_upconv;       // (device, r_in, mode)
 std::map<std::tuple<int, int, int, int>, ConvTables> g_conv;   // (device, r, stride, mode)
 std::map<std::tuple<int, int, int>, UpTables> g_up;            // (device, r, mode)
 
@@ -162,6 +172,42 @@ const UpTables& up_tables(int r_in, int mode) {
     t.idx_b = upload(b.idx);
     t.coef_b = upload(b.coef);
     return g_up.emplace(key, t).first->second;
+}
+
+const UpconvDev& upconv_tables(int r_in, int mode) {
+    int dev = 0;
+    ICN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(dev, r_in, mode);
+    auto it = g_upconv.find(key);
+    if (it != g_upconv.end()) return it->second;
+    icn::UpconvTable h;
+    icn::build_upconv_fwd(r_in, mode, h);
+    UpconvDev d;
+    d.Pc = h.Pc; d.Pf = h.Pf; d.n_slots = h.n_slots; d.E = h.E; d.nseg = h.nseg;
+    for (int i = 0; i < h.nseg; ++i) { d.seg_cnt[i] = h.seg_cnt[i]; d.seg_off[i] = h.seg_off[i]; d.seg_mask[i] = h.seg_mask[i]; }
+    d.pix = upload(h.pix);
+    d.code = upload(h.code);
+    d.slot_idx = upload(h.slot_idx);
+    d.alpha = upload(h.alpha);
+    d.slot_coef = upload(h.slot_coef);
+    return g_upconv.emplace(key, d).first->second;
+}
+
+// slots of the composite table per level (host only, cached; the larger of the two corner modes)
+int upconv_slots(int r_in) {
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(r_in);
+    if (it != cache.end()) return it->second;
+    int n = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+        icn::UpconvTable h;
+        icn::build_upconv_fwd(r_in, mode, h);
+        n = std::max(n, h.n_slots);
+    }
+    return cache[r_in] = n;
 }
 
 // ---- profiling state (off by default) ------------------------------------------------------------------
@@ -589,6 +635,78 @@ int icn_conv_pair_bwd_weight(const float* x, const float* dy0, const float* dy1,
     }
 }
 
+// ---- composite upsample + conv (forward): y_k = conv_k(upsample(x)), k = 0 (, 1), from the COARSE tensor ------------------
+namespace {
+bool upconv_supported(int B, int Cin, int C0, int C1, int r_in) {
+    if (B < 1 || r_in < 0 || r_in > 9 || Cin < 32 || Cin % 32 != 0 || C0 < 64 || C0 % 64 != 0 || C1 < 0 || C1 % 64 != 0) return false;
+    const size_t Pc = icn::pixels(r_in), Pf = 4 * Pc, lim = (size_t)1 << 31;
+    const size_t C = (size_t)C0 + C1;
+    if ((size_t)B * Pf + 5 * 8 * 128 >= lim) return false;          // rows incl. the padding of the 5 row segments
+    if ((size_t)B * Pc * Cin * 4 >= lim || (size_t)icn::UPCONV_TAPS * C * Cin * 4 >= lim) return false;
+    if ((size_t)B * Pf * std::max(C0, C1) * 4 >= ((size_t)1 << 34)) return false;       // dst rows are 32-bit, bytes are size_t
+    if ((size_t)B * upconv_slots(r_in) * Cin * 4 >= lim / 2) return false;
+    return true;
+}
+size_t upconv_ws_bytes(int B, int Cin, int C0, int C1, int r_in) {
+    const size_t C = (size_t)C0 + C1;
+    return align256((size_t)icn::UPCONV_TAPS * C * Cin * sizeof(float)) + align256(C * sizeof(float)) +
+           align256((size_t)B * upconv_slots(r_in) * Cin * sizeof(float));
+}
+}  // namespace
+
+int icn_upconv_supported(int B, int Cin, int Cout0, int Cout1, int r_in) {
+    try {
+        return upconv_supported(B, Cin, Cout0, Cout1, r_in) ? 1 : 0;
+    } catch (const std::exception&) {
+        return 0;
+    }
+}
+
+size_t icn_upconv_workspace_bytes(int B, int Cin, int Cout0, int Cout1, int r_in) {
+    try {
+        return upconv_supported(B, Cin, Cout0, Cout1, r_in) ? upconv_ws_bytes(B, Cin, Cout0, Cout1, r_in) : 0;
+    } catch (const std::exception&) {
+        return 0;
+    }
+}
+
+int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const float* w1, const float* bias1, float* y0, float* y1, int B,
+                   int Cin, int Cout0, int Cout1, int r_in, int corner_mode, void* ws, size_t ws_bytes, void* stream) {
+    try {
+        if (!x || !w0 || !y0) throw std::invalid_argument("icn_upconv_fwd: null tensor pointer");
+        if ((w1 == nullptr) != (Cout1 == 0) || (w1 && !y1)) throw std::invalid_argument("icn_upconv_fwd: second branch needs w1, y1 and Cout1 > 0");
+        if (w1 && (bias0 == nullptr) != (bias1 == nullptr)) throw std::invalid_argument("icn_upconv_fwd: both biases or none");
+        if (corner_mode != 0 && corner_mode != 1) throw std::invalid_argument("icn: corner_mode must be 0 (zeros) or 1 (average)");
+        if (!upconv_supported(B, Cin, Cout0, Cout1, r_in)) throw std::invalid_argument("icn_upconv_fwd: unsupported shape");
+        if (!ws || ws_bytes < upconv_ws_bytes(B, Cin, Cout0, Cout1, r_in)) throw std::invalid_argument("icn_upconv_fwd: workspace too small");
+        const UpconvDev& t = upconv_tables(r_in, corner_mode);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const int C = Cout0 + Cout1;
+        const size_t wbytes = align256((size_t)icn::UPCONV_TAPS * C * Cin * sizeof(float));
+        float* weff = static_cast<float*>(ws);
+        float* bias_cat = (w1 && bias0) ? reinterpret_cast<float*>(at(ws, wbytes)) : nullptr;
+        float* side = reinterpret_cast<float*>(at(ws, wbytes + align256((size_t)C * sizeof(float))));
+        icn::UpconvPrologueArgs p{};
+        p.w = w0; p.w2 = w1; p.packed = weff; p.Cout = Cout0; p.Cout2 = Cout1; p.Cin = Cin; p.NV = icn::UPCONV_TAPS; p.alpha = t.alpha;
+        p.bias = bias0; p.bias2 = bias1; p.bias_cat = bias_cat;
+        p.src = x; p.slot_idx = t.slot_idx; p.slot_coef = t.slot_coef; p.side = side; p.n_slots = t.n_slots; p.E = t.E; p.B = B; p.Ps = t.Pc;
+        icn::launch_upconv_prologue(p, s);
+        icn::GatherGemmArgs a{};
+        a.src = x; a.wt = weff; a.bias = w1 ? bias_cat : bias0; a.dst = y0; a.dst2 = w1 ? y1 : nullptr; a.N0 = Cout0;
+        a.dcode = t.code; a.side = side; a.n_slots = t.n_slots; a.perm = t.pix;
+        a.Ps = t.Pc; a.Pd = t.Pf; a.K = Cin; a.N = C; a.E = 1; a.T = icn::UPCONV_TAPS;
+        a.segs.nseg = t.nseg; a.segs.B = B;
+        for (int i = 0; i < t.nseg; ++i) { a.segs.cnt[i] = t.seg_cnt[i]; a.segs.off[i] = t.seg_off[i]; a.segs.mask[i] = t.seg_mask[i]; }
+        a.M = B * t.Pf;                                          // the launch pads the row segments to its tile height
+        a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pf;      // of the two operators it replaces (executed: ~0.68 of it)
+        icn::launch_gather_gemm_auto(a, s);
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
 int icn_upsample_fwd(const float* x, float* y, int B, int C, int r_in, int corner_mode, void* stream) {
     try {
         if (!x || !y || B < 1 || C < 1) throw std::invalid_argument("icn_upsample_fwd: bad arguments");
@@ -822,6 +940,33 @@ long icn_table_upsample_pairs(int r_in, int32_t* out, size_t cap) {
         icn::build_upsample_pairs(r_in, v);
         if (out) std::memcpy(out, v.data(), std::min(cap, v.size()) * sizeof(int32_t));
         return (long)v.size();
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+long icn_table_upconv(int r_in, int corner_mode, int32_t* ints, size_t cap_ints, float* floats, size_t cap_floats, int* meta) {
+    try {
+        icn::UpconvTable t;
+        icn::build_upconv_fwd(r_in, corner_mode, t);
+        std::vector<int32_t> iv;
+        for (int sg = 0; sg < t.nseg; ++sg) {
+            iv.push_back(t.seg_cnt[sg]);
+            iv.push_back(t.seg_off[sg]);
+            iv.push_back((int32_t)t.seg_mask[sg]);
+        }
+        iv.insert(iv.end(), t.pix.begin(), t.pix.end());
+        iv.insert(iv.end(), t.code.begin(), t.code.end());
+        iv.insert(iv.end(), t.slot_idx.begin(), t.slot_idx.end());
+        std::vector<float> fv(t.alpha);
+        fv.insert(fv.end(), t.slot_coef.begin(), t.slot_coef.end());
+        if (meta) {
+            meta[0] = t.Pf; meta[1] = t.Pc; meta[2] = t.n_slots; meta[3] = t.E; meta[4] = t.nseg; meta[5] = icn::UPCONV_TAPS;
+            meta[6] = (int)fv.size();
+        }
+        if (ints) std::memcpy(ints, iv.data(), std::min(cap_ints, iv.size()) * sizeof(int32_t));
+        if (floats) std::memcpy(floats, fv.data(), std::min(cap_floats, fv.size()) * sizeof(float));
+        return (long)iv.size();
     } catch (const std::exception& e) {
         return fail(e.what());
     }

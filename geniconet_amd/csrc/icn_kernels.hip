@@ -349,7 +349,7 @@ using lds_ptr_t = __attribute__((address_space(3))) void*;
 constexpr unsigned SIDE_FLAG = 0x80000000u;
 constexpr unsigned NOTHING_OFFSET = 0xC0000000u;
 
-template <int BM, int BN>
+template <int BM, int BN, bool SEG>   // SEG: class-major rows + virtual taps of a composite table (icn_upconv_*)
 __global__ __launch_bounds__(256) void k_conv_dma(
     const float* __restrict__ src,      // (B, Ps, Ks)   Ks = K, or K / 2 with src2
     const float* __restrict__ src2,     // second half of the K axis (pair bwd-data), or null
@@ -362,8 +362,15 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     const float* __restrict__ side2,    // same for src2
     const int32_t* __restrict__ perm,   // [Pd] row -> dst pixel, or null (identity)
     const uint32_t* __restrict__ mask32,// [Pd/32] taps in use per 32 rows, or null (all 7)
-    int M, int Ps, int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles) {
+    int M, int Ps, int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles, int T_arg,
+    const RowSegs segs) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
+    // T taps in wt / dcode (7 hex taps, or the virtual taps of a composite table); a tile runs at most 7 of them (its tap
+    // mask), and the LDS offset table is indexed by a tap's RANK inside that mask.
+    // The plain instantiation (SEG = false) is the kernel of every ordinary convolution: 7 taps, rank == tap id, rows
+    // m = b * Pd + q; all of the class-major machinery compiles away there.
+    constexpr unsigned INVALID_ROW = 0xFFFFFFFFu;      // destination-row table: padding row (nothing is stored)
+    const int T = SEG ? T_arg : 7;
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;          // rows per lane (one 16-byte chunk of each)
     constexpr int NDMA = RA + RB;                      // DMA instructions per wave per stage
@@ -387,22 +394,64 @@ __global__ __launch_bounds__(256) void k_conv_dma(
 
     const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
     const auto rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src2 ? src2 : src), 0, src_bytes, 0x00020000);
-    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, 7 * N * K * 4, 0x00020000);
+    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, T * N * K * 4, 0x00020000);
     const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side ? side : src), 0, side ? side_bytes : 0u,
                                                           0x00020000);
     const auto rsrc_s2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side2 ? side2 : src), 0, side2 ? side_bytes : 0u,
                                                            0x00020000);
-    const auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(dcode), 0, 7 * Pd * 4, 0x00020000);
+    const auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(dcode), 0, T * Pd * 4, 0x00020000);
     const auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(perm ? perm : dcode), 0, Pd * 4, 0x00020000);
     const auto rsrc_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias ? bias : src), 0, bias ? N * 4 : 0, 0x00020000);
 
     // XCD-aware tile order: tiles with equal index mod 8 (one persistent block's residue class, hence one XCD
     // and one L2) form a contiguous run of (m, n) tiles.
     auto tile_origin = [&](int tile, int& m0, int& n0) __attribute__((always_inline)) {
+        if constexpr (SEG) {
+            // class-major rows: XCD x takes the x-th eighth of EVERY segment (segments are SEG_ALIGN-row aligned, so their
+            // tile counts are multiples of 8): all XCDs walk the classes in step and carry equal work.
+            const int x = tile % 8;
+            int i = tile / 8;
+            m0 = 0;
+            n0 = 0;
+#pragma unroll
+            for (int sg = 0; sg < MAX_SEGS; ++sg) {
+                if (sg < segs.nseg) {
+                    const int end = sg + 1 < segs.nseg ? segs.row0[sg + 1] : M;
+                    const int per = ((end - segs.row0[sg]) / BM) * ntn / 8;
+                    if (i >= 0 && i < per) {
+                        const int sw = x * per + i;
+                        m0 = segs.row0[sg] + (sw / ntn) * BM;
+                        n0 = (sw % ntn) * BN;
+                    }
+                    i -= per;
+                }
+            }
+            return;
+        }
         const int q = ntiles / 8, rem = ntiles % 8, x = tile % 8;
         const int sw = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + tile / 8;
         m0 = (sw / ntn) * BM;
         n0 = (sw % ntn) * BN;
+    };
+    // GEMM row m -> sample b (-1: padding row / past M) and position q in the per-sample code / perm tables
+    auto decode_row = [&](int m, int& b, int& q) __attribute__((always_inline)) {
+        if constexpr (!SEG) {
+            b = m < M ? m / Pd : -1;
+            q = m - (m / Pd) * Pd;
+            return;
+        }
+        int r0 = segs.row0[0], cn = segs.cnt[0], of = segs.off[0];
+#pragma unroll
+        for (int sg = 1; sg < MAX_SEGS; ++sg)
+            if (sg < segs.nseg && m >= segs.row0[sg]) { r0 = segs.row0[sg]; cn = segs.cnt[sg]; of = segs.off[sg]; }
+        const int k = m - r0, bb = k / cn;
+        b = bb < segs.B ? bb : -1;
+        q = bb < segs.B ? of + k - bb * cn : 0;
+    };
+    // n-th set bit of a tap mask (wave-uniform arguments)
+    auto nth_tap = [&](unsigned mk, int nth) __attribute__((always_inline)) {
+        for (int i = 0; i < nth; ++i) mk &= mk - 1u;
+        return __ffs(mk) - 1;
     };
     // lane-constant parts of the DMA source offsets (bytes)
     unsigned achunk[RA], bconst[RB];
@@ -421,15 +470,19 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     };
     // Metadata of the block's FIRST tile, built synchronously with ordinary loads: row offsets, destination rows, bias.
     // (Later tiles: ICN_META_ISSUE / ICN_META_CONVERT below, by LDS-DMA, one tile ahead.)
-    auto build_first = [&](int m0, int n0) {
-        for (int e = tid; e < 7 * BM; e += 256) {
-            const int t = e / BM, row = e % BM, m = m0 + row;
-            otab[e] = m < M ? row_offset(dcode[(size_t)t * Pd + m % Pd], m / Pd) : NOTHING_OFFSET;
+    auto build_first = [&](int m0, int n0, unsigned mk) {
+        const int nt = SEG ? __popc(mk) : 7;
+        for (int e = tid; e < nt * BM; e += 256) {
+            const int t = SEG ? nth_tap(mk, e / BM) : e / BM, row = e % BM;
+            int b, q;
+            decode_row(m0 + row, b, q);
+            otab[e] = b >= 0 ? row_offset(dcode[(size_t)t * Pd + q], b) : NOTHING_OFFSET;
         }
         if (perm)
             for (int row = tid; row < BM; row += 256) {
-                const int m = m0 + row;
-                drow_s[row] = m < M ? (unsigned)((m / Pd) * Pd + perm[m % Pd]) : 0u;
+                int b, q;
+                decode_row(m0 + row, b, q);
+                drow_s[row] = b >= 0 ? (unsigned)(b * Pd + perm[q]) : (SEG ? INVALID_ROW : 0u);
             }
         if (bias)
             for (int c = tid; c < BN; c += 256) bias_s[c] = bias[n0 + c];
@@ -438,6 +491,13 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     // wave-uniform index => scalar loads
     auto tile_taps = [&](int m0) __attribute__((always_inline)) {
         unsigned mk = 0x7f;
+        if constexpr (SEG) {                             // the tile lies in one segment
+            mk = segs.mask[0];
+#pragma unroll
+            for (int sg = 1; sg < MAX_SEGS; ++sg)
+                if (sg < segs.nseg && m0 >= segs.row0[sg]) mk = segs.mask[sg];
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)mk);
+        }
         if (mask32) {
             mk = 0;
 #pragma unroll
@@ -511,7 +571,7 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     // and scalar offset as wave-uniform or it wraps every DMA in a waterfall loop.
     int tile = blockIdx.x, m0, n0;
     tile_origin(tile, m0, n0);
-    build_first(m0, n0);
+    build_first(m0, n0, tile_taps(m0));
     __syncthreads();
     int slot = 0, eslot = 0;                              // offset-table slot / epilogue-table slot of the compute tile
     int next_tile = tile + gridDim.x;
@@ -522,7 +582,7 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     int i_t = __ffs(mask_c) - 1, i_kc = 0, i_ring = 0, i_own = 1, i_live = 1;       // DMA pointer; i_own: inside compute tile
     unsigned pbase[RA];                                   // row offsets of the next stage to be issued (prefetched)
 #pragma unroll
-    for (int i = 0; i < RA; ++i) pbase[i] = otab[i_t * BM + 8 * (wave + 4 * i) + rsub];
+    for (int i = 0; i < RA; ++i) pbase[i] = otab[(SEG ? 0 : i_t) * BM + 8 * (wave + 4 * i) + rsub];   // SEG: rank 0
     int issued = 0, p_exact = 1;
     int mb[RL];                                           // metadata pass: sample of the lane's rows in the next tile, or -1
     // Issue the stage under the DMA pointer, advance the pointer, prefetch the next stage's row offsets.
@@ -580,7 +640,9 @@ _Pragma("unroll") \
                 } \
             } \
             if (i_live) { \
-                const int tb = __builtin_amdgcn_readfirstlane(((i_own ? slot : slot ^ 1) * 7 + i_t) * BM); \
+                const unsigned mr_ = i_own ? mask_c : mask_n; \
+                const int rk_ = SEG ? __popc(mr_ & ((1u << i_t) - 1u)) : i_t;   /* row of the offset table */ \
+                const int tb = __builtin_amdgcn_readfirstlane(((i_own ? slot : slot ^ 1) * 7 + rk_) * BM); \
 _Pragma("unroll") \
                 for (int i = 0; i < RA; ++i) pbase[i] = otab[tb + 8 * (wave + 4 * i) + rsub]; \
             } \
@@ -591,23 +653,21 @@ _Pragma("unroll") \
     // destination-row permutation, the last BN / 64 waves the bias.
 #define ICN_META_ISSUE() do { \
         const int ne_ = __builtin_amdgcn_readfirstlane(eslot == 2 ? 0 : eslot + 1); \
+        const int nj_ = SEG ? __builtin_amdgcn_readfirstlane(__popc(mask_n) * RL) : NJ;   /* SEG: the next tile's taps only */ \
         int mp_[RL]; \
 _Pragma("unroll") \
-        for (int r = 0; r < RL; ++r) { \
-            const int m = nm0 + r * 64 + lane; \
-            mb[r] = m < M ? m / Pd : -1; \
-            mp_[r] = m - (m / Pd) * Pd; \
-        } \
+        for (int r = 0; r < RL; ++r) decode_row(nm0 + r * 64 + lane, mb[r], mp_[r]); \
 _Pragma("unroll") \
         for (int jj = 0; jj < JW; ++jj) { \
             const int j = wave + 4 * jj; \
-            if (j < NJ) { \
+            if (j < nj_) { \
                 const int r = j % RL; \
                 const int b_ = RL == 1 ? mb[0] : (r ? mb[RL - 1] : mb[0]); \
                 const int p_ = RL == 1 ? mp_[0] : (r ? mp_[RL - 1] : mp_[0]); \
+                const int t_ = SEG ? __builtin_amdgcn_readfirstlane(nth_tap(mask_n, j / RL)) : j / RL; \
                 unsigned* dst_ = otab + __builtin_amdgcn_readfirstlane((slot ^ 1) * 7 * BM + j * 64); \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)dst_, 4, \
-                                                         b_ >= 0 ? (unsigned)((j / RL) * Pd + p_) * 4u : SIDE_FLAG, 0, 0, 0); \
+                                                         b_ >= 0 ? (unsigned)(t_ * Pd + p_) * 4u : SIDE_FLAG, 0, 0, 0); \
             } \
         } \
         if (perm && wave < RL) { \
@@ -626,10 +686,11 @@ _Pragma("unroll") \
     // lane that fetched them; the step's barrier publishes the tables.
 #define ICN_META_CONVERT() do { \
         const int ne_ = eslot == 2 ? 0 : eslot + 1; \
+        const int nj_ = SEG ? __builtin_amdgcn_readfirstlane(__popc(mask_n) * RL) : NJ; \
 _Pragma("unroll") \
         for (int jj = 0; jj < JW; ++jj) { \
             const int j = wave + 4 * jj; \
-            if (j < NJ) { \
+            if (j < nj_) { \
                 const int r = j % RL; \
                 const int b_ = RL == 1 ? mb[0] : (r ? mb[RL - 1] : mb[0]); \
                 unsigned* e_ = otab + (slot ^ 1) * 7 * BM + j * 64 + lane; \
@@ -639,7 +700,7 @@ _Pragma("unroll") \
         if (perm && wave < RL) { \
             const int b_ = RL == 1 ? mb[0] : (wave ? mb[RL - 1] : mb[0]); \
             unsigned* e_ = drow_s + ne_ * BM + wave * 64 + lane; \
-            *e_ = b_ >= 0 ? (unsigned)(b_ * Pd) + *e_ : 0u; \
+            *e_ = b_ >= 0 ? (unsigned)(b_ * Pd) + *e_ : (SEG ? INVALID_ROW : 0u); \
         } \
     } while (0)
     // End of a K-step: retire the previous stage (and the metadata fetched ahead of this step's stage), publish.
@@ -681,7 +742,10 @@ _Pragma("unroll") \
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rl = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, m = m0 + rl;
-                    if (m < M) {
+                    if constexpr (SEG) {
+                        const unsigned drow = drow_s[eslot * BM + rl];
+                        if (drow != INVALID_ROW) dcol[(size_t)drow * dstride] = acc[i][j][r] + bv;
+                    } else if (m < M) {
                         const size_t drow = perm ? (size_t)drow_s[eslot * BM + rl] : (size_t)m;
                         dcol[drow * dstride] = acc[i][j][r] + bv;
                     }
@@ -715,34 +779,63 @@ static size_t conv_dma_lds(int bm, int bn, bool perm, bool bias) {
     return (size_t)3 * (bm + bn) * BK * 4 + (size_t)2 * 7 * bm * 4 + (perm ? (size_t)3 * bm * 4 : 0) + (bias ? (size_t)3 * bn * 4 : 0);
 }
 
-template <int BM, int BN>
-static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
-    const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+template <int BM, int BN, bool SEG>
+static void launch_conv_dma_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
+    const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);   // class-major rows: M is a multiple of 8 * BM
     int grid = std::min(ntiles, 256 * occ);              // (more blocks than slots: measured, no difference -- DESIGN 4.2)
     if (grid >= 8) grid -= grid % 8;                     // keep a block's tiles in one residue class mod 8 (one XCD)
     const size_t lds = conv_dma_lds(BM, BN, a.perm != nullptr, a.bias != nullptr);
     static std::atomic<uint64_t> attr_devices{0};        // LDS opt-in, once per device
     if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_dma<BM, BN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_dma<BM, BN, SEG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
     }
     const int Ks = a.src2 ? a.K / 2 : a.K;
-    const unsigned src_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.Ps * Ks * 4);
-    const unsigned side_bytes = (unsigned)((size_t)(a.M / a.Pd) * a.n_slots * Ks * 4);
+    const size_t nb = a.segs.nseg > 0 ? (size_t)a.segs.B : (size_t)(a.M / a.Pd);          // samples
+    const unsigned src_bytes = (unsigned)(nb * a.Ps * Ks * 4);
+    const unsigned side_bytes = (unsigned)(nb * a.n_slots * Ks * 4);
     prof_mark_begin(BM == 64 ? (BN == 128 ? PROF_DMA_64x128 : PROF_DMA_64x64) : (BN == 128 ? PROF_DMA_128x128 : PROF_DMA_128x64),
                     a.algo_flops, s);
-    hipLaunchKernelGGL((k_conv_dma<BM, BN>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2,
+    hipLaunchKernelGGL((k_conv_dma<BM, BN, SEG>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2,
                        a.dcode, a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.mask32, a.M,
-                       a.Ps, a.Pd, a.K, a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles);
+                       a.Ps, a.Pd, a.K, a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs);
     prof_mark_end(s);
+}
+
+// rows of a class-major launch for tile height bm: every segment padded to a multiple of 8 * bm rows (8 XCDs x one tile)
+static long seg_rows(const RowSegs& sg, int bm, int* row0) {
+    long row = 0;
+    const long al = 8L * bm;
+    for (int i = 0; i < sg.nseg; ++i) {
+        if (row0) row0[i] = (int)row;
+        row += ((long)sg.B * sg.cnt[i] + al - 1) / al * al;
+    }
+    return row;
+}
+
+template <int BM, int BN>
+static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
+    if (a.segs.nseg == 0) return launch_conv_dma_t<BM, BN, false>(a, occ, s);
+    GatherGemmArgs b = a;
+    b.M = (int)seg_rows(a.segs, BM, b.segs.row0);
+    launch_conv_dma_t<BM, BN, true>(b, occ, s);
 }
 
 bool conv_dma_usable(const GatherGemmArgs& a) {
     if (dbg_flags() & 16) return false;
     const int Ks = a.src2 ? a.K / 2 : a.K;
-    const size_t src_bytes = (size_t)(a.M / a.Pd) * a.Ps * Ks * 4, wt_bytes = (size_t)7 * a.N * a.K * 4;
-    const size_t side_bytes = (size_t)(a.M / a.Pd) * a.n_slots * Ks * 4;
+    const size_t nb = a.segs.nseg > 0 ? (size_t)a.segs.B : (size_t)(a.M / a.Pd);
+    const size_t src_bytes = nb * a.Ps * Ks * 4, wt_bytes = (size_t)(a.T > 0 ? a.T : 7) * a.N * a.K * 4;
+    const size_t side_bytes = nb * a.n_slots * Ks * 4;
+    if (a.segs.nseg > 0) {
+        // class-major rows: permuted, every tile's tap mask comes from its segment (1..7 taps); the launch pads the segments
+        if (a.perm == nullptr || a.segs.nseg > MAX_SEGS || a.segs.B < 1 || seg_rows(a.segs, 128, nullptr) >= (1L << 31)) return false;
+        for (int i = 0; i < a.segs.nseg; ++i) {
+            const int pc = __builtin_popcount(a.segs.mask[i]);
+            if (pc < 1 || pc > 7 || pc * (a.K / BK) < 4 || a.segs.cnt[i] < 1) return false;
+        }
+    }
     if (a.dcode == nullptr || (a.n_slots > 0 && (a.side == nullptr || (a.src2 && a.side2 == nullptr)))) return false;
     if (side_bytes >= ((size_t)1 << 30)) return false;
     if (a.src2 && Ks % BK != 0) return false;
@@ -750,7 +843,7 @@ bool conv_dma_usable(const GatherGemmArgs& a) {
     // The cross-tile pipeline needs >= 4 K-steps per tile: the next tile's metadata is fetched in the tile's first
     // step and published by that step's barrier, and the DMA pointer (2 steps ahead) prefetches the next stage's row
     // offsets one step earlier still, i.e. in step S-3 >= 1.  With tap masks a tile may use a single tap.
-    if ((a.mask32 ? 1 : 7) * (a.K / BK) < 4) return false;
+    if (a.segs.nseg == 0 && (a.mask32 ? 1 : 7) * (a.K / BK) < 4) return false;
     return src_bytes < ((size_t)1 << 31) && wt_bytes < ((size_t)1 << 31);
 }
 
@@ -770,7 +863,8 @@ static void launch_conv_dma_auto(const GatherGemmArgs& a, hipStream_t s) {
         if (a.N % c.bn != 0) continue;
         // blocks per CU: the shape's design point, unless the epilogue tables push its LDS over 160 KB / occ
         const int occ = std::max(1, std::min(c.occ, (int)((160 * 1024) / conv_dma_lds(c.bm, c.bn, a.perm != nullptr, a.bias != nullptr))));
-        const long tiles = (long)((a.M + c.bm - 1) / c.bm) * (a.N / c.bn);
+        const long rows = a.segs.nseg > 0 ? seg_rows(a.segs, c.bm, nullptr) : a.M;
+        const long tiles = ((rows + c.bm - 1) / c.bm) * (a.N / c.bn);
         const long slots = 256L * occ;
         double cost = (double)((tiles + slots - 1) / slots) * occ * c.bm * c.bn / (c.eff * occ / c.occ);
         if (force && atoi(force) == i) cost = -1;
@@ -802,6 +896,7 @@ static int pick_tile(int M, int N, int E) {
 void launch_gather_gemm_auto(const GatherGemmArgs& a, hipStream_t s) {
     if (conv_dma_usable(a)) return launch_conv_dma_auto(a, s);
     if (a.src2 || a.dst2) throw std::invalid_argument("icn: pair gather-GEMM outside the LDS-DMA kernel's limits");
+    if (a.segs.nseg > 0 || a.T > 7) throw std::invalid_argument("icn: composite gather-GEMM outside the LDS-DMA kernel's limits");
     switch (pick_tile(a.M, a.N, a.E)) {
         case 0: return launch_gather_gemm<128, 128>(a, s);
         case 1: return launch_gather_gemm<128, 64>(a, s);
@@ -1550,6 +1645,43 @@ void launch_row_scatter_add(const float* src, float* dst, const int32_t* q, int 
     const size_t total = (size_t)B * nv * (C / 4);
     hipLaunchKernelGGL(k_row_scatter_add, dim3((unsigned)std::min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s, src, dst, q, B,
                        nv, nvp, P, C);
+}
+
+// Prologue of a composite upsample + conv call (icn_upconv_*), one launch: blocks [0, npack) build the effective weights
+//   packed[v][n][k] = sum_t alpha[v][t] * w(n, k, t)        (B operand [NV][N][K] of the gather-GEMM; n runs over the
+// output channels of w, then of w2), and concatenate the biases; the other blocks fill the side buffer of the irregular
+// rows,  side[b][s][:] = sum_e coef[s][e] * x[b, idx[s][e], :]  (the upsampled neighbour values those rows gather).
+__global__ __launch_bounds__(256) void k_upconv_prologue(UpconvPrologueArgs a, int npack) {
+    if ((int)blockIdx.x < npack) {
+        const int Ct = a.Cout + a.Cout2, total = a.NV * Ct * a.Cin;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += npack * 256) {
+            const int ci = i % a.Cin, co = (i / a.Cin) % Ct, v = i / (a.Cin * Ct);
+            const float* wp = co < a.Cout ? a.w + ((size_t)co * a.Cin + ci) * 7 : a.w2 + ((size_t)(co - a.Cout) * a.Cin + ci) * 7;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 7; ++t) acc += a.alpha[v * 7 + t] * wp[t];
+            a.packed[i] = acc;
+        }
+        if (a.bias_cat && blockIdx.x == 0)
+            for (int c = threadIdx.x; c < Ct; c += 256) a.bias_cat[c] = c < a.Cout ? a.bias[c] : a.bias2[c - a.Cout];
+        return;
+    }
+    const int j = blockIdx.x - npack;
+    const int b = j / a.n_slots, sl = j % a.n_slots;
+    for (int ch = 4 * threadIdx.x; ch < a.Cin; ch += 4 * 256) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < a.E; ++e) {
+            const int32_t c = a.slot_idx[sl * a.E + e];
+            if (c >= 0) v += a.slot_coef[sl * a.E + e] * ld4(a.src + ((size_t)b * a.Ps + c) * a.Cin + ch);
+        }
+        *reinterpret_cast<f32x4*>(a.side + ((size_t)b * a.n_slots + sl) * a.Cin + ch) = v;
+    }
+}
+
+void launch_upconv_prologue(const UpconvPrologueArgs& a, hipStream_t s) {
+    const int npack = std::min(4096, (a.NV * (a.Cout + a.Cout2) * a.Cin + 255) / 256);
+    const int nside = (a.side && a.n_slots > 0) ? a.B * a.n_slots : 0;
+    hipLaunchKernelGGL(k_upconv_prologue, dim3(npack + nside), dim3(256), 0, s, a, npack);
 }
 
 void launch_conv_prologue(const PrologueArgs& a, hipStream_t s) {

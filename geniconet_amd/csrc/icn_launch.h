@@ -9,6 +9,19 @@ namespace icn {
 // Pair forms (two convolutions sharing their input, reference models.py:37-39,59-60) are plain concatenations:
 //   * src2 != null: the K (channel) axis is [src | src2], K / 2 channels each (bwd-data of a pair: dy0 | dy1);
 //   * dst2 != null: the N axis is [dst (N0 columns) | dst2 (N - N0 columns)] (forward of a pair).
+// Class-major row map of the composite (upsample + conv) GEMM: rows [row0[s], row0[s] + B * cnt[s]) of segment s are
+// (sample b, list position off[s] + j), b-major; every segment starts at a multiple of 8 tiles of rows (8 XCDs: each gets an
+// equal share of every segment; the rest is padding that computes nothing), so a tile lies in one segment and runs only that
+// segment's taps `mask[s]`.  The caller fills nseg, B, cnt, off, mask; row0 (and the launch's M) follow from the tile height
+// the launcher picks.  nseg == 0: plain rows m = b * Pd + q (every other launch).
+constexpr int MAX_SEGS = 5;
+struct RowSegs {
+    int nseg;
+    int B;
+    int row0[MAX_SEGS], cnt[MAX_SEGS], off[MAX_SEGS];
+    unsigned mask[MAX_SEGS];
+};
+
 struct GatherGemmArgs {
     const float* src;       // (B, Ps, K)  [or (B, Ps, K/2) with src2]
     const float* src2;      // second half of the K axis, or null
@@ -26,6 +39,8 @@ struct GatherGemmArgs {
     const uint32_t* mask32; // [Pd/32] tap mask per 32 rows (one word each: scalar loads), or null
     int M, Ps, Pd, K, N, E, ns;
     double algo_flops;      // algorithmic FLOPs of this launch (profiling only)
+    int T;                  // taps of wt / dcode: 0 = the 7 hex taps; > 7: virtual taps of a composite table (LDS-DMA kernel only)
+    RowSegs segs;           // nseg > 0: class-major rows (M = padded row count, perm = list position -> dst pixel)
 };
 
 struct WgradArgs {
@@ -80,6 +95,15 @@ struct PrologueArgs {
     const float* src; const float* src2; const int32_t* slots; float* side; float* side2; int n_slots, E, B, Ps, K, ns;
 };
 void launch_conv_prologue(const PrologueArgs& a, hipStream_t s);
+
+// Same for a composite upsample + conv call: effective weights packed[NV][Cout + Cout2][Cin] = sum_t alpha[v][t] W_t,
+// concatenated bias, side buffer side[b][slot] = sum_e slot_coef * x[b, slot_idx] (irregular rows; src = x (B, Ps, Cin)).
+struct UpconvPrologueArgs {
+    const float* w; const float* w2; float* packed; int Cout, Cout2, Cin, NV; const float* alpha;
+    const float* bias; const float* bias2; float* bias_cat;
+    const float* src; const int32_t* slot_idx; const float* slot_coef; float* side; int n_slots, E, B, Ps;
+};
+void launch_upconv_prologue(const UpconvPrologueArgs& a, hipStream_t s);
 
 // ---- fused BatchNorm (+ residual) + ReLU (icn_bn.hip); stat = [mean | invstd] (2*C), sums = NS*C, ws = chunks*NS*C floats
 bool bn_supported(int C);

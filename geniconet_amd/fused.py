@@ -13,7 +13,8 @@ import os
 import torch
 
 from . import _lib
-from .ico_conv import _nhwc, _stream, ico_conv_pair, ico_conv_pair_supported
+from .ico_conv import (_nhwc, _stream, ico_conv_pair, ico_conv_pair_supported, ico_upconv_pair,
+                       ico_upconv_pair_supported)
 
 _DISABLED = os.environ.get('ICN_NO_FUSED_BN', '') == '1'
 
@@ -50,6 +51,31 @@ def conv_pair(x, conv_a, conv_b):
         return ico_conv_pair(x, conv_a.weight, conv_a.bias, conv_b.weight, conv_b.bias, conv_a.subdivisions,
                              conv_a.stride, conv_a.corner_mode)
     return conv_a(x), conv_b(x)
+
+
+_NO_UPCONV = os.environ.get('ICN_NO_UPCONV', '') == '1'
+
+
+def upconv_pair(x, up_a, up_b, conv_a, conv_b):
+    """(conv_a(up_a(x)), conv_b(up_b(x))) -- the head of the reference's decoder block (models.py:58-60).  The two
+    IcoUpsampleS2S modules are parameter-free and see the same tensor, so the r -> r+1 upsample is shared; when the shape
+    allows, upsample and pair convolution run as ONE composite gather-GEMM over the coarse tensor (icn_upconv_fwd), else
+    as one upsample + the pair convolution, else module by module (someone hooked a module, unequal branches ...)."""
+    mods = (up_a, up_b, conv_a, conv_b)
+    plain = not any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in mods)
+    same = (up_a.subdivisions == up_b.subdivisions and up_a.corner_mode == up_b.corner_mode == conv_a.corner_mode
+            == conv_b.corner_mode and conv_a.stride == conv_b.stride == 1
+            and conv_a.subdivisions == conv_b.subdivisions == up_a.subdivisions + 1
+            and (conv_a.bias is None) == (conv_b.bias is None))
+    if plain and same and not _NO_PAIR and not _NO_UPCONV and x.is_cuda and x.dtype == torch.float32 \
+            and ico_upconv_pair_supported(x, conv_a.weight, conv_b.weight, up_a.subdivisions):
+        return ico_upconv_pair(x, conv_a.weight, conv_a.bias, conv_b.weight, conv_b.bias, up_a.subdivisions, up_a.corner_mode)
+    up = up_a(x)
+    hooked = up_b._forward_hooks or up_b._forward_pre_hooks
+    up_skip = up_b(x) if hooked else up
+    if up_skip is up:
+        return conv_pair(up, conv_a, conv_b)
+    return conv_a(up), conv_b(up_skip)
 
 
 class _BnReluFn(torch.autograd.Function):

@@ -185,6 +185,98 @@ class _IcoUpsampleFn(torch.autograd.Function):
         return dx.permute(0, 3, 1, 2), None, None
 
 
+class _IcoUpConvPairFn(torch.autograd.Function):
+    """(conv0(upsample(x)), conv1(upsample(x))) -- the head of the reference's decoder block (models.py:58-60) -- with the
+    FORWARD computed from the coarse tensor by one composite gather-GEMM (icn_upconv_fwd in include/icn.h: 0.68 of the
+    multiply-adds, no upsampled tensor).  Backward is that of the separate operators: the upsample is recomputed from x
+    (an HBM-bound pass), the pair's bwd-data / bwd-weight kernels run on it, and the upsample's transpose brings the
+    gradient back to the coarse level.  Same results as ico_conv_pair(ico_upsample(x), ...) up to fp32 rounding order."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, r, mode):
+        L = _lib.lib()
+        B, Cin = x.shape[0], x.shape[1]
+        C0, C1 = w0.shape[0], w1.shape[0]
+        nf = 2 ** (r + 1)
+        xp = _nhwc(x)
+        w0c, w1c = w0.contiguous(), w1.contiguous()
+        b0c = b0.contiguous() if b0 is not None else None
+        b1c = b1.contiguous() if b1 is not None else None
+        y0 = torch.empty(B, 5 * nf, 2 * nf, C0, dtype=torch.float32, device=x.device)
+        y1 = torch.empty(B, 5 * nf, 2 * nf, C1, dtype=torch.float32, device=x.device)
+        ws_bytes = L.icn_upconv_workspace_bytes(B, Cin, C0, C1, r)
+        ws = _workspace(ws_bytes, x.device)
+        with torch.cuda.device(x.device):
+            rc = L.icn_upconv_fwd(xp.data_ptr(), w0c.data_ptr(), b0c.data_ptr() if b0c is not None else None, w1c.data_ptr(),
+                                  b1c.data_ptr() if b1c is not None else None, y0.data_ptr(), y1.data_ptr(), B, Cin, C0, C1, r,
+                                  mode, ws.data_ptr(), ws_bytes, _stream())
+        _lib.check(rc, 'icn_upconv_fwd')
+        ctx.save_for_backward(xp, w0c, w1c)
+        ctx.cfg = (B, Cin, C0, C1, r, mode, b0 is not None)
+        return y0.permute(0, 3, 1, 2), y1.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy0, gy1):
+        L = _lib.lib()
+        xp, w0, w1 = ctx.saved_tensors
+        B, Cin, C0, C1, r, mode, has_bias = ctx.cfg
+        rf, n, nf = r + 1, 2 ** r, 2 ** (r + 1)
+        g0, g1 = _nhwc(gy0), _nhwc(gy1)
+        dev = g0.device
+        dx = dw0 = db0 = dw1 = db1 = None
+        need = ctx.needs_input_grad
+        with torch.cuda.device(dev):
+            st = _stream()
+            if need[0]:
+                dup = torch.empty(B, 5 * nf, 2 * nf, Cin, dtype=torch.float32, device=dev)
+                ws_bytes = L.icn_conv_pair_workspace_bytes(_lib.OP_CONV_BWD_DATA, B, Cin, C0, C1, rf, 1)
+                ws = _workspace(ws_bytes, dev)
+                _lib.check(L.icn_conv_pair_bwd_data(g0.data_ptr(), g1.data_ptr(), w0.data_ptr(), w1.data_ptr(), dup.data_ptr(), B,
+                                                    Cin, C0, C1, rf, 1, mode, ws.data_ptr(), ws_bytes, st), 'icn_conv_pair_bwd_data')
+                dxp = torch.empty(B, 5 * n, 2 * n, Cin, dtype=torch.float32, device=dev)
+                _lib.check(L.icn_upsample_bwd(dup.data_ptr(), dxp.data_ptr(), B, Cin, r, mode, st), 'icn_upsample_bwd')
+                del dup
+                dx = dxp.permute(0, 3, 1, 2)
+            if need[1] or need[3] or (has_bias and (need[2] or need[4])):
+                up = torch.empty(B, 5 * nf, 2 * nf, Cin, dtype=torch.float32, device=dev)
+                _lib.check(L.icn_upsample_fwd(xp.data_ptr(), up.data_ptr(), B, Cin, r, mode, st), 'icn_upsample_fwd')
+                dw0, dw1 = torch.empty_like(w0), torch.empty_like(w1)
+                if has_bias:
+                    db0 = torch.empty(C0, dtype=torch.float32, device=dev)
+                    db1 = torch.empty(C1, dtype=torch.float32, device=dev)
+                ws_bytes = L.icn_conv_pair_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, B, Cin, C0, C1, rf, 1)
+                ws = _workspace(ws_bytes, dev)
+                _lib.check(L.icn_conv_pair_bwd_weight(up.data_ptr(), g0.data_ptr(), g1.data_ptr(), dw0.data_ptr(),
+                                                      db0.data_ptr() if db0 is not None else None, dw1.data_ptr(),
+                                                      db1.data_ptr() if db1 is not None else None, B, Cin, C0, C1, rf, 1, mode,
+                                                      ws.data_ptr(), ws_bytes, st), 'icn_conv_pair_bwd_weight')
+        return dx, dw0, db0, dw1, db1, None, None
+
+
+def ico_upconv_pair_supported(x, weight0, weight1, subdivisions):
+    """True when (conv0(upsample(x)), conv1(upsample(x))) can take the composite forward (icn_upconv_fwd) and the pair
+    backward kernels at the fine level; `subdivisions` is the level of x."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight0.dim() == 3 and weight1.dim() == 3):
+        return False
+    L = _lib.lib()
+    B, Cin, C0, C1 = x.shape[0], x.shape[1], weight0.shape[0], weight1.shape[0]
+    return bool(L.icn_upconv_supported(B, Cin, C0, C1, subdivisions)
+                and L.icn_conv_pair_supported(B, Cin, C0, C1, subdivisions + 1, 1))
+
+
+def ico_upconv_pair(x, weight0, bias0, weight1, bias1, subdivisions, corner_mode='zeros'):
+    """ico_conv_pair(ico_upsample(x, subdivisions), ..., subdivisions + 1) with the forward computed from the coarse tensor."""
+    _require_gpu(x, 'ico_upconv_pair')
+    _check_grid(x, subdivisions, 'ico_upconv_pair')
+    for w in (weight0, weight1):
+        if w.dim() != 3 or w.shape[1] != x.shape[1] or w.shape[2] != 7:
+            raise ValueError('ico_upconv_pair: weight must be (Cout, %d, 7), got %s' % (x.shape[1], tuple(w.shape)))
+    if (bias0 is None) != (bias1 is None):
+        raise ValueError('ico_upconv_pair: both convolutions carry a bias or neither does')
+    return _IcoUpConvPairFn.apply(x, weight0, bias0, weight1, bias1, subdivisions, _lib.corner_code(corner_mode))
+
+
 def ico_conv(x, weight, bias, subdivisions, stride=1, corner_mode='zeros'):
     """Functional form of IcoConvS2S.forward."""
     _require_gpu(x, 'ico_conv')

@@ -63,15 +63,10 @@ class BasicIcoS2SUpBlock(nn.Module):
         self.icobn10 = nn.BatchNorm2d(out_features)
 
     def forward(self, x):
-        # upsample00 and upsample10 are parameter-free and see the same input (reference models.py:59-60): compute the
-        # r -> r+1 upsample once and let autograd sum the two gradients, unless someone hooked upsample10 itself.
-        up = self.upsample00(x)
-        hooked = self.upsample10._forward_hooks or self.upsample10._forward_pre_hooks
-        up_skip = self.upsample10(x) if hooked else up
-        if up_skip is up:
-            c00, c10 = fused.conv_pair(up, self.conv00, self.conv10)
-        else:
-            c00, c10 = self.conv00(up), self.conv10(up_skip)
+        # upsample00 and upsample10 are parameter-free and see the same input (reference models.py:59-60): the r -> r+1
+        # upsample is shared, and upsample + the two convolutions run as one composite gather-GEMM over the coarse tensor
+        # when the shape allows (fused.upconv_pair; module by module when someone hooked one of them).
+        c00, c10 = fused.upconv_pair(x, self.upsample00, self.upsample10, self.conv00, self.conv10)
         if fused.can_fuse(x, self.icobn00, self.icobn01, self.icobn10):
             h = fused.bn_relu(c00, self.icobn00)
             return fused.bn_add_relu(self.conv01(h), self.icobn01, c10, self.icobn10)

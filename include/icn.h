@@ -89,6 +89,20 @@ int icn_conv_pair_bwd_weight(const float* x, const float* dy0, const float* dy1,
 int icn_upsample_fwd(const float* x, float* y, int B, int C, int r_in, int corner_mode, void* stream);
 int icn_upsample_bwd(const float* dy, float* dx, int B, int C, int r_in, int corner_mode, void* stream);
 
+/* Composite  conv_stride1(upsample(x))  -- the first two operators of every decoder block of the reference (models.py:58-60:
+ * conv00(upsample00(x)), conv10(upsample10(x)); also its IcoUpS2S, models.py:9-20) -- computed from the COARSE tensor x
+ * (B, 10*4^r_in, Cin) in one gather-GEMM: the upsample is linear, so away from the 12 singular vertices an output pixel is
+ * a fixed combination of 7 (coarse-site pixels) or 4 (edge midpoints) coarse pixels with effective weights
+ * sum_t alpha[t] W_t; the 4x larger upsampled tensor never exists and 0.68 of the multiply-adds of the two operators run.
+ * Same results as icn_upsample_fwd followed by icn_conv_fwd / icn_conv_pair_fwd at level r_in + 1, up to fp32 rounding
+ * order.  Cout1 = 0, w1 = y1 = NULL: one convolution; else a pair sharing x (both biases or neither).  Shapes outside
+ * icn_upconv_supported() (Cin % 32, Cout % 64, tensors below 2 GiB) take the two separate calls.  Forward only: the
+ * backward passes are those of the separate operators (the caller recomputes the upsample from x). */
+int icn_upconv_supported(int B, int Cin, int Cout0, int Cout1, int r_in);
+size_t icn_upconv_workspace_bytes(int B, int Cin, int Cout0, int Cout1, int r_in);
+int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const float* w1, const float* bias1, float* y0, float* y1, int B,
+                   int Cin, int Cout0, int Cout1, int r_in, int corner_mode, void* ws, size_t ws_bytes, void* stream);
+
 /* Fused BatchNorm + ReLU of the residual blocks (training mode; replaces the torch builtins at models.py:36-40,58-62).
  * Tensors are channels-last rows (M = B * pixels, C), C in {64, 128, 256, 512, ...: C % 4 == 0 and 256 % (C/4) == 0}.
  *   stat   [2*C]  batch mean | 1/sqrt(var + eps), written by icn_bn_stats and read by the other two
@@ -160,6 +174,12 @@ long icn_table_conv_bwd(int r_in, int stride, int corner_mode, int32_t* out, siz
 long icn_table_upsample(int r_in, int corner_mode, int transpose, int32_t* idx, float* coef, size_t cap, int* width);
 long icn_table_upsample_pairs(int r_in, int32_t* out, size_t cap);                            /* [2][P_fine]   */
 long icn_table_faces(int r, int32_t* out, size_t cap);                                         /* [20*4^r][3]   */
+/* Composite table of conv_stride1(upsample(x)) over the COARSE tensor (icn_upconv_*; csrc/icn_geometry.h UpconvTable):
+ * meta[7] = {P_fine, P_coarse, n_slots, E, nseg, NV (virtual taps), number of floats};
+ * ints = seg[nseg][3] (rows per sample, first list position, virtual-tap mask) | pix[P_fine] (class-major list of fine
+ * pixels) | code[NV][P_fine] (by list position: coarse pixel, -1 nothing, -2 - slot) | slot_idx[n_slots][E];
+ * floats = alpha[NV][7] (W_eff[v] = sum_t alpha[v][t] W_t) | slot_coef[n_slots][E].  Returns the number of ints. */
+long icn_table_upconv(int r_in, int corner_mode, int32_t* ints, size_t cap_ints, float* floats, size_t cap_floats, int* meta);
 
 /* Optional diagnostics: HIP-event timing of every MFMA kernel launch between start and stop, on the launch
  * stream.  `stop` synchronises the device and returns the number of entries written (one per kernel that ran).

@@ -553,3 +553,65 @@ def test_device_resident_dataset_feeds_the_hip_path(tmp_path):
     assert got.shape == (2,) and abs(float(got[0]) - want) <= 1e-6 * abs(want)
     v = train.validate(a, ds.subset([4, 5]), 2)
     assert np.isfinite(v) and a.model.training
+
+
+# ---- composite upsample + conv (icn_upconv_fwd): forward from the coarse tensor, backward of the separate operators -----------
+# (r_in, cin, cout per branch, B, mode, bias): every level of the decoder incl. the tiny ones (almost all rows irregular),
+# 64-channel branches (a 128-column tile straddles the two outputs), 'zeros' poles, no bias, sample counts that do not fill
+# a row segment
+UPCONV_CASES = [(0, 64, 64, 2, 'average', True), (1, 64, 128, 3, 'average', True), (2, 256, 256, 2, 'average', True),
+                (3, 128, 64, 2, 'average', True), (2, 64, 64, 5, 'zeros', True), (3, 64, 128, 1, 'zeros', False),
+                (4, 128, 64, 1, 'average', True), (2, 128, 192, 3, 'average', False)]
+
+
+@pytest.mark.parametrize('case', UPCONV_CASES, ids=lambda c: 'r%d_%dx2x%d_b%d_%s_bias%d' % c)
+def test_upconv_pair_matches_oracle_upsample_then_convs(case):
+    """(conv0(up(x)), conv1(up(x))) of the reference's decoder block (models.py:58-60): outputs and all gradients against the
+    oracle's separate operators, and the routing (the composite kernel really ran: one k_conv_dma launch in the forward)."""
+    from geniconet_amd import _lib
+    from geniconet_amd.ico_conv import ico_upconv_pair, ico_upconv_pair_supported
+    r, cin, cout, B, mode, bias = case
+    g = torch.Generator().manual_seed(101 + r)
+    n = 2 ** r
+    x = torch.randn(B, cin, 5 * n, 2 * n, generator=g)
+    ws = [torch.randn(cout, cin, 7, generator=g) / (7 * cin) ** 0.5 for _ in range(2)]
+    bs = [torch.randn(cout, generator=g) if bias else None for _ in range(2)]
+    xr = x.clone().requires_grad_()
+    wr = [w.clone().requires_grad_() for w in ws]
+    br = [b.clone().requires_grad_() if bias else None for b in bs]
+    up = ico_ref.ico_upsample(xr, r, mode)
+    yr = [ico_ref.ico_conv(up, wr[k], br[k], r + 1, 1, mode) for k in range(2)]
+    gys = [torch.randn(y.shape, generator=g) for y in yr]
+    (yr[0] * gys[0]).sum().add((yr[1] * gys[1]).sum()).backward()
+    xg = x.cuda().requires_grad_()
+    wg = [w.cuda().requires_grad_() for w in ws]
+    bg = [b.cuda().requires_grad_() if bias else None for b in bs]
+    assert ico_upconv_pair_supported(xg, wg[0], wg[1], r)
+    _lib.profile_start(64)
+    yg = ico_upconv_pair(xg, wg[0], bg[0], wg[1], bg[1], r, mode)
+    prof = _lib.profile_stop()
+    assert sum(e['launches'] for e in prof) == 1 and prof[0]['kernel'].startswith('k_conv_dma'), prof
+    torch.autograd.backward(yg, [gy.cuda() for gy in gys])
+    pairs = {'y0': (yg[0], yr[0]), 'y1': (yg[1], yr[1]), 'dx': (xg.grad, xr.grad), 'dw0': (wg[0].grad, wr[0].grad),
+             'dw1': (wg[1].grad, wr[1].grad)}
+    if bias:
+        pairs.update({'db0': (bg[0].grad, br[0].grad), 'db1': (bg[1].grad, br[1].grad)})
+    for k, (got, want) in pairs.items():
+        assert got.shape == want.shape, k
+        assert rel_l2(got.detach().cpu().numpy(), want.detach().numpy()) < TOL, k
+
+
+def test_upconv_full_size_equals_the_separate_operators():
+    """BASELINE size (I5 / batch 36: the 128 -> 2 x 64 block from level 4 to 5, and I6 / batch 8): the composite forward
+    against upsample -> pair convolution on the same device (both HIP paths; the small cases above pin both to the oracle)."""
+    from geniconet_amd.ico_conv import ico_conv_pair, ico_upconv_pair, ico_upsample
+    g = torch.Generator(device='cuda').manual_seed(6)
+    for r, B, cin, cout in ((4, 36, 128, 64), (2, 36, 256, 256), (5, 8, 128, 64)):
+        n = 2 ** r
+        x = torch.randn(B, cin, 5 * n, 2 * n, device='cuda', generator=g)
+        w0, w1 = (torch.randn(cout, cin, 7, device='cuda', generator=g) / (7 * cin) ** 0.5 for _ in range(2))
+        b0, b1 = (torch.randn(cout, device='cuda', generator=g) for _ in range(2))
+        with torch.no_grad():
+            a0, a1 = ico_upconv_pair(x, w0, b0, w1, b1, r, 'average')
+            c0, c1 = ico_conv_pair(ico_upsample(x, r, 'average'), w0, b0, w1, b1, r + 1, 1, 'average')
+        assert float((a0 - c0).norm() / c0.norm()) < 1e-5 and float((a1 - c1).norm() / c1.norm()) < 1e-5

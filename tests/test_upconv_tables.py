@@ -1,0 +1,73 @@
+"""Composite table of conv_stride1(upsample(x)) (csrc/icn_geometry.cpp build_upconv_fwd; consumed by icn_upconv_*):
+evaluated in numpy (float64) from the table alone and compared with the oracle's two separate operators
+(oracle/ico_ref.py ico_upsample -> ico_conv; reference models.py:58-60).  CPU only: this pins the table before any kernel."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from geniconet_amd import _lib
+from oracle import ico_ref
+
+
+def eval_composite(tab, x, w, bias):
+    """x (B, Cin, Pc), w (Cout, Cin, 7), bias (Cout) -> y (B, Cout, Pf) using only the table."""
+    B, Cin, _ = x.shape
+    weff = np.einsum('vt,oit->voi', tab['alpha'].astype(np.float64), w)                # (NV, Cout, Cin)
+    side = np.zeros((B, Cin, max(len(tab['slot_idx']), 1)))
+    for s, (idx, coef) in enumerate(zip(tab['slot_idx'], tab['slot_coef'])):
+        for i, c in zip(idx, coef):
+            if i >= 0:
+                side[:, :, s] += float(c) * x[:, :, i]
+    y = np.zeros((B, w.shape[0], tab['Pf'])) + bias[None, :, None]
+    macs = 0
+    for cnt, off, mask in tab['seg']:
+        taps = [v for v in range(tab['code'].shape[0]) if (int(mask) >> v) & 1]
+        for pos in range(off, off + cnt):
+            p = tab['pix'][pos]
+            for v in taps:
+                c = tab['code'][v, pos]
+                macs += 1
+                if c >= 0:
+                    y[:, :, p] += x[:, :, c] @ weff[v].T
+                elif c <= -2:
+                    y[:, :, p] += side[:, :, -2 - c] @ weff[v].T
+    return y, macs
+
+
+@pytest.mark.parametrize('mode', ['average', 'zeros'])
+@pytest.mark.parametrize('r', [0, 1, 2, 3])
+def test_composite_table_equals_upsample_then_conv(r, mode):
+    tab = _lib.table_upconv(r, mode)
+    n = 2 ** r
+    Pc, Pf = 10 * n * n, 40 * n * n
+    assert tab['Pc'] == Pc and tab['Pf'] == Pf
+    assert sorted(tab['pix'].tolist()) == list(range(Pf))                              # every fine pixel exactly once
+    assert int(tab['seg'][:, 0].sum()) == Pf and list(tab['seg'][:, 1]) == list(np.cumsum(np.r_[0, tab['seg'][:-1, 0]]))
+    g = torch.Generator().manual_seed(5 + r)
+    B, Cin, Cout = 2, 3, 4
+    x = torch.randn(B, Cin, 5 * n, 2 * n, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 7, generator=g, dtype=torch.float64)
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    want = ico_ref.ico_conv(ico_ref.ico_upsample(x, r, mode), w, b, r + 1, 1, mode)
+    got, macs = eval_composite(tab, x.reshape(B, Cin, Pc).numpy(), w.numpy(), b.numpy())
+    assert rel_l2(got, want.reshape(B, Cout, Pf).numpy()) < 1e-6      # coefficients are stored as fp32 (0.1, 0.02 are inexact)
+    assert macs <= 7 * Pf
+    if r >= 2 and mode == 'average':
+        irregular = int(tab['seg'][-1, 0]) if int(tab['seg'][-1, 2]) >> 19 else 0
+        assert irregular <= 12 * 24, irregular                                           # a patch around each singular vertex
+        regular = Pf - irregular
+        assert macs == 7 * irregular + sum(int(c) * bin(int(m)).count('1') for c, _, m in tab['seg'] if not int(m) >> 19)
+        # three quarters of the regular rows are edge midpoints (4 virtual taps), one quarter coarse sites (7)
+        assert abs(macs / (7.0 * Pf) - 4.75 / 7.0) < 0.2 * 4.0 ** (2 - r) + 0.01, (macs, Pf, regular)
+
+
+def test_virtual_taps_are_the_documented_ones():
+    tab = _lib.table_upconv(3, 'average')
+    a = tab['alpha']
+    assert a.shape == (26, 7)
+    assert np.allclose(a[19:], np.eye(7))                                              # irregular rows: the original taps
+    assert np.allclose(sorted(a[:7].sum(1)), [0.5] * 6 + [4.0])                         # site class: centre 1 + 6 x 0.5; ring 0.5 each
+    assert np.allclose(a[:19].sum(0), 4 * np.ones(7))                                   # every W_t is used with total weight 4 = 4 fine pixels
+    masks = [int(m) for m in tab['seg'][:, 2]]
+    assert masks == [0x7f, 0xf << 7, 0xf << 11, 0xf << 15, 0x7f << 19]
