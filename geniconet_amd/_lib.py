@@ -39,6 +39,9 @@ SIGNATURES = {
     'icn_upconv_supported': (ctypes.c_int, [ctypes.c_int] * 5),
     'icn_upconv_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 5),
     'icn_upconv_fwd': (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'icn_upconv_bwd_supported': (ctypes.c_int, [ctypes.c_int] * 6),
+    'icn_upconv_bwd_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 5),
+    'icn_upconv_bwd': (ctypes.c_int, [_c_float_p] * 10 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'icn_upsample_fwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'icn_upsample_bwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'icn_bn_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),
@@ -63,6 +66,7 @@ SIGNATURES = {
     'icn_table_upsample': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, _f32p, ctypes.c_size_t, _intp]),
     'icn_table_upsample_pairs': (ctypes.c_long, [ctypes.c_int, _i32p, ctypes.c_size_t]),
     'icn_table_faces': (ctypes.c_long, [ctypes.c_int, _i32p, ctypes.c_size_t]),
+    'icn_table_upconv_bwd': (ctypes.c_long, [ctypes.c_int] * 2 + [_i32p, _f32p, ctypes.c_size_t, _intp]),
     'icn_table_upconv': (ctypes.c_long, [ctypes.c_int, ctypes.c_int, _i32p, ctypes.c_size_t, _f32p, ctypes.c_size_t, _intp]),
 }
 
@@ -182,6 +186,18 @@ def table_upconv(r_in, corner_mode):
     slot_idx = ints[o:o + n_slots * E].reshape(n_slots, E)
     return dict(Pf=Pf, Pc=Pc, seg=seg, pix=pix, code=code, alpha=floats[:NV * 7].reshape(NV, 7), slot_idx=slot_idx,
                 slot_coef=floats[NV * 7:].reshape(n_slots, E))
+
+
+def table_upconv_bwd(r_in, corner_mode):
+    """ELL matrix dy -> g of the aggregated upsample + conv backward: (idx, coef), each (7 * Pc, width), row s * 7 + t."""
+    L, m = lib(), corner_code(corner_mode)
+    w = ctypes.c_int(0)
+    n = L.icn_table_upconv_bwd(r_in, m, None, None, 0, ctypes.byref(w))
+    if n < 0:
+        check(-1, 'icn_table_upconv_bwd')
+    idx, coef = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.float32)
+    L.icn_table_upconv_bwd(r_in, m, idx.ctypes.data_as(_i32p), coef.ctypes.data_as(_f32p), n, ctypes.byref(w))
+    return idx.reshape(-1, w.value), coef.reshape(-1, w.value)
 
 
 def profile_start(max_launches=4096):

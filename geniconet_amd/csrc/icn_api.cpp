@@ -84,8 +84,17 @@ struct UpconvDev {
     float *alpha = nullptr, *slot_coef = nullptr;
 };
 
+// device tables of the aggregated backward (icn_upconv_bwd): dy -> g as a width-8 ELL matrix over all 7 * Pc rows plus an
+// overflow matrix over the few rows with more entries; iota = identity table [Pc] (the coarse-level GEMMs do not gather)
+struct UpconvBwdDev {
+    int Pc = 0, Pf = 0, W8 = 8, n_ovf = 0, W_ovf = 0;
+    int32_t *idx8 = nullptr, *ovf_rows = nullptr, *ovf_idx = nullptr, *iota = nullptr;
+    float *coef8 = nullptr, *ovf_coef = nullptr;
+};
+
 std::mutex g_mu;
 std::map<std::tuple<int, int, int>, UpconvDev> g_upconv;       // (device, r_in, mode)
+std::map<std::tuple<int, int, int>, UpconvBwdDev> g_upconv_bwd;
 std::map<std::tuple<int, int, int, int>, ConvTables> g_conv;   // (device, r, stride, mode)
 std::map<std::tuple<int, int, int>, UpTables> g_up;            // (device, r, mode)
 
@@ -192,6 +201,46 @@ const UpconvDev& upconv_tables(int r_in, int mode) {
     d.alpha = upload(h.alpha);
     d.slot_coef = upload(h.slot_coef);
     return g_upconv.emplace(key, d).first->second;
+}
+
+const UpconvBwdDev& upconv_bwd_tables(int r_in, int mode) {
+    int dev = 0;
+    ICN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(dev, r_in, mode);
+    auto it = g_upconv_bwd.find(key);
+    if (it != g_upconv_bwd.end()) return it->second;
+    icn::Ell e;
+    icn::build_upconv_bwd(r_in, mode, e);
+    UpconvBwdDev d;
+    d.Pc = icn::pixels(r_in);
+    d.Pf = 4 * d.Pc;
+    const int W = e.width, W8 = d.W8;
+    std::vector<int32_t> idx8((size_t)e.rows * W8, icn::IDX_ZERO), ovf_rows, ovf_idx, iota(d.Pc);
+    std::vector<float> coef8((size_t)e.rows * W8, 0.f), ovf_coef;
+    d.W_ovf = std::max(W - W8, 0);
+    for (int r = 0; r < e.rows; ++r) {
+        for (int k = 0; k < std::min(W, W8); ++k) {
+            idx8[(size_t)r * W8 + k] = e.idx[(size_t)r * W + k];
+            coef8[(size_t)r * W8 + k] = e.coef[(size_t)r * W + k];
+        }
+        if (W > W8 && e.idx[(size_t)r * W + W8] != icn::IDX_ZERO) {          // rows are left-packed
+            ovf_rows.push_back(r);
+            for (int k = W8; k < W; ++k) {
+                ovf_idx.push_back(e.idx[(size_t)r * W + k]);
+                ovf_coef.push_back(e.coef[(size_t)r * W + k]);
+            }
+        }
+    }
+    for (int i = 0; i < d.Pc; ++i) iota[i] = i;
+    d.n_ovf = (int)ovf_rows.size();
+    d.idx8 = upload(idx8);
+    d.coef8 = upload(coef8);
+    d.ovf_rows = upload(ovf_rows);
+    d.ovf_idx = upload(ovf_idx);
+    d.ovf_coef = upload(ovf_coef);
+    d.iota = upload(iota);
+    return g_upconv_bwd.emplace(key, d).first->second;
 }
 
 // slots of the composite table per level (host only, cached; the larger of the two corner modes)
@@ -707,6 +756,93 @@ int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const fl
     }
 }
 
+// ---- backward of the same pair through the coarse-level aggregate g (csrc/icn_geometry.h build_upconv_bwd) ------------------
+namespace {
+bool upconv_bwd_supported(int B, int Cin, int C0, int C1, int r_in, int corner_mode) {
+    if (corner_mode != ICN_CORNER_AVERAGE) return false;                    // dbias = sum g_0 needs upsample rows that sum to one
+    if (B < 1 || r_in < 0 || r_in > 9 || Cin < 64 || Cin % 64 != 0 || C0 < 64 || C0 % 64 != 0 || C1 < 0 || C1 % 64 != 0) return false;
+    const size_t Pc = icn::pixels(r_in), Pf = 4 * Pc, lim = (size_t)1 << 31, C = (size_t)C0 + C1;
+    if ((size_t)B * Pf >= lim || (size_t)B * Pc * 7 * C * 4 >= lim || (size_t)B * Pc * Cin * 4 >= lim) return false;
+    if ((size_t)7 * C * Cin * 4 >= lim) return false;
+    return icn::gather_gemm_supported((int)(7 * C), Cin) && icn::wgrad_supported(Cin, (int)C);
+}
+struct UpconvBwdWs { size_t g, wb, partial, bpart, total; };
+UpconvBwdWs upconv_bwd_ws(int B, int Cin, int C0, int C1, int r_in) {
+    const int C = C0 + C1, M = B * icn::pixels(r_in);
+    UpconvBwdWs w{};
+    w.g = 0;
+    w.wb = align256((size_t)M * 7 * C * sizeof(float));
+    w.partial = w.wb + align256((size_t)7 * C * Cin * sizeof(float));
+    w.bpart = w.partial + wgrad_partial_bytes(M, Cin, C, C1 ? C0 : C);
+    w.total = w.bpart + wgrad_bias_partial_bytes(M, Cin, C, C1 ? C0 : C);
+    return w;
+}
+}  // namespace
+
+int icn_upconv_bwd_supported(int B, int Cin, int Cout0, int Cout1, int r_in, int corner_mode) {
+    try {
+        return upconv_bwd_supported(B, Cin, Cout0, Cout1, r_in, corner_mode) ? 1 : 0;
+    } catch (const std::exception&) {
+        return 0;
+    }
+}
+
+size_t icn_upconv_bwd_workspace_bytes(int B, int Cin, int Cout0, int Cout1, int r_in) {
+    try {
+        return upconv_bwd_supported(B, Cin, Cout0, Cout1, r_in, ICN_CORNER_AVERAGE) ? upconv_bwd_ws(B, Cin, Cout0, Cout1, r_in).total : 0;
+    } catch (const std::exception&) {
+        return 0;
+    }
+}
+
+int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const float* w0, const float* w1, float* dx, float* dw0,
+                   float* dbias0, float* dw1, float* dbias1, int B, int Cin, int Cout0, int Cout1, int r_in, int corner_mode, void* ws,
+                   size_t ws_bytes, void* stream) {
+    try {
+        if (!dy0 || (Cout1 > 0) != (dy1 != nullptr)) throw std::invalid_argument("icn_upconv_bwd: dy1 goes with Cout1 > 0");
+        if (dx && (!w0 || (Cout1 > 0 && !w1))) throw std::invalid_argument("icn_upconv_bwd: dx needs the weights");
+        if (dw0 && (!x || (Cout1 > 0 && !dw1))) throw std::invalid_argument("icn_upconv_bwd: dw needs x (and dw1 for a pair)");
+        if (!upconv_bwd_supported(B, Cin, Cout0, Cout1, r_in, corner_mode)) throw std::invalid_argument("icn_upconv_bwd: unsupported shape / corner mode");
+        const UpconvBwdWs wo = upconv_bwd_ws(B, Cin, Cout0, Cout1, r_in);
+        if (!ws || ws_bytes < wo.total) throw std::invalid_argument("icn_upconv_bwd: workspace too small");
+        const UpconvBwdDev& t = upconv_bwd_tables(r_in, corner_mode);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const int C = Cout0 + Cout1, M = B * t.Pc;
+        float* g = reinterpret_cast<float*>(at(ws, wo.g));
+        // 1. g[b, s, t, :] = sum_p U[nbr_t(p), s] [dy0 | dy1][b, p, :]
+        icn::launch_upconv_gather(dy0, dy1, g, t.idx8, t.coef8, nullptr, B, t.Pf, 7 * t.Pc, 7 * t.Pc, Cout0, Cout1, t.W8, 0, s);
+        icn::launch_upconv_gather(dy0, dy1, g, t.ovf_idx, t.ovf_coef, t.ovf_rows, B, t.Pf, t.n_ovf, 7 * t.Pc, Cout0, Cout1, t.W_ovf, 1, s);
+        if (dx) {
+            // 2. dx[b, s, :] = g[b, s, (t, c)] . Wb[(t, c), :]: a dense GEMM, K = 7 * C (one "tap" whose gather is the identity)
+            float* wb = reinterpret_cast<float*>(at(ws, wo.wb));
+            icn::PrologueArgs p{};
+            p.w = w0; p.w2 = w1; p.packed = wb; p.Cout = Cout0; p.Cout2 = Cout1; p.Cin = Cin; p.transpose = 2;
+            icn::launch_conv_prologue(p, s);
+            icn::GatherGemmArgs a{};
+            a.src = g; a.wt = wb; a.dst = dx; a.N0 = Cin; a.dcode = t.iota; a.perm = t.iota;
+            a.Ps = t.Pc; a.Pd = t.Pc; a.K = 7 * C; a.N = Cin; a.E = 1; a.T = 1; a.M = M;
+            a.segs.nseg = 1; a.segs.B = B; a.segs.cnt[0] = t.Pc; a.segs.off[0] = 0; a.segs.mask[0] = 1u;
+            a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pf;            // of the fine-level bwd-data it replaces
+            icn::launch_gather_gemm_auto(a, s);
+        }
+        if (dw0) {
+            // 3. dW_t = sum_{b, s} x[b, s, :]^T g[b, s, t, :]   (+ dbias = sum g_0)
+            icn::WgradArgs a{};
+            a.x = x; a.dy = g; a.dy2 = nullptr; a.Cout0 = Cout1 ? Cout0 : C; a.dcode = t.iota; a.n_slots = 0; a.y_taps = 7;
+            a.partial = reinterpret_cast<float*>(at(ws, wo.partial));
+            a.bias_partial = (dbias0 || dbias1) ? reinterpret_cast<float*>(at(ws, wo.bpart)) : nullptr;
+            a.dw = dw0; a.dbias = dbias0; a.dw2 = dw1; a.dbias2 = dbias1;
+            a.M = M; a.Ps = t.Pc; a.Pd = t.Pc; a.Cin = Cin; a.Cout = C; a.ns = 1 << r_in;
+            a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pf;
+            icn::launch_wgrad(a, s);
+        }
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
 int icn_upsample_fwd(const float* x, float* y, int B, int C, int r_in, int corner_mode, void* stream) {
     try {
         if (!x || !y || B < 1 || C < 1) throw std::invalid_argument("icn_upsample_fwd: bad arguments");
@@ -967,6 +1103,19 @@ long icn_table_upconv(int r_in, int corner_mode, int32_t* ints, size_t cap_ints,
         if (ints) std::memcpy(ints, iv.data(), std::min(cap_ints, iv.size()) * sizeof(int32_t));
         if (floats) std::memcpy(floats, fv.data(), std::min(cap_floats, fv.size()) * sizeof(float));
         return (long)iv.size();
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+long icn_table_upconv_bwd(int r_in, int corner_mode, int32_t* idx, float* coef, size_t cap, int* width) {
+    try {
+        icn::Ell e;
+        icn::build_upconv_bwd(r_in, corner_mode, e);
+        if (width) *width = e.width;
+        if (idx) std::memcpy(idx, e.idx.data(), std::min(cap, e.idx.size()) * sizeof(int32_t));
+        if (coef) std::memcpy(coef, e.coef.data(), std::min(cap, e.coef.size()) * sizeof(float));
+        return (long)e.idx.size();
     } catch (const std::exception& e) {
         return fail(e.what());
     }

@@ -466,6 +466,29 @@ void build_upconv_fwd(int r_in, int corner_mode, UpconvTable& out) {
         }
 }
 
+void build_upconv_bwd(int r_in, int corner_mode, Ell& out) {
+    check_args(r_in, 1, corner_mode);
+    if (r_in > 9) throw std::invalid_argument("icn: subdivisions out of range for upsample + conv");
+    const int n = 1 << r_in, Pc = 10 * n * n;
+    std::vector<CompRow> rows;
+    composite_rows(r_in, corner_mode, rows);
+    std::vector<std::vector<std::pair<int32_t, float>>> lists((size_t)Pc * NTAPS);
+    for (int p = 0; p < (int)rows.size(); ++p)                              // p ascending: entries of a row sorted by p
+        for (int t = 0; t < NTAPS; ++t)
+            for (auto& e : rows[p].by_tap[t]) lists[(size_t)e.first * NTAPS + t].push_back({p, (float)e.second});
+    size_t w = 1;
+    for (auto& l : lists) w = std::max(w, l.size());
+    out.rows = Pc * NTAPS;
+    out.width = (int)w;
+    out.idx.assign(lists.size() * w, IDX_ZERO);
+    out.coef.assign(lists.size() * w, 0.0f);
+    for (size_t r = 0; r < lists.size(); ++r)
+        for (size_t e = 0; e < lists[r].size(); ++e) {
+            out.idx[r * w + e] = lists[r][e].first;
+            out.coef[r * w + e] = lists[r][e].second;
+        }
+}
+
 void build_bwd_row_order(int r_in, int stride, const std::vector<int32_t>& bwd_idx, int E,
                          std::vector<int32_t>& perm, std::vector<uint8_t>& mask32) {
     const int n = 1 << r_in, Pin = 10 * n * n;

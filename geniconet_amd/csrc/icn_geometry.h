@@ -108,6 +108,15 @@ struct UpconvTable {
 };
 void build_upconv_fwd(int r_in, int corner_mode, UpconvTable& out);
 
+// Backward of the same pair of operators through ONE coarse-level aggregate of dy.  With U the upsample matrix and
+// nbr_t the fine conv's gather,
+//     g_t[s] = sum_p U[nbr_t(p), s] dy[p]        (7 coarse tensors: dy shifted by tap t, then upsample-transposed)
+// gives both gradients as DENSE coarse-level contractions, a quarter of the fine level's multiply-adds:
+//     dx[s] = sum_t W_t^T g_t[s]                 dW_t = sum_s x[s]^T g_t[s]
+// (and, with corner_mode 'average', dbias = sum_s g_0[s], because every row of U sums to one).  `out` is the ELL matrix of
+// dy -> g: row s * 7 + t lists the fine pixels p and coefficients of g_t[s] (7 entries away from the singular vertices).
+void build_upconv_bwd(int r_in, int corner_mode, Ell& out);
+
 // Row permutation + per-32-row tap masks for stride-2 bwd-data (rows grouped by lattice parity class so
 // that all-empty taps can be skipped tile-wise).  perm[k] = input pixel handled by row k.
 void build_bwd_row_order(int r_in, int stride, const std::vector<int32_t>& bwd_idx, int E,

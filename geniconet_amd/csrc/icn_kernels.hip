@@ -66,8 +66,9 @@ __global__ __launch_bounds__(256) void k_conv_prologue(PrologueArgs a, int npack
         for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += npack * 256) {
             // i enumerates the OUTPUT layout so that stores are coalesced
             int t, co, ci;
-            if (!a.transpose) { ci = i % a.Cin; co = (i / a.Cin) % Ct; t = i / (a.Cin * Ct); }
-            else { co = i % Ct; ci = (i / Ct) % a.Cin; t = i / (a.Cin * Ct); }
+            if (a.transpose == 0) { ci = i % a.Cin; co = (i / a.Cin) % Ct; t = i / (a.Cin * Ct); }
+            else if (a.transpose == 1) { co = i % Ct; ci = (i / Ct) % a.Cin; t = i / (a.Cin * Ct); }
+            else { co = i % Ct; t = (i / Ct) % 7; ci = i / (7 * Ct); }        // [Cin][7][Ct]: one K axis of 7 * Ct (icn_upconv_bwd)
             a.packed[i] = co < a.Cout ? a.w[((size_t)co * a.Cin + ci) * 7 + t] : a.w2[((size_t)(co - a.Cout) * a.Cin + ci) * 7 + t];
         }
         if (a.bias_cat && blockIdx.x == 0)
@@ -1055,8 +1056,10 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
     float* __restrict__ partial,        // [S][7][Cin][Cout]
     float* __restrict__ bias_partial,   // [S][Cout] or null
     int M, int Ps, int Pd, int Cin, int Cout, int Cout0, int n_slots, int rows_per_split, int n_splits, unsigned x_bytes,
-    unsigned side_bytes) {
+    unsigned side_bytes, int y_taps) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // y_taps = 7: dy is the tap-major aggregate g (M, 7, Cout) of icn_upconv_bwd -- tap t reads channels [t * Cout, (t+1) * Cout)
+    // of a row of 7 * Cout floats -- and dcode is ONE table [Pd] shared by the taps (the rows of x are not shifted).
     constexpr int TI = BI / 64, TJ = BJ / 64;
     constexpr int LA = BI / 4, LB = BJ / 4;            // lanes (16-byte chunks) per row
     constexpr int RPA = 64 / LA, RPB = 64 / LB;        // rows per DMA instruction
@@ -1086,13 +1089,15 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
 
     // the block's output-channel tile lies in one of the two dy tensors (block-uniform)
     const bool ysec = co0 >= Cout0;
-    const int yC = ysec ? Cout - Cout0 : Cout0, yc0 = ysec ? co0 - Cout0 : co0;      // its row stride / first channel there
+    const int yC = y_taps ? y_taps * Cout : (ysec ? Cout - Cout0 : Cout0);           // its row stride / first channel there
+    const int yc0 = y_taps ? t * Cout + co0 : (ysec ? co0 - Cout0 : co0);
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
     const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ysec ? dy2 : dy), 0, (unsigned)M * (unsigned)yC * 4u,
                                                           0x00020000);
     const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side ? side : x), 0, side ? side_bytes : 0u,
                                                           0x00020000);
-    const auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(dcode + (size_t)t * Pd), 0, Pd * 4, 0x00020000);
+    const auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(dcode + (y_taps ? (size_t)0 : (size_t)t * Pd)), 0, Pd * 4,
+                                                          0x00020000);
 
     f32x16 acc[TI][TJ];
 #pragma unroll
@@ -1469,7 +1474,7 @@ int wgrad_splits(int M, int Cin, int Cout, int Cout0) {
 }
 
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
-    const bool pair = a.dy2 != nullptr;
+    const bool pair = a.dy2 != nullptr || (a.y_taps && a.Cout0 > 0 && a.Cout0 < a.Cout);   // two weight tensors to fill
     const int Cout0 = pair ? a.Cout0 : a.Cout;
     const int S = wgrad_splits(a.M, a.Cin, a.Cout, Cout0);
     if (wgrad_supported(a.Cin, a.Cout)) {
@@ -1479,18 +1484,19 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         const int BI = bi128 ? 128 : 64, BJ = bj128 ? 128 : 64;
         dim3 grid((a.Cin / BI) * (a.Cout / BJ) * 7 * ((S + 7) / 8 * 8));   // whole XCD rounds; blocks of splits >= S exit
         const size_t lds = wgrad_lds(BI, BJ, false);
-        const size_t x_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.Cin * 4, dy_bytes = (size_t)a.M * std::max(Cout0, a.Cout - Cout0) * 4;
+        const size_t x_bytes = (size_t)(a.M / a.Pd) * a.Ps * a.Cin * 4;
+        const size_t dy_bytes = a.y_taps ? (size_t)a.M * a.y_taps * a.Cout * 4 : (size_t)a.M * std::max(Cout0, a.Cout - Cout0) * 4;
         const size_t side_bytes = (size_t)(a.M / a.Pd) * a.n_slots * a.Cin * 4;
         const bool dma = !(dbg_flags() & 32) && a.dcode != nullptr && (a.n_slots == 0 || a.side != nullptr) &&
                          x_bytes < ((size_t)1 << 31) && dy_bytes < ((size_t)1 << 31) && side_bytes < ((size_t)1 << 30);
-        if (pair && !dma) throw std::invalid_argument("icn: pair weight gradient outside the LDS-DMA kernel's limits");
+        if ((pair || a.y_taps) && !dma) throw std::invalid_argument("icn: pair weight gradient outside the LDS-DMA kernel's limits");
         const size_t lds_dma = wgrad_lds(BI, BJ, true);
 #define ICN_WG(I, J)                                                                                                       \
     do {                                                                                                                   \
         if (dma)                                                                                                           \
             hipLaunchKernelGGL((k_wgrad_dma<I, J>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.dy2, a.dcode,                  \
                                a.n_slots > 0 ? a.side : nullptr, a.partial, a.bias_partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout,   \
-                               Cout0, a.n_slots, rows, S, (unsigned)x_bytes, (unsigned)side_bytes);                          \
+                               a.y_taps ? a.Cout : Cout0, a.n_slots, rows, S, (unsigned)x_bytes, (unsigned)side_bytes, a.y_taps); \
         else                                                                                                               \
             hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M,   \
                                a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows, S);                                                  \
@@ -1572,6 +1578,53 @@ __global__ void k_spmm_ell(const float* __restrict__ in, float* __restrict__ out
         if (VEC == 4) *reinterpret_cast<f32x4*>(o) = f32x4{accv[0], accv[1], accv[2], accv[3]};
         else o[0] = accv[0];
     }
+}
+
+// Aggregate of the composite backward (icn_upconv_bwd):  g[b, row, c] (+)= sum_e coef[r][e] * dy[b, idx[r][e], c]  with the
+// channel axis c over [dy0 | dy1] (C0 + C1 channels, a pair's two output gradients side by side), row = rows ? rows[r] : r.
+// Main pass: every row of the width-8 table; second pass (acc = 1): the few rows with more than 8 entries (next to the
+// poles), added on top.  HBM/L2-bound: a thread owns 4 channels of one row, its (up to 8) source rows are independent loads.
+__global__ __launch_bounds__(256) void k_upconv_gather(const float* __restrict__ dy0, const float* __restrict__ dy1,
+                                                        float* __restrict__ g, const int32_t* __restrict__ idx,
+                                                        const float* __restrict__ coef, const int32_t* __restrict__ rows, int B,
+                                                        int Pin, int nrows, int rows_total, int C0, int C1, int W, int acc) {
+    const int C = C0 + C1, cv = C / 4;
+    const size_t total = (size_t)B * nrows * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * 4;
+        const size_t br = i / cv;
+        const int r = (int)(br % nrows), b = (int)(br / nrows);
+        const bool second = c >= C0;
+        const float* src = (second ? dy1 : dy0) + (size_t)b * Pin * (second ? C1 : C0) + (second ? c - C0 : c);
+        const int stride = second ? C1 : C0;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int e0 = 0; e0 < W; e0 += 8) {
+            int32_t j[8];
+            float w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool in_row = e0 + k < W;
+                j[k] = in_row ? idx[(size_t)r * W + e0 + k] : -1;
+                w[k] = in_row ? coef[(size_t)r * W + e0 + k] : 0.f;
+            }
+            f32x4 x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = j[k] >= 0 ? ld4(src + (size_t)j[k] * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += w[k] * x[k];
+        }
+        float* o = g + ((size_t)b * rows_total + (rows ? rows[r] : r)) * C + c;
+        if (acc) sum += ld4(o);
+        *reinterpret_cast<f32x4*>(o) = sum;
+    }
+}
+
+void launch_upconv_gather(const float* dy0, const float* dy1, float* g, const int32_t* idx, const float* coef, const int32_t* rows,
+                          int B, int Pin, int nrows, int rows_total, int C0, int C1, int W, int acc, hipStream_t s) {
+    if (nrows <= 0) return;
+    const size_t total = (size_t)B * nrows * ((C0 + C1) / 4);
+    hipLaunchKernelGGL(k_upconv_gather, dim3((unsigned)std::min((size_t)16384, (total + 255) / 256)), dim3(256), 0, s, dy0, dy1, g, idx,
+                       coef, rows, B, Pin, nrows, rows_total, C0, C1, W, acc);
 }
 
 void launch_spmm_ell(const float* in, float* out, const int32_t* idx, const float* coef, int B, int Pin, int Pout, int C,

@@ -60,6 +60,7 @@ struct WgradArgs {
     float* dbias2;          // [Cout - Cout0] or null
     int M, Ps, Pd, Cin, Cout, ns;
     double algo_flops;
+    int y_taps;             // 7: dy is the tap-major aggregate g (M, 7, Cout) of icn_upconv_bwd and dcode one table [Pd]; else 0
 };
 
 bool gather_gemm_supported(int K, int N);
@@ -74,6 +75,11 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s);
 bool stem_supported(int Cin, int Cout);
 void launch_stem_fwd(const float* x, const float* w, const float* bias, float* y, const int32_t* idx, int M, int Ps, int Pd,
                      int Cin, int Cout, int ns, hipStream_t s);
+
+// g[b, rows ? rows[r] : r, :] (+)= sum_e coef[r][e] * [dy0 | dy1][b, idx[r][e], :]   (aggregate of icn_upconv_bwd; g has
+// rows_total rows of C0 + C1 channels per sample; acc: add to what is there)
+void launch_upconv_gather(const float* dy0, const float* dy1, float* g, const int32_t* idx, const float* coef, const int32_t* rows,
+                          int B, int Pin, int nrows, int rows_total, int C0, int C1, int W, int acc, hipStream_t s);
 
 void launch_spmm_ell(const float* in, float* out, const int32_t* idx, const float* coef, int B, int Pin, int Pout, int C,
                      int W, hipStream_t s);

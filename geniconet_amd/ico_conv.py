@@ -11,6 +11,7 @@ stream.  There is no CPU implementation here: CPU tensors are rejected (the CPU 
 is test infrastructure under oracle/).
 """
 import math
+import os
 
 import torch
 
@@ -31,6 +32,9 @@ def _check_grid(x, r, who):
     if x.dim() != 4 or x.shape[2] != 5 * n or x.shape[3] != 2 * n:
         raise ValueError('%s: expected (B, C, %d, %d) at subdivisions=%d, got %s'
                          % (who, 5 * n, 2 * n, r, tuple(x.shape)))
+
+
+_NO_UPCONV_BWD = os.environ.get('ICN_NO_UPCONV_BWD', '') == '1'    # developer switch: backward of the separate operators
 
 
 def _nhwc(x):
@@ -188,9 +192,11 @@ class _IcoUpsampleFn(torch.autograd.Function):
 class _IcoUpConvPairFn(torch.autograd.Function):
     """(conv0(upsample(x)), conv1(upsample(x))) -- the head of the reference's decoder block (models.py:58-60) -- with the
     FORWARD computed from the coarse tensor by one composite gather-GEMM (icn_upconv_fwd in include/icn.h: 0.68 of the
-    multiply-adds, no upsampled tensor).  Backward is that of the separate operators: the upsample is recomputed from x
-    (an HBM-bound pass), the pair's bwd-data / bwd-weight kernels run on it, and the upsample's transpose brings the
-    gradient back to the coarse level.  Same results as ico_conv_pair(ico_upsample(x), ...) up to fp32 rounding order."""
+    multiply-adds, no upsampled tensor) and the BACKWARD through one coarse-level aggregate of the output gradients
+    (icn_upconv_bwd: both gradients as dense coarse-level contractions, a quarter of the multiply-adds).  With 'zeros' poles
+    or shapes outside that path the backward is that of the separate operators: the upsample is recomputed from x, the pair's
+    bwd-data / bwd-weight kernels run on it, and the upsample's transpose brings the gradient back to the coarse level.
+    Same results as ico_conv_pair(ico_upsample(x), ...) up to fp32 rounding order."""
 
     @staticmethod
     def forward(ctx, x, w0, b0, w1, b1, r, mode):
@@ -226,6 +232,23 @@ class _IcoUpConvPairFn(torch.autograd.Function):
         dev = g0.device
         dx = dw0 = db0 = dw1 = db1 = None
         need = ctx.needs_input_grad
+        want_w = need[1] or need[3] or (has_bias and (need[2] or need[4]))
+        if not _NO_UPCONV_BWD and L.icn_upconv_bwd_supported(B, Cin, C0, C1, r, mode):
+            # both gradients from one coarse-level aggregate of (gy0 | gy1): a quarter of the fine level's multiply-adds
+            dxp = torch.empty(B, 5 * n, 2 * n, Cin, dtype=torch.float32, device=dev) if need[0] else None
+            if want_w:
+                dw0, dw1 = torch.empty_like(w0), torch.empty_like(w1)
+                if has_bias:
+                    db0 = torch.empty(C0, dtype=torch.float32, device=dev)
+                    db1 = torch.empty(C1, dtype=torch.float32, device=dev)
+            ws_bytes = L.icn_upconv_bwd_workspace_bytes(B, Cin, C0, C1, r)
+            ws = _workspace(ws_bytes, dev)
+            ptr = lambda t: t.data_ptr() if t is not None else None
+            with torch.cuda.device(dev):
+                _lib.check(L.icn_upconv_bwd(xp.data_ptr(), g0.data_ptr(), g1.data_ptr(), w0.data_ptr(), w1.data_ptr(), ptr(dxp),
+                                            ptr(dw0), ptr(db0), ptr(dw1), ptr(db1), B, Cin, C0, C1, r, mode, ws.data_ptr(),
+                                            ws_bytes, _stream()), 'icn_upconv_bwd')
+            return (dxp.permute(0, 3, 1, 2) if dxp is not None else None), dw0, db0, dw1, db1, None, None
         with torch.cuda.device(dev):
             st = _stream()
             if need[0]:
@@ -238,7 +261,7 @@ class _IcoUpConvPairFn(torch.autograd.Function):
                 _lib.check(L.icn_upsample_bwd(dup.data_ptr(), dxp.data_ptr(), B, Cin, r, mode, st), 'icn_upsample_bwd')
                 del dup
                 dx = dxp.permute(0, 3, 1, 2)
-            if need[1] or need[3] or (has_bias and (need[2] or need[4])):
+            if want_w:
                 up = torch.empty(B, 5 * nf, 2 * nf, Cin, dtype=torch.float32, device=dev)
                 _lib.check(L.icn_upsample_fwd(xp.data_ptr(), up.data_ptr(), B, Cin, r, mode, st), 'icn_upsample_fwd')
                 dw0, dw1 = torch.empty_like(w0), torch.empty_like(w1)

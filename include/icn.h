@@ -103,6 +103,20 @@ size_t icn_upconv_workspace_bytes(int B, int Cin, int Cout0, int Cout1, int r_in
 int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const float* w1, const float* bias1, float* y0, float* y1, int B,
                    int Cin, int Cout0, int Cout1, int r_in, int corner_mode, void* ws, size_t ws_bytes, void* stream);
 
+/* Backward of the same pair, aggregated at the COARSE level.  With U the upsample matrix and nbr_t the fine conv's gather,
+ *     g_t[s] = sum_p U[nbr_t(p), s] dy[p]           (one HBM-bound pass over dy0 | dy1; 7 coarse tensors, tap-major rows)
+ * both gradients become dense coarse-level contractions with a QUARTER of the fine level's multiply-adds and no gather:
+ *     dx[s] = sum_t W_t^T g_t[s]        dW_t = sum_s x[s]^T g_t[s]        dbias = sum_s g_0[s]
+ * -- equal to icn_conv_(pair_)bwd_data at level r_in + 1 followed by icn_upsample_bwd, and to icn_conv_(pair_)bwd_weight on
+ * icn_upsample_fwd(x), up to fp32 rounding order.  dx and (dw0, dbias0, dw1, dbias1) are each optional (NULL); x is only read
+ * for the weight gradients, w0 / w1 only for dx.  corner_mode 'average' only (dbias relies on upsample rows summing to one);
+ * other shapes / modes: icn_upconv_bwd_supported() == 0 and the caller uses the separate operators' backward. */
+int icn_upconv_bwd_supported(int B, int Cin, int Cout0, int Cout1, int r_in, int corner_mode);
+size_t icn_upconv_bwd_workspace_bytes(int B, int Cin, int Cout0, int Cout1, int r_in);
+int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const float* w0, const float* w1, float* dx, float* dw0,
+                   float* dbias0, float* dw1, float* dbias1, int B, int Cin, int Cout0, int Cout1, int r_in, int corner_mode, void* ws,
+                   size_t ws_bytes, void* stream);
+
 /* Fused BatchNorm + ReLU of the residual blocks (training mode; replaces the torch builtins at models.py:36-40,58-62).
  * Tensors are channels-last rows (M = B * pixels, C), C in {64, 128, 256, 512, ...: C % 4 == 0 and 256 % (C/4) == 0}.
  *   stat   [2*C]  batch mean | 1/sqrt(var + eps), written by icn_bn_stats and read by the other two
@@ -180,6 +194,9 @@ long icn_table_faces(int r, int32_t* out, size_t cap);                          
  * pixels) | code[NV][P_fine] (by list position: coarse pixel, -1 nothing, -2 - slot) | slot_idx[n_slots][E];
  * floats = alpha[NV][7] (W_eff[v] = sum_t alpha[v][t] W_t) | slot_coef[n_slots][E].  Returns the number of ints. */
 long icn_table_upconv(int r_in, int corner_mode, int32_t* ints, size_t cap_ints, float* floats, size_t cap_floats, int* meta);
+/* ELL matrix dy (fine) -> g (coarse, 7 taps) of the aggregated backward of the same pair (icn_upconv_bwd): row s * 7 + t
+ * lists the fine pixels and coefficients of g_t[s]; [7 * P_coarse][width], -1 padded. */
+long icn_table_upconv_bwd(int r_in, int corner_mode, int32_t* idx, float* coef, size_t cap, int* width);
 
 /* Optional diagnostics: HIP-event timing of every MFMA kernel launch between start and stop, on the launch
  * stream.  `stop` synchronises the device and returns the number of entries written (one per kernel that ran).

@@ -38,7 +38,7 @@ def test_training_trajectory_matches_the_oracle_trainer(name, monkeypatch):
     Bounds: loss 1e-4 relative at the first step (identical weights), 1e-3 after; the weight UPDATE w - w_init of every tensor with a non-zero true gradient 0.15
     rel-L2 -- Adam divides by sqrt(v), so an element whose gradient is at rounding-noise level (whole-network gradients agree
     to ~1e-3) moves by a full +-lr on either side: 0.1 % of such elements already give 0.06, and the two trajectories then
-    drift apart at that level -- hence also 2e-3 rel-L2 on the BatchNorm running statistics after three steps (the statistics
+    drift apart at that level -- hence also 5e-3 rel-L2 on the BatchNorm running statistics after three steps (the statistics
     of a single step from identical weights are held to 1e-4 in test_gpu_parity.py)."""
     from geniconet_amd import data, models
     from geniconet_amd.train import Trainer, build_criterion
@@ -74,7 +74,7 @@ def test_training_trajectory_matches_the_oracle_trainer(name, monkeypatch):
         if 'num_batches_tracked' in key:
             assert int(vg) == int(vc) == STEPS, key
         elif 'running' in key:
-            assert rel_l2(vg.numpy(), vc.numpy()) < 2e-3, key
+            assert rel_l2(vg.numpy(), vc.numpy()) < 5e-3, key
         elif not _zero_true_gradient(key):
             du_g, du_c = (vg - init[key]).numpy(), (vc - init[key]).numpy()
             assert np.linalg.norm(du_c) > 0, key

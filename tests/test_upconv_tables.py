@@ -71,3 +71,40 @@ def test_virtual_taps_are_the_documented_ones():
     assert np.allclose(a[:19].sum(0), 4 * np.ones(7))                                   # every W_t is used with total weight 4 = 4 fine pixels
     masks = [int(m) for m in tab['seg'][:, 2]]
     assert masks == [0x7f, 0xf << 7, 0xf << 11, 0xf << 15, 0x7f << 19]
+
+
+@pytest.mark.parametrize('mode', ['average', 'zeros'])
+@pytest.mark.parametrize('r', [0, 1, 2, 3])
+def test_aggregated_backward_table_gives_both_gradients(r, mode):
+    """icn_table_upconv_bwd: g_t[s] = sum_p U[nbr_t(p), s] dy[p] turns the backward of conv(upsample(x)) into dense
+    coarse-level contractions, dx[s] = sum_t W_t^T g_t[s] and dW_t = sum_s x[s]^T g_t[s] (and dbias = sum_s g_0[s] for
+    'average' poles) -- checked against autograd through the oracle's two operators (float64)."""
+    idx, coef = _lib.table_upconv_bwd(r, mode)
+    n = 2 ** r
+    Pc, Pf = 10 * n * n, 40 * n * n
+    assert idx.shape[0] == 7 * Pc
+    g = torch.Generator().manual_seed(9 + r)
+    B, Cin, Cout = 2, 3, 4
+    x = torch.randn(B, Cin, 5 * n, 2 * n, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, 7, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(Cout, generator=g, dtype=torch.float64, requires_grad=True)
+    y = ico_ref.ico_conv(ico_ref.ico_upsample(x, r, mode), w, b, r + 1, 1, mode)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    dyf = dy.reshape(B, Cout, Pf).numpy()
+    gt = np.zeros((B, Cout, Pc, 7))
+    for row in range(7 * Pc):
+        s, t = divmod(row, 7)
+        for p, c in zip(idx[row], coef[row]):
+            if p >= 0:
+                gt[:, :, s, t] += float(c) * dyf[:, :, p]
+    wn, xn = w.detach().numpy(), x.detach().reshape(B, Cin, Pc).numpy()
+    dx = np.einsum('oit,bost->bis', wn, gt)
+    dw = np.einsum('bis,bost->oit', xn, gt)
+    assert rel_l2(dx, x.grad.reshape(B, Cin, Pc).numpy()) < 1e-6
+    assert rel_l2(dw, w.grad.numpy()) < 1e-6
+    if mode == 'average':
+        assert rel_l2(gt[:, :, :, 0].sum((0, 2)), b.grad.numpy()) < 1e-6
+    if r >= 2:
+        used = (idx >= 0).sum(1)
+        assert int(np.median(used)) == 7 and idx.shape[1] <= 24
