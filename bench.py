@@ -191,6 +191,9 @@ def main():
                 'kernel': dom['kernel'], 'launches_per_step': dom['launches'] / args.steps,
                 'avg_launch_us': round(per_launch_ms * 1e3, 2),
                 'algorithmic_gflop_per_launch': round(dom['total_flops'] / dom['launches'] / 1e9, 3),
+                # per-kernel figures count the FLOPs a launch executes (= algorithmic for ordinary convolutions; the composite
+                # upsample+conv launches of the decoder execute 0.68 x / 0.25 x of the operators they replace), so frac <= 1
+                'flops_counted': 'executed',
                 'all_mfma_kernels': [{'kernel': e['kernel'], 'launches_per_step': e['launches'] / args.steps,
                                       'avg_launch_us': round(e['total_ms'] / e['launches'] * 1e3, 2),
                                       'tflops': round(e['total_flops'] / (e['total_ms'] * 1e-3) / 1e12, 2)} for e in prof],
@@ -198,6 +201,10 @@ def main():
                 'step_tflops': round(value * TRAIN_GFLOP_PER_MESH[(cfg['model'], cfg['R'])] / 1e3, 2),
                 'step_frac_of_mfma_peak': round(value * TRAIN_GFLOP_PER_MESH[(cfg['model'], cfg['R'])] / 1e3
                                                 / PEAK_FP32_MFMA_TFLOPS / world, 4),
+                # step_tflops is ALGORITHMIC (3 x forward conv FLOPs of the reference's operator graph);
+                # the MFMA launches of this implementation execute fewer (composite decoder blocks):
+                'step_executed_tflops': round(sum(e['total_flops'] for e in prof) / args.steps / (elapsed / args.steps) / 1e12, 2),
+                'step_executed_gflop': round(sum(e['total_flops'] for e in prof) / args.steps / 1e9, 1),
                 # the HBM side of the same step (SURVEY 8d asks for both fractions; the binding one is MFMA)
                 'achieved_hbm': round(value * TRAIN_MB_PER_MESH[(cfg['model'], cfg['R'])] / 1e3 / world, 1),
                 'peak_hbm': PEAK_HBM_GBPS, 'unit_hbm': 'GB/s',

@@ -84,12 +84,48 @@ struct UpconvDev {
     float *alpha = nullptr, *slot_coef = nullptr;
 };
 
-// device tables of the aggregated backward (icn_upconv_bwd): dy -> g as a width-8 ELL matrix over all 7 * Pc rows plus an
-// overflow matrix over the few rows with more entries; iota = identity table [Pc] (the coarse-level GEMMs do not gather)
+// An ELL matrix on the device, split into a main part of fixed width (every row) and an overflow part over the few rows
+// with more entries (rows next to the poles), which a second launch adds on top.
+struct EllSplitDev {
+    int W = 0, n_ovf = 0, W_ovf = 0;
+    int32_t *idx = nullptr, *ovf_rows = nullptr, *ovf_idx = nullptr;
+    float *coef = nullptr, *ovf_coef = nullptr;
+};
+EllSplitDev upload_ell_split(const icn::Ell& e, int W_main) {
+    EllSplitDev d;
+    const int W = e.width;
+    d.W = W_main;
+    d.W_ovf = std::max(W - W_main, 0);
+    std::vector<int32_t> idx((size_t)e.rows * W_main, icn::IDX_ZERO), ovf_rows, ovf_idx;
+    std::vector<float> coef((size_t)e.rows * W_main, 0.f), ovf_coef;
+    for (int r = 0; r < e.rows; ++r) {
+        for (int k = 0; k < std::min(W, W_main); ++k) {
+            idx[(size_t)r * W_main + k] = e.idx[(size_t)r * W + k];
+            coef[(size_t)r * W_main + k] = e.coef[(size_t)r * W + k];
+        }
+        if (W > W_main && e.idx[(size_t)r * W + W_main] != icn::IDX_ZERO) {       // rows are left-packed
+            ovf_rows.push_back(r);
+            for (int k = W_main; k < W; ++k) {
+                ovf_idx.push_back(e.idx[(size_t)r * W + k]);
+                ovf_coef.push_back(e.coef[(size_t)r * W + k]);
+            }
+        }
+    }
+    d.n_ovf = (int)ovf_rows.size();
+    d.idx = upload(idx);
+    d.coef = upload(coef);
+    d.ovf_rows = upload(ovf_rows);
+    d.ovf_idx = upload(ovf_idx);
+    d.ovf_coef = upload(ovf_coef);
+    return d;
+}
+
+// device tables of the aggregated paths of the decoder-block head: dy -> g (icn_upconv_bwd) and z -> y (dense forward of
+// icn_upconv_fwd) as split ELL matrices; iota = identity table [Pc] (the coarse-level GEMMs do not gather)
 struct UpconvBwdDev {
-    int Pc = 0, Pf = 0, W8 = 8, n_ovf = 0, W_ovf = 0;
-    int32_t *idx8 = nullptr, *ovf_rows = nullptr, *ovf_idx = nullptr, *iota = nullptr;
-    float *coef8 = nullptr, *ovf_coef = nullptr;
+    int Pc = 0, Pf = 0;
+    EllSplitDev gather, scatter;
+    int32_t* iota = nullptr;
 };
 
 std::mutex g_mu;
@@ -210,35 +246,16 @@ const UpconvBwdDev& upconv_bwd_tables(int r_in, int mode) {
     auto key = std::make_tuple(dev, r_in, mode);
     auto it = g_upconv_bwd.find(key);
     if (it != g_upconv_bwd.end()) return it->second;
-    icn::Ell e;
+    icn::Ell e, f;
     icn::build_upconv_bwd(r_in, mode, e);
+    icn::build_upconv_scatter(r_in, mode, f);
     UpconvBwdDev d;
     d.Pc = icn::pixels(r_in);
     d.Pf = 4 * d.Pc;
-    const int W = e.width, W8 = d.W8;
-    std::vector<int32_t> idx8((size_t)e.rows * W8, icn::IDX_ZERO), ovf_rows, ovf_idx, iota(d.Pc);
-    std::vector<float> coef8((size_t)e.rows * W8, 0.f), ovf_coef;
-    d.W_ovf = std::max(W - W8, 0);
-    for (int r = 0; r < e.rows; ++r) {
-        for (int k = 0; k < std::min(W, W8); ++k) {
-            idx8[(size_t)r * W8 + k] = e.idx[(size_t)r * W + k];
-            coef8[(size_t)r * W8 + k] = e.coef[(size_t)r * W + k];
-        }
-        if (W > W8 && e.idx[(size_t)r * W + W8] != icn::IDX_ZERO) {          // rows are left-packed
-            ovf_rows.push_back(r);
-            for (int k = W8; k < W; ++k) {
-                ovf_idx.push_back(e.idx[(size_t)r * W + k]);
-                ovf_coef.push_back(e.coef[(size_t)r * W + k]);
-            }
-        }
-    }
+    d.gather = upload_ell_split(e, 8);             // 7 entries per row away from the singular vertices
+    d.scatter = upload_ell_split(f, 16);           // 12-13
+    std::vector<int32_t> iota(d.Pc);
     for (int i = 0; i < d.Pc; ++i) iota[i] = i;
-    d.n_ovf = (int)ovf_rows.size();
-    d.idx8 = upload(idx8);
-    d.coef8 = upload(coef8);
-    d.ovf_rows = upload(ovf_rows);
-    d.ovf_idx = upload(ovf_idx);
-    d.ovf_coef = upload(ovf_coef);
     d.iota = upload(iota);
     return g_upconv_bwd.emplace(key, d).first->second;
 }
@@ -696,10 +713,27 @@ bool upconv_supported(int B, int Cin, int C0, int C1, int r_in) {
     if ((size_t)B * upconv_slots(r_in) * Cin * 4 >= lim / 2) return false;
     return true;
 }
+// Two forward methods.  COMPOSITE: one gather-GEMM over the coarse tensor with 19 virtual taps (0.68 of the multiply-adds).
+// DENSE: z_t[s] = W_t x[s] for all taps as one dense coarse-level GEMM (N = 7 * C, a quarter of the multiply-adds) followed by
+// the HBM-bound combination y[p] = bias + sum U[nbr_t(p), s] z_t[s].  ICN_UPCONV_FWD=composite|dense overrides the choice.
+bool upconv_dense_ok(int B, int Cin, int C0, int C1, int r_in) {
+    const size_t Pc = icn::pixels(r_in), C = (size_t)C0 + C1;
+    return Cin >= 128 && (size_t)B * Pc * 7 * C * 4 < ((size_t)1 << 31) && (size_t)7 * C * Cin * 4 < ((size_t)1 << 31);
+}
+bool upconv_use_dense(int B, int Cin, int C0, int C1, int r_in) {
+    if (!upconv_dense_ok(B, Cin, C0, C1, r_in)) return false;
+    static const char* force = getenv("ICN_UPCONV_FWD");
+    if (force && force[0] == 'c') return false;
+    if (force && force[0] == 'd') return true;
+    return true;
+}
 size_t upconv_ws_bytes(int B, int Cin, int C0, int C1, int r_in) {
     const size_t C = (size_t)C0 + C1;
-    return align256((size_t)icn::UPCONV_TAPS * C * Cin * sizeof(float)) + align256(C * sizeof(float)) +
-           align256((size_t)B * upconv_slots(r_in) * Cin * sizeof(float));
+    const size_t composite = align256((size_t)icn::UPCONV_TAPS * C * Cin * sizeof(float)) + align256(C * sizeof(float)) +
+                             align256((size_t)B * upconv_slots(r_in) * Cin * sizeof(float));
+    const size_t dense = align256((size_t)7 * C * Cin * sizeof(float)) + align256(C * sizeof(float)) +
+                         align256((size_t)B * icn::pixels(r_in) * 7 * C * sizeof(float));
+    return upconv_dense_ok(B, Cin, C0, C1, r_in) ? std::max(composite, dense) : composite;
 }
 }  // namespace
 
@@ -728,9 +762,33 @@ int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const fl
         if (corner_mode != 0 && corner_mode != 1) throw std::invalid_argument("icn: corner_mode must be 0 (zeros) or 1 (average)");
         if (!upconv_supported(B, Cin, Cout0, Cout1, r_in)) throw std::invalid_argument("icn_upconv_fwd: unsupported shape");
         if (!ws || ws_bytes < upconv_ws_bytes(B, Cin, Cout0, Cout1, r_in)) throw std::invalid_argument("icn_upconv_fwd: workspace too small");
-        const UpconvDev& t = upconv_tables(r_in, corner_mode);
         hipStream_t s = static_cast<hipStream_t>(stream);
         const int C = Cout0 + Cout1;
+        if (upconv_use_dense(B, Cin, Cout0, Cout1, r_in)) {
+            const UpconvBwdDev& d = upconv_bwd_tables(r_in, corner_mode);
+            const size_t wb = align256((size_t)7 * C * Cin * sizeof(float)), bb = align256((size_t)C * sizeof(float));
+            float* wf = static_cast<float*>(ws);
+            float* bias_cat = (w1 && bias0) ? reinterpret_cast<float*>(at(ws, wb)) : nullptr;
+            float* z = reinterpret_cast<float*>(at(ws, wb + bb));
+            icn::PrologueArgs p{};                     // [7][C][Cin] = the B operand [1][N = 7 * C][K = Cin] of one dense GEMM
+            p.w = w0; p.w2 = w1; p.packed = wf; p.Cout = Cout0; p.Cout2 = Cout1; p.Cin = Cin; p.transpose = 0;
+            p.bias = bias0; p.bias2 = bias1; p.bias_cat = bias_cat;
+            icn::launch_conv_prologue(p, s);
+            icn::GatherGemmArgs a{};
+            a.src = x; a.wt = wf; a.dst = z; a.N0 = 7 * C; a.dcode = d.iota; a.perm = d.iota;
+            a.Ps = d.Pc; a.Pd = d.Pc; a.K = Cin; a.N = 7 * C; a.E = 1; a.T = 1; a.M = B * d.Pc;
+            a.segs.nseg = 1; a.segs.B = B; a.segs.cnt[0] = d.Pc; a.segs.off[0] = 0; a.segs.mask[0] = 1u;
+            a.algo_flops = 2.0 * 7 * Cin * C * (double)B * d.Pc;                  // executed: a quarter of the fine-level forward
+            icn::launch_gather_gemm_auto(a, s);
+            const EllSplitDev& sc = d.scatter;
+            const float* bias = w1 ? bias_cat : bias0;
+            icn::launch_upconv_scatter(z, bias, y0, y1, sc.idx, sc.coef, nullptr, B, 7 * d.Pc, d.Pf, d.Pf, Cout0, Cout1, sc.W, 0, s);
+            icn::launch_upconv_scatter(z, nullptr, y0, y1, sc.ovf_idx, sc.ovf_coef, sc.ovf_rows, B, 7 * d.Pc, sc.n_ovf, d.Pf, Cout0, Cout1,
+                                       sc.W_ovf, 1, s);
+            ICN_HIP(hipGetLastError());
+            return 0;
+        }
+        const UpconvDev& t = upconv_tables(r_in, corner_mode);
         const size_t wbytes = align256((size_t)icn::UPCONV_TAPS * C * Cin * sizeof(float));
         float* weff = static_cast<float*>(ws);
         float* bias_cat = (w1 && bias0) ? reinterpret_cast<float*>(at(ws, wbytes)) : nullptr;
@@ -747,7 +805,9 @@ int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const fl
         a.segs.nseg = t.nseg; a.segs.B = B;
         for (int i = 0; i < t.nseg; ++i) { a.segs.cnt[i] = t.seg_cnt[i]; a.segs.off[i] = t.seg_off[i]; a.segs.mask[i] = t.seg_mask[i]; }
         a.M = B * t.Pf;                                          // the launch pads the row segments to its tile height
-        a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pf;      // of the two operators it replaces (executed: ~0.68 of it)
+        double taps = 0;                                         // executed: 7 (coarse-site rows) or 4 (midpoint rows) K-blocks per row,
+        for (int i = 0; i < t.nseg; ++i) taps += (double)t.seg_cnt[i] * __builtin_popcount(t.seg_mask[i]);   // ~0.68 of the 7 per row
+        a.algo_flops = 2.0 * Cin * C * (double)B * taps;         // of the two operators it replaces (2 * 7 * Cin * C * B * Pf)
         icn::launch_gather_gemm_auto(a, s);
         ICN_HIP(hipGetLastError());
         return 0;
@@ -810,8 +870,9 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
         const int C = Cout0 + Cout1, M = B * t.Pc;
         float* g = reinterpret_cast<float*>(at(ws, wo.g));
         // 1. g[b, s, t, :] = sum_p U[nbr_t(p), s] [dy0 | dy1][b, p, :]
-        icn::launch_upconv_gather(dy0, dy1, g, t.idx8, t.coef8, nullptr, B, t.Pf, 7 * t.Pc, 7 * t.Pc, Cout0, Cout1, t.W8, 0, s);
-        icn::launch_upconv_gather(dy0, dy1, g, t.ovf_idx, t.ovf_coef, t.ovf_rows, B, t.Pf, t.n_ovf, 7 * t.Pc, Cout0, Cout1, t.W_ovf, 1, s);
+        const EllSplitDev& ga = t.gather;
+        icn::launch_upconv_gather(dy0, dy1, g, ga.idx, ga.coef, nullptr, B, t.Pf, 7 * t.Pc, 7 * t.Pc, Cout0, Cout1, ga.W, 0, s);
+        icn::launch_upconv_gather(dy0, dy1, g, ga.ovf_idx, ga.ovf_coef, ga.ovf_rows, B, t.Pf, ga.n_ovf, 7 * t.Pc, Cout0, Cout1, ga.W_ovf, 1, s);
         if (dx) {
             // 2. dx[b, s, :] = g[b, s, (t, c)] . Wb[(t, c), :]: a dense GEMM, K = 7 * C (one "tap" whose gather is the identity)
             float* wb = reinterpret_cast<float*>(at(ws, wo.wb));
@@ -822,7 +883,7 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
             a.src = g; a.wt = wb; a.dst = dx; a.N0 = Cin; a.dcode = t.iota; a.perm = t.iota;
             a.Ps = t.Pc; a.Pd = t.Pc; a.K = 7 * C; a.N = Cin; a.E = 1; a.T = 1; a.M = M;
             a.segs.nseg = 1; a.segs.B = B; a.segs.cnt[0] = t.Pc; a.segs.off[0] = 0; a.segs.mask[0] = 1u;
-            a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pf;            // of the fine-level bwd-data it replaces
+            a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pc;            // executed: a quarter of the fine-level bwd-data it replaces
             icn::launch_gather_gemm_auto(a, s);
         }
         if (dw0) {
@@ -833,7 +894,7 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
             a.bias_partial = (dbias0 || dbias1) ? reinterpret_cast<float*>(at(ws, wo.bpart)) : nullptr;
             a.dw = dw0; a.dbias = dbias0; a.dw2 = dw1; a.dbias2 = dbias1;
             a.M = M; a.Ps = t.Pc; a.Pd = t.Pc; a.Cin = Cin; a.Cout = C; a.ns = 1 << r_in;
-            a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pf;
+            a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pc;            // executed: a quarter of the fine-level bwd-weight
             icn::launch_wgrad(a, s);
         }
         ICN_HIP(hipGetLastError());
@@ -988,15 +1049,16 @@ int icn_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const f
     }
 }
 
-int icn_bn_relu_bwd(const float* dy, const float* y, const float* a, const float* b, const float* stat_a, const float* stat_b,
-                    const float* gamma_a, const float* gamma_b, float* da, float* db, float* sums, float* ws, int M, int C,
-                    void* stream) {
+int icn_bn_relu_bwd(const float* dy, const float* a, const float* b, const float* stat_a, const float* stat_b, const float* gamma_a,
+                    const float* beta_a, const float* gamma_b, const float* beta_b, float* da, float* db, float* sums, float* ws, int M,
+                    int C, void* stream) {
     try {
-        if (!dy || !y || !a || !stat_a || !gamma_a || !da || !sums || !ws || M < 1)
+        if (!dy || !a || !stat_a || !gamma_a || !beta_a || !da || !sums || !ws || M < 1)
             throw std::invalid_argument("icn_bn_relu_bwd: bad arguments");
-        if (b && (!stat_b || !gamma_b || !db)) throw std::invalid_argument("icn_bn_relu_bwd: second input needs its buffers");
+        if (b && (!stat_b || !gamma_b || !beta_b || !db)) throw std::invalid_argument("icn_bn_relu_bwd: second input needs its buffers");
         if (!icn::bn_supported(C)) throw std::invalid_argument("icn_bn_relu_bwd: unsupported channel count");
-        icn::launch_bn_relu_bwd(dy, y, a, b, stat_a, stat_b, gamma_a, gamma_b, da, db, sums, ws, M, C, static_cast<hipStream_t>(stream));
+        icn::launch_bn_relu_bwd(dy, a, b, stat_a, stat_b, gamma_a, beta_a, gamma_b, beta_b, da, db, sums, ws, M, C,
+                                static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());
         return 0;
     } catch (const std::exception& e) {

@@ -19,17 +19,31 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f),
 
 constexpr int BN_MAX_CHUNKS = 512;
 
+// pre-activation of the fused op for 4 channels: bn_a(a) [+ bn_b(b)]; scale = invstd * gamma.  Forward and both backward
+// passes go through this one function, so the ReLU mask the backward recomputes is bit-identical to the forward's.
+template <int DUAL>
+__device__ __forceinline__ f32x4 bn_pre4(f32x4 a, f32x4 mean_a, f32x4 scale_a, f32x4 beta_a, f32x4 b, f32x4 mean_b, f32x4 scale_b,
+                                         f32x4 beta_b) {
+    f32x4 v = (a - mean_a) * scale_a + beta_a;
+    if (DUAL) v += (b - mean_b) * scale_b + beta_b;
+    return v;
+}
+
 // partial[chunk][k][C], k < NS: per-channel sums of NS quantities over the chunk's rows.
 //   MODE 0 (forward stats of x):                 k0 = sum (x - x0), k1 = sum (x - x0)^2       x0 = row 0 of x (per channel)
 //          The shift keeps var = E[(x-x0)^2] - E[x-x0]^2 free of cancellation when |mean| >> std (torch uses Welford;
 //          a plain E[x^2] - mean^2 in fp32 loses the variance of e.g. x = 100 + randn).
-//   MODE 1 (backward of relu(bn(x))):            k0 = sum g,        k1 = sum g * xhat         g = dy * (y > 0)
+//   MODE 1 (backward of relu(bn(x))):            k0 = sum g,        k1 = sum g * xhat         g = dy * (v > 0)
 //   MODE 2 (backward of relu(bn_a(a)+bn_b(b))):  k0 = sum g,        k1 = sum g * ahat,  k2 = sum g * bhat
+//          v = the pre-activation, RECOMPUTED from a (and b) with the forward's own expression (bn_pre4) instead of reading
+//          the saved output y: one tensor less to stream in each of the two backward passes.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0, const float* __restrict__ p1,
-                                                     const float* __restrict__ p2, const float* __restrict__ p3,
-                                                     const float* __restrict__ stat_a, const float* __restrict__ stat_b,
-                                                     float* __restrict__ partial, int M, int C, int rows_per_chunk) {
+__global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0, const float* __restrict__ p2,
+                                                     const float* __restrict__ p3, const float* __restrict__ stat_a,
+                                                     const float* __restrict__ stat_b, const float* __restrict__ ga,
+                                                     const float* __restrict__ ba, const float* __restrict__ gb,
+                                                     const float* __restrict__ bb, float* __restrict__ partial, int M, int C,
+                                                     int rows_per_chunk) {
     constexpr int NS = MODE == 2 ? 3 : 2;
     __shared__ f32x4 red[NS][256];
     const int c4n = C / 4, stripes = 256 / c4n;
@@ -38,9 +52,9 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
     f32x4 s[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) s[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 mean_a{}, inv_a{}, mean_b{}, inv_b{};
-    if (MODE >= 1) { mean_a = ldv(stat_a + c); inv_a = ldv(stat_a + C + c); }
-    if (MODE == 2) { mean_b = ldv(stat_b + c); inv_b = ldv(stat_b + C + c); }
+    f32x4 mean_a{}, inv_a{}, mean_b{}, inv_b{}, sc_a{}, sc_b{}, be_a{}, be_b{};
+    if (MODE >= 1) { mean_a = ldv(stat_a + c); inv_a = ldv(stat_a + C + c); sc_a = inv_a * ldv(ga + c); be_a = ldv(ba + c); }
+    if (MODE == 2) { mean_b = ldv(stat_b + c); inv_b = ldv(stat_b + C + c); sc_b = inv_b * ldv(gb + c); be_b = ldv(bb + c); }
     f32x4 shift{};
     if (MODE == 0) shift = ldv(p0 + c);
     if (stripe < stripes) {
@@ -51,14 +65,17 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
                 s[0] += x;
                 s[1] += x * x;
             } else {
-                // p0 = dy, p1 = y (output of the fused op), p2 = x / a, p3 = b
-                const f32x4 dy = ldv(p0 + o), y = ldv(p1 + o);
+                // p0 = dy, p2 = x / a, p3 = b
+                const f32x4 dy = ldv(p0 + o), av = ldv(p2 + o);
+                f32x4 bv{};
+                if (MODE == 2) bv = ldv(p3 + o);
+                const f32x4 v = bn_pre4<MODE == 2>(av, mean_a, sc_a, be_a, bv, mean_b, sc_b, be_b);
                 f32x4 g;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = y[j] > 0.f ? dy[j] : 0.f;
+                for (int j = 0; j < 4; ++j) g[j] = v[j] > 0.f ? dy[j] : 0.f;
                 s[0] += g;
-                s[1] += g * ((ldv(p2 + o) - mean_a) * inv_a);
-                if (MODE == 2) s[2] += g * ((ldv(p3 + o) - mean_b) * inv_b);
+                s[1] += g * ((av - mean_a) * inv_a);
+                if (MODE == 2) s[2] += g * ((bv - mean_b) * inv_b);
             }
         }
     }
@@ -142,32 +159,38 @@ __global__ void k_bn_relu_fwd(const float* __restrict__ a, const float* __restri
                               int C) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
-        f32x4 v = (ldv(a + i * 4) - ldv(stat_a + c)) * (ldv(stat_a + C + c) * ldv(ga + c)) + ldv(ba + c);
-        if (DUAL) v += (ldv(b + i * 4) - ldv(stat_b + c)) * (ldv(stat_b + C + c) * ldv(gb + c)) + ldv(bb + c);
+        f32x4 bv{}, mb{}, sb{}, bbv{};
+        if (DUAL) { bv = ldv(b + i * 4); mb = ldv(stat_b + c); sb = ldv(stat_b + C + c) * ldv(gb + c); bbv = ldv(bb + c); }
+        const f32x4 v = bn_pre4<DUAL>(ldv(a + i * 4), ldv(stat_a + c), ldv(stat_a + C + c) * ldv(ga + c), ldv(ba + c), bv, mb, sb, bbv);
         stv(y + i * 4, relu4(v));
     }
 }
 
-// dx = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M),   g = dy * (y > 0)      (and the same for b when DUAL)
+// dx = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M),   g = dy * (v > 0), v recomputed (bn_pre4)   (same for b when DUAL)
 template <int DUAL>
-__global__ void k_bn_relu_bwd(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ a,
-                              const float* __restrict__ b, const float* __restrict__ stat_a, const float* __restrict__ stat_b,
-                              const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ sums,
-                              float* __restrict__ da, float* __restrict__ db, size_t total4, int C, float inv_m) {
+__global__ void k_bn_relu_bwd(const float* __restrict__ dy, const float* __restrict__ a, const float* __restrict__ b,
+                              const float* __restrict__ stat_a, const float* __restrict__ stat_b, const float* __restrict__ ga,
+                              const float* __restrict__ ba, const float* __restrict__ gb, const float* __restrict__ bb,
+                              const float* __restrict__ sums, float* __restrict__ da, float* __restrict__ db, size_t total4, int C,
+                              float inv_m) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
-        const f32x4 d = ldv(dy + i * 4), yy = ldv(y + i * 4);
+        const f32x4 d = ldv(dy + i * 4), av = ldv(a + i * 4);
+        const f32x4 mean_a = ldv(stat_a + c), inv_a = ldv(stat_a + C + c), gam_a = ldv(ga + c);
+        f32x4 bv{}, mean_b{}, inv_b{}, gam_b{}, be_b{};
+        if (DUAL) { bv = ldv(b + i * 4); mean_b = ldv(stat_b + c); inv_b = ldv(stat_b + C + c); gam_b = ldv(gb + c); be_b = ldv(bb + c); }
+        const f32x4 v = bn_pre4<DUAL>(av, mean_a, inv_a * gam_a, ldv(ba + c), bv, mean_b, inv_b * gam_b, be_b);
         f32x4 g;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = yy[j] > 0.f ? d[j] : 0.f;
+        for (int j = 0; j < 4; ++j) g[j] = v[j] > 0.f ? d[j] : 0.f;
         const f32x4 sg = ldv(sums + c) * inv_m;
         {
-            const f32x4 inv = ldv(stat_a + C + c), xh = (ldv(a + i * 4) - ldv(stat_a + c)) * inv;
-            stv(da + i * 4, ldv(ga + c) * inv * (g - sg - xh * (ldv(sums + C + c) * inv_m)));
+            const f32x4 xh = (av - mean_a) * inv_a;
+            stv(da + i * 4, gam_a * inv_a * (g - sg - xh * (ldv(sums + C + c) * inv_m)));
         }
         if (DUAL) {
-            const f32x4 inv = ldv(stat_b + C + c), xh = (ldv(b + i * 4) - ldv(stat_b + c)) * inv;
-            stv(db + i * 4, ldv(gb + c) * inv * (g - sg - xh * (ldv(sums + 2 * C + c) * inv_m)));
+            const f32x4 xh = (bv - mean_b) * inv_b;
+            stv(db + i * 4, gam_b * inv_b * (g - sg - xh * (ldv(sums + 2 * C + c) * inv_m)));
         }
     }
 }
@@ -180,7 +203,8 @@ static int stream_blocks(size_t total4) { return (int)std::min((size_t)8192, (to
 void launch_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
                      float* ws, hipStream_t s) {
     const int chunks = bn_chunks(M), rows = (M + chunks - 1) / chunks;
-    hipLaunchKernelGGL(k_bn_partial<0>, dim3(chunks), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, ws, M, C, rows);
+    hipLaunchKernelGGL(k_bn_partial<0>, dim3(chunks), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, ws, M, C, rows);
     hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 15) / 16), dim3(256), 0, s, x, ws, chunks, M, C, eps, momentum, running_mean,
                        running_var, stat);
 }
@@ -192,16 +216,17 @@ void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, con
     else hipLaunchKernelGGL(k_bn_relu_fwd<0>, dim3(stream_blocks(total4)), dim3(256), 0, s, a, b, stat_a, stat_b, ga, ba, gb, bb, y, total4, C);
 }
 
-void launch_bn_relu_bwd(const float* dy, const float* y, const float* a, const float* b, const float* stat_a, const float* stat_b,
-                        const float* ga, const float* gb, float* da, float* db, float* sums, float* ws, int M, int C, hipStream_t s) {
+void launch_bn_relu_bwd(const float* dy, const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga,
+                        const float* ba, const float* gb, const float* bb, float* da, float* db, float* sums, float* ws, int M, int C,
+                        hipStream_t s) {
     const int chunks = bn_chunks(M), rows = (M + chunks - 1) / chunks;
     const int NS = b ? 3 : 2;
-    if (b) hipLaunchKernelGGL(k_bn_partial<2>, dim3(chunks), dim3(256), 0, s, dy, y, a, b, stat_a, stat_b, ws, M, C, rows);
-    else hipLaunchKernelGGL(k_bn_partial<1>, dim3(chunks), dim3(256), 0, s, dy, y, a, b, stat_a, stat_b, ws, M, C, rows);
+    if (b) hipLaunchKernelGGL(k_bn_partial<2>, dim3(chunks), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, ws, M, C, rows);
+    else hipLaunchKernelGGL(k_bn_partial<1>, dim3(chunks), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, ws, M, C, rows);
     hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((C + 15) / 16, NS), dim3(256), 0, s, ws, chunks, C, NS, sums);
     const size_t total4 = (size_t)M * C / 4;
-    if (b) hipLaunchKernelGGL(k_bn_relu_bwd<1>, dim3(stream_blocks(total4)), dim3(256), 0, s, dy, y, a, b, stat_a, stat_b, ga, gb, sums, da, db, total4, C, 1.f / M);
-    else hipLaunchKernelGGL(k_bn_relu_bwd<0>, dim3(stream_blocks(total4)), dim3(256), 0, s, dy, y, a, b, stat_a, stat_b, ga, gb, sums, da, db, total4, C, 1.f / M);
+    if (b) hipLaunchKernelGGL(k_bn_relu_bwd<1>, dim3(stream_blocks(total4)), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, sums, da, db, total4, C, 1.f / M);
+    else hipLaunchKernelGGL(k_bn_relu_bwd<0>, dim3(stream_blocks(total4)), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, sums, da, db, total4, C, 1.f / M);
 }
 
 }  // namespace icn

@@ -489,6 +489,32 @@ void build_upconv_bwd(int r_in, int corner_mode, Ell& out) {
         }
 }
 
+void build_upconv_scatter(int r_in, int corner_mode, Ell& out) {
+    check_args(r_in, 1, corner_mode);
+    if (r_in > 9) throw std::invalid_argument("icn: subdivisions out of range for upsample + conv");
+    std::vector<CompRow> rows;
+    composite_rows(r_in, corner_mode, rows);
+    size_t w = 1;
+    for (auto& r : rows) {
+        size_t k = 0;
+        for (int t = 0; t < NTAPS; ++t) k += r.by_tap[t].size();
+        w = std::max(w, k);
+    }
+    out.rows = (int)rows.size();
+    out.width = (int)w;
+    out.idx.assign(rows.size() * w, IDX_ZERO);
+    out.coef.assign(rows.size() * w, 0.0f);
+    for (size_t p = 0; p < rows.size(); ++p) {
+        size_t k = 0;
+        for (int t = 0; t < NTAPS; ++t)
+            for (auto& e : rows[p].by_tap[t]) {
+                out.idx[p * w + k] = e.first * NTAPS + t;
+                out.coef[p * w + k] = (float)e.second;
+                ++k;
+            }
+    }
+}
+
 void build_bwd_row_order(int r_in, int stride, const std::vector<int32_t>& bwd_idx, int E,
                          std::vector<int32_t>& perm, std::vector<uint8_t>& mask32) {
     const int n = 1 << r_in, Pin = 10 * n * n;

@@ -116,6 +116,11 @@ void build_upconv_fwd(int r_in, int corner_mode, UpconvTable& out);
 // (and, with corner_mode 'average', dbias = sum_s g_0[s], because every row of U sums to one).  `out` is the ELL matrix of
 // dy -> g: row s * 7 + t lists the fine pixels p and coefficients of g_t[s] (7 entries away from the singular vertices).
 void build_upconv_bwd(int r_in, int corner_mode, Ell& out);
+// The transpose of that matrix serves the FORWARD the same way:  z_t[s] = W_t x[s] for all 7 taps is a dense coarse-level
+// GEMM (N = 7 * Cout, a quarter of the multiply-adds), and  y[p] = bias + sum_t sum_s U[nbr_t(p), s] z_t[s]  is an
+// HBM-bound sparse combination.  `out`: row p (fine pixel) lists the rows s * 7 + t of z and their coefficients (12-13
+// entries away from the singular vertices).
+void build_upconv_scatter(int r_in, int corner_mode, Ell& out);
 
 // Row permutation + per-32-row tap masks for stride-2 bwd-data (rows grouped by lattice parity class so
 // that all-empty taps can be skipped tile-wise).  perm[k] = input pixel handled by row k.

@@ -1619,6 +1619,52 @@ __global__ __launch_bounds__(256) void k_upconv_gather(const float* __restrict__
     }
 }
 
+// Mirror image for the forward (icn_upconv_fwd, dense path):  [y0 | y1][b, rows ? rows[r] : r, c] (+)= bias[c] +
+// sum_e coef[r][e] * z[b, idx[r][e], c]  with z (B, zrows, C0 + C1) the per-tap products W_t x[s] (row s * 7 + t).
+__global__ __launch_bounds__(256) void k_upconv_scatter(const float* __restrict__ z, const float* __restrict__ bias,
+                                                         float* __restrict__ y0, float* __restrict__ y1,
+                                                         const int32_t* __restrict__ idx, const float* __restrict__ coef,
+                                                         const int32_t* __restrict__ rows, int B, int zrows, int nrows, int Pout,
+                                                         int C0, int C1, int W, int acc) {
+    const int C = C0 + C1, cv = C / 4;
+    const size_t total = (size_t)B * nrows * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * 4;
+        const size_t br = i / cv;
+        const int r = (int)(br % nrows), b = (int)(br / nrows);
+        const float* src = z + (size_t)b * zrows * C + c;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        if (bias && !acc) sum = ld4(bias + c);
+        for (int e0 = 0; e0 < W; e0 += 8) {
+            int32_t j[8];
+            float w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool in_row = e0 + k < W;
+                j[k] = in_row ? idx[(size_t)r * W + e0 + k] : -1;
+                w[k] = in_row ? coef[(size_t)r * W + e0 + k] : 0.f;
+            }
+            f32x4 x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = j[k] >= 0 ? ld4(src + (size_t)j[k] * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += w[k] * x[k];
+        }
+        const int row = rows ? rows[r] : r;
+        float* o = c < C0 ? y0 + ((size_t)b * Pout + row) * C0 + c : y1 + ((size_t)b * Pout + row) * C1 + (c - C0);
+        if (acc) sum += ld4(o);
+        *reinterpret_cast<f32x4*>(o) = sum;
+    }
+}
+
+void launch_upconv_scatter(const float* z, const float* bias, float* y0, float* y1, const int32_t* idx, const float* coef,
+                           const int32_t* rows, int B, int zrows, int nrows, int Pout, int C0, int C1, int W, int acc, hipStream_t s) {
+    if (nrows <= 0) return;
+    const size_t total = (size_t)B * nrows * ((C0 + C1) / 4);
+    hipLaunchKernelGGL(k_upconv_scatter, dim3((unsigned)std::min((size_t)16384, (total + 255) / 256)), dim3(256), 0, s, z, bias, y0, y1,
+                       idx, coef, rows, B, zrows, nrows, Pout, C0, C1, W, acc);
+}
+
 void launch_upconv_gather(const float* dy0, const float* dy1, float* g, const int32_t* idx, const float* coef, const int32_t* rows,
                           int B, int Pin, int nrows, int rows_total, int C0, int C1, int W, int acc, hipStream_t s) {
     if (nrows <= 0) return;

@@ -81,6 +81,11 @@ void launch_stem_fwd(const float* x, const float* w, const float* bias, float* y
 void launch_upconv_gather(const float* dy0, const float* dy1, float* g, const int32_t* idx, const float* coef, const int32_t* rows,
                           int B, int Pin, int nrows, int rows_total, int C0, int C1, int W, int acc, hipStream_t s);
 
+// [y0 | y1][b, rows ? rows[r] : r, :] (+)= bias + sum_e coef[r][e] * z[b, idx[r][e], :]   (dense forward path of
+// icn_upconv_fwd; z has zrows rows of C0 + C1 channels per sample, the outputs Pout rows of C0 / C1 channels)
+void launch_upconv_scatter(const float* z, const float* bias, float* y0, float* y1, const int32_t* idx, const float* coef,
+                           const int32_t* rows, int B, int zrows, int nrows, int Pout, int C0, int C1, int W, int acc, hipStream_t s);
+
 void launch_spmm_ell(const float* in, float* out, const int32_t* idx, const float* coef, int B, int Pin, int Pout, int C,
                      int W, hipStream_t s);
 
@@ -118,8 +123,9 @@ void launch_bn_stats(const float* x, int M, int C, float eps, float momentum, fl
                      float* ws, hipStream_t s);
 void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga, const float* ba,
                         const float* gb, const float* bb, float* y, int M, int C, hipStream_t s);
-void launch_bn_relu_bwd(const float* dy, const float* y, const float* a, const float* b, const float* stat_a, const float* stat_b,
-                        const float* ga, const float* gb, float* da, float* db, float* sums, float* ws, int M, int C, hipStream_t s);
+void launch_bn_relu_bwd(const float* dy, const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga,
+                        const float* ba, const float* gb, const float* bb, float* da, float* db, float* sums, float* ws, int M, int C,
+                        hipStream_t s);
 
 // ---- fused 1x1 head + tanh (icn_bn.hip); ws = head_chunks(M) * 4 * (Cin + 4) floats
 bool head_supported(int Cin, int Cout);

@@ -105,7 +105,7 @@ class _BnReluFn(torch.autograd.Function):
                                          stat_b.data_ptr() if dual else None, ga.data_ptr(), ba.data_ptr(),
                                          gb.data_ptr() if dual else None, bb.data_ptr() if dual else None, y.data_ptr(), M, C,
                                          st), 'icn_bn_relu_fwd')
-        ctx.save_for_backward(ap, bp, y, stat_a, stat_b, ga, gb)
+        ctx.save_for_backward(ap, bp, stat_a, stat_b, ga, ba, gb, bb)    # not y: the backward recomputes the ReLU mask
         ctx.dims = (M, C, dual)
         return y.permute(0, 3, 1, 2)
 
@@ -113,7 +113,7 @@ class _BnReluFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
         L = _lib.lib()
-        ap, bp, y, stat_a, stat_b, ga, gb = ctx.saved_tensors
+        ap, bp, stat_a, stat_b, ga, ba, gb, bb = ctx.saved_tensors
         M, C, dual = ctx.dims
         gyp = _nhwc(gy)
         dev = gyp.device
@@ -122,10 +122,11 @@ class _BnReluFn(torch.autograd.Function):
         sums = torch.empty(3 * C, dtype=torch.float32, device=dev)
         ws = torch.empty(L.icn_bn_workspace_floats(M, C), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(L.icn_bn_relu_bwd(gyp.data_ptr(), y.data_ptr(), ap.data_ptr(), bp.data_ptr() if dual else None,
-                                         stat_a.data_ptr(), stat_b.data_ptr() if dual else None, ga.data_ptr(),
-                                         gb.data_ptr() if dual else None, da.data_ptr(), db.data_ptr() if dual else None,
-                                         sums.data_ptr(), ws.data_ptr(), M, C, _stream()), 'icn_bn_relu_bwd')
+            _lib.check(L.icn_bn_relu_bwd(gyp.data_ptr(), ap.data_ptr(), bp.data_ptr() if dual else None, stat_a.data_ptr(),
+                                         stat_b.data_ptr() if dual else None, ga.data_ptr(), ba.data_ptr(),
+                                         gb.data_ptr() if dual else None, bb.data_ptr() if dual else None, da.data_ptr(),
+                                         db.data_ptr() if dual else None, sums.data_ptr(), ws.data_ptr(), M, C, _stream()),
+                       'icn_bn_relu_bwd')
         dbeta, dga = sums[:C], sums[C:2 * C]
         out = [da.permute(0, 3, 1, 2), dga, dbeta, None, None, None, None]
         if dual:

@@ -123,15 +123,17 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
  *   ws     at least icn_bn_workspace_floats(M, C) floats
  * icn_bn_stats also updates running_mean / running_var (momentum, unbiased variance) when they are not NULL.
  * icn_bn_relu_fwd : y = relu(bn_a(a) [+ bn_b(b)])            (b == NULL: single input)
- * icn_bn_relu_bwd : da [, db], and sums[k*C + c]: k = 0 -> d(beta), 1 -> d(gamma_a), 2 -> d(gamma_b)           */
+ * icn_bn_relu_bwd : da [, db], and sums[k*C + c]: k = 0 -> d(beta), 1 -> d(gamma_a), 2 -> d(gamma_b).  The ReLU mask is
+ *                   recomputed from a (, b) and the affine parameters with the forward's own expression, so the saved
+ *                   output y is not read (one tensor less to stream in each of the two backward passes).              */
 size_t icn_bn_workspace_floats(int M, int C);
 int icn_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
                  float* ws, void* stream);
 int icn_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* gamma_a,
                     const float* beta_a, const float* gamma_b, const float* beta_b, float* y, int M, int C, void* stream);
-int icn_bn_relu_bwd(const float* dy, const float* y, const float* a, const float* b, const float* stat_a, const float* stat_b,
-                    const float* gamma_a, const float* gamma_b, float* da, float* db, float* sums, float* ws, int M, int C,
-                    void* stream);
+int icn_bn_relu_bwd(const float* dy, const float* a, const float* b, const float* stat_a, const float* stat_b, const float* gamma_a,
+                    const float* beta_a, const float* gamma_b, const float* beta_b, float* da, float* db, float* sums, float* ws, int M,
+                    int C, void* stream);
 
 /* Fused output head  y = tanh(x W^T + b)  (reference models.py:151-154: Conv2d(64, 3, 1x1) + Tanh).
  * x (M, Cin) channels-last rows, w (Cout, Cin), Cin in {16,32,64,128,256}, Cout <= 4; y (M, Cout).
@@ -200,8 +202,9 @@ long icn_table_upconv_bwd(int r_in, int corner_mode, int32_t* idx, float* coef, 
 
 /* Optional diagnostics: HIP-event timing of every MFMA kernel launch between start and stop, on the launch
  * stream.  `stop` synchronises the device and returns the number of entries written (one per kernel that ran).
- * total_flops is ALGORITHMIC: 2*7*Cin*Cout*B*P_out per conv pass (the small virtual-row launch of a stride-1 bwd-data adds time,
- * not FLOPs).  The 2 * max_launches events are created once and reused.  Off by default. */
+ * total_flops counts what a launch multiplies: 2*7*Cin*Cout*B*P_out per pass of an ordinary convolution (= its algorithmic
+ * FLOPs; the small virtual-row launch of a stride-1 bwd-data adds time, not FLOPs); the composite icn_upconv_* launches execute
+ * fewer FLOPs than the two operators they replace (0.68 x forward, 0.25 x backward) and are credited with the executed ones.  The 2 * max_launches events are created once and reused.  Off by default. */
 typedef struct icn_profile_entry {
     const char* kernel;
     long launches;
