@@ -1017,6 +1017,19 @@ int icn_reparam_bwd(const float* dz, const float* logvar, const float* eps, size
     }
 }
 
+int icn_point_to_mesh(const float* points, const float* vertices, const int32_t* faces, int B, int P, int V, int F, float* dist2,
+                      int32_t* face, int32_t* kind, void* stream) {
+    try {
+        if (!points || !vertices || !faces || !dist2 || !face || !kind) throw std::invalid_argument("icn_point_to_mesh: null pointer");
+        if (B < 1 || B > 65535 || P < 1 || V < 1 || F < 1) throw std::invalid_argument("icn_point_to_mesh: bad sizes");
+        icn::launch_point_to_mesh(points, vertices, faces, B, P, V, F, dist2, face, kind, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
 int icn_set_debug_flags(int flags) { return icn::set_debug_flags(flags); }
 
 // ---- fused BatchNorm + ReLU ---------------------------------------------------------------------------------

@@ -152,6 +152,10 @@ void launch_kld_bwd(const float* mu, const float* logvar, const float* upstream,
 void launch_reparam_fwd(const float* mu, const float* logvar, const float* eps, size_t n, float* z, hipStream_t s);
 void launch_reparam_bwd(const float* dz, const float* logvar, const float* eps, size_t n, float* dmu, float* dlogvar, hipStream_t s);
 
+// point-to-mesh distance (icn_loss.hip): squared distance, closest face and feature kind per point; faces (F, 3) shared
+void launch_point_to_mesh(const float* pts, const float* vts, const int32_t* faces, int B, int P, int V, int F, float* dist,
+                          int32_t* face, int32_t* kind, hipStream_t s);
+
 // developer routing flags (ICN_DEBUG / icn_set_debug_flags): 16 = convs on k_gather_gemm, 32 = wgrads on k_wgrad
 int debug_flags();
 int set_debug_flags(int flags);

@@ -386,4 +386,97 @@ void launch_reparam_bwd(const float* dz, const float* logvar, const float* eps, 
     hipLaunchKernelGGL(k_reparam_bwd, dim3(ew_blocks(n)), dim3(LOSS_BLOCK), 0, s, dz, logvar, eps, n, dmu, dlogvar);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Test-time metric of the reference (ico_utils.py:26-44, mode 'point2mesh'; upstream: kaolin 0.9.1's CUDA extension):
+// squared distance of every point to the closest point of a triangle mesh.  One thread per point; the triangles of the
+// point's sample go through LDS in tiles of 256 (each thread stages one triangle's three vertices), so every vertex is
+// fetched once per block.  Region classification of Ericson, Real-Time Collision Detection 5.1.5; ties keep the lowest face.
+// kind: 0 interior, 1 / 2 / 3 vertex 0 / 1 / 2, 4 / 5 / 6 edge (0,1) / (1,2) / (2,0).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float tri_dist2(f3 p, f3 a, f3 b, f3 c, int& kind) {
+    const f3 ab = b - a, ac = c - a, ap = p - a;
+    const float d1 = dot(ab, ap), d2 = dot(ac, ap);
+    f3 q;
+    if (d1 <= 0.f && d2 <= 0.f) { kind = 1; q = a; }
+    else {
+        const f3 bp = p - b;
+        const float d3 = dot(ab, bp), d4 = dot(ac, bp);
+        if (d3 >= 0.f && d4 <= d3) { kind = 2; q = b; }
+        else {
+            const f3 cp = p - c;
+            const float d5 = dot(ab, cp), d6 = dot(ac, cp);
+            if (d6 >= 0.f && d5 <= d6) { kind = 3; q = c; }
+            else {
+                const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+                if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {
+                    const float den = d1 - d3, t = den != 0.f ? d1 / den : 0.f;
+                    kind = 4; q = a + f3{ab.x * t, ab.y * t, ab.z * t};
+                } else if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {
+                    const float den = d2 - d6, t = den != 0.f ? d2 / den : 0.f;
+                    kind = 6; q = a + f3{ac.x * t, ac.y * t, ac.z * t};
+                } else if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+                    const float den = (d4 - d3) + (d5 - d6), t = den != 0.f ? (d4 - d3) / den : 0.f;
+                    const f3 bc = c - b;
+                    kind = 5; q = b + f3{bc.x * t, bc.y * t, bc.z * t};
+                } else {
+                    const float den = va + vb + vc, inv = den != 0.f ? 1.f / den : 0.f;
+                    const float v = vb * inv, w = vc * inv;
+                    kind = 0; q = a + f3{ab.x * v + ac.x * w, ab.y * v + ac.y * w, ab.z * v + ac.z * w};
+                }
+            }
+        }
+    }
+    const f3 d = p - q;
+    return dot(d, d);
+}
+
+__global__ __launch_bounds__(LOSS_BLOCK) void k_point_to_mesh(const float* __restrict__ pts, const float* __restrict__ vts,
+                                                               const int32_t* __restrict__ faces, int P, int V, int F,
+                                                               float* __restrict__ dist, int32_t* __restrict__ face,
+                                                               int32_t* __restrict__ kind) {
+    __shared__ float tri[LOSS_BLOCK][9];
+    const int b = blockIdx.y, i = blockIdx.x * LOSS_BLOCK + threadIdx.x;
+    const bool live = i < P;
+    f3 p = {0.f, 0.f, 0.f};
+    if (live) { const float* q = pts + ((size_t)b * P + i) * 3; p = {q[0], q[1], q[2]}; }
+    float best = 3.4e38f;
+    int best_f = 0, best_k = 0;
+    for (int f0 = 0; f0 < F; f0 += LOSS_BLOCK) {
+        __syncthreads();
+        const int f = f0 + threadIdx.x;
+        if (f < F) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int v = faces[(size_t)f * 3 + k];
+                const float* q = vts + ((size_t)b * V + v) * 3;
+                tri[threadIdx.x][3 * k] = q[0]; tri[threadIdx.x][3 * k + 1] = q[1]; tri[threadIdx.x][3 * k + 2] = q[2];
+            }
+        }
+        __syncthreads();
+        const int nf = min(LOSS_BLOCK, F - f0);
+        if (live)
+            for (int j = 0; j < nf; ++j) {
+                int k;
+                const float d2 = tri_dist2(p, f3{tri[j][0], tri[j][1], tri[j][2]}, f3{tri[j][3], tri[j][4], tri[j][5]},
+                                           f3{tri[j][6], tri[j][7], tri[j][8]}, k);
+                if (d2 < best) { best = d2; best_f = f0 + j; best_k = k; }
+            }
+    }
+    if (live) {
+        dist[(size_t)b * P + i] = best;
+        face[(size_t)b * P + i] = best_f;
+        kind[(size_t)b * P + i] = best_k;
+    }
+}
+
+}  // namespace
+
+void launch_point_to_mesh(const float* pts, const float* vts, const int32_t* faces, int B, int P, int V, int F, float* dist,
+                          int32_t* face, int32_t* kind, hipStream_t s) {
+    hipLaunchKernelGGL(k_point_to_mesh, dim3((P + LOSS_BLOCK - 1) / LOSS_BLOCK, B), dim3(LOSS_BLOCK), 0, s, pts, vts, faces, P, V, F,
+                       dist, face, kind);
+}
+
 }  // namespace icn

@@ -1,0 +1,70 @@
+"""Import shims that let the reference's own `run.py` (and `losses.py`, `ico_utils.py`, `data.py`) run UNCHANGED against
+this package.
+
+The reference imports, besides `icocnn` (this repo's drop-in package at the repo root), a second un-vendored sibling checkout
+`../PythonFunctions` (`torch_utils`, `python_utils`, `torchsummary`, `mesh.utils`; run.py:22-26, losses.py:6-7,
+ico_utils.py:7-8) plus `natsort`, `kaolin` and `torch.utils.tensorboard`, none of which exist offline.  The modules in this
+directory restate the handful of functions the reference calls from them -- signatures from the call sites, behaviour from
+the names and from how the results are used; each docstring cites the call site.  They are host-side orchestration helpers
+(logging, file names, mesh I/O), not part of the hot path.
+
+    import geniconet_amd.shims as shims; shims.install()      # then `import run` from the reference checkout works
+or  python tools/run_reference.py /path/to/GenIcoNet --model ico2ico --process train --quickLearn 8 ...
+"""
+import importlib
+import os
+import sys
+import types
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+
+
+class SummaryWriter:
+    """No-op stand-in for torch.utils.tensorboard.SummaryWriter (run.py:413 and the log_* functions): every `add_*` call is
+    accepted and counted, nothing is written.  Used only when the real tensorboard package is not installed."""
+
+    def __init__(self, log_dir=None, **kwargs):
+        self.log_dir = log_dir
+        self.calls = {}
+        if log_dir:
+            os.makedirs(log_dir, exist_ok=True)
+
+    def __getattr__(self, name):
+        if not name.startswith('add_'):
+            raise AttributeError(name)
+
+        def record(*args, **kwargs):
+            self.calls[name] = self.calls.get(name, 0) + 1
+        return record
+
+    def flush(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def install(tensorboard_stub=None):
+    """Put the shim modules and the repo root (the `icocnn` drop-in) in front of sys.path; register the tensorboard stand-in
+    when `torch.utils.tensorboard` cannot be imported (tensorboard_stub=True forces it, False forbids it).  Idempotent."""
+    for p in (_HERE, _ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    if 'Inf' not in np.__dict__:                       # run.py:342,433,459 use np.Inf, which NumPy 2.0 removed
+        np.Inf = np.inf
+    if tensorboard_stub is False:
+        return
+    if tensorboard_stub is None:
+        try:
+            importlib.import_module('torch.utils.tensorboard')
+            return
+        except Exception:                                  # ImportError, or tensorboard's own version checks
+            pass
+    import torch.utils
+    mod = types.ModuleType('torch.utils.tensorboard')
+    mod.SummaryWriter = SummaryWriter
+    mod.__doc__ = 'geniconet_amd.shims: no-op stand-in (tensorboard is not installed)'
+    sys.modules['torch.utils.tensorboard'] = mod
+    torch.utils.tensorboard = mod

@@ -183,6 +183,14 @@ int icn_kld_bwd(const float* mu, const float* logvar, const float* upstream, siz
 int icn_reparam_fwd(const float* mu, const float* logvar, const float* eps, size_t n, float* z, void* stream);
 int icn_reparam_bwd(const float* dz, const float* logvar, const float* eps, size_t n, float* dmu, float* dlogvar, void* stream);
 
+/* Test-time metric of the reference (ico_utils.py:26-44 computeDistance, mode 'point2mesh'; upstream calls kaolin 0.9.1's
+ * kaolin.metrics.trianglemesh.point_to_mesh_distance): for every point of (B, P, 3) the squared distance to the closest point
+ * of the triangle mesh vertices (B, V, 3) / faces (F, 3) (shared by the batch; indices are NOT range-checked on the device),
+ * the index of a closest face (lowest on ties) and where on it the closest point lies: 0 interior, 1 / 2 / 3 vertex 0 / 1 / 2,
+ * 4 / 5 / 6 edge (0,1) / (1,2) / (2,0). */
+int icn_point_to_mesh(const float* points, const float* vertices, const int32_t* faces, int B, int P, int V, int F, float* dist2,
+                      int32_t* face, int32_t* kind, void* stream);
+
 /* Host-side introspection (no device needed).  Each writes at most `cap` elements and returns the element
  * count required (negative on error). */
 long icn_table_conv_fwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap);      /* [7][P_out]     */
