@@ -207,8 +207,8 @@ def profile_start(max_launches=4096):
 
 def profile_stop():
     """-> list of dicts(kernel, launches, total_ms, total_flops) for the MFMA kernels launched since profile_start."""
-    buf = (ProfileEntry * 32)()
-    n = lib().icn_profile_stop(buf, 32)
+    buf = (ProfileEntry * 48)()
+    n = lib().icn_profile_stop(buf, 48)
     if n < 0:
         check(-1, 'icn_profile_stop')
     return [dict(kernel=buf[i].kernel.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms,

@@ -469,11 +469,13 @@ void conv_bwd_weight_impl(const float* x, const float* dy0, const float* dy1, fl
 
 namespace icn {
 // names as rocprofv3 prints them (modulo "void icn::"), so bench.py's live numbers line up with profiles/
-const char* const PROF_NAMES[PROF_KINDS] = {"k_conv_dma<128, 128>", "k_conv_dma<128, 64>", "k_conv_dma<64, 128>", "k_conv_dma<64, 64>",
+const char* const PROF_NAMES[PROF_KINDS] = {"k_conv_dma<128, 128, false>", "k_conv_dma<128, 64, false>", "k_conv_dma<64, 128, false>",
+                                            "k_conv_dma<64, 64, false>",
                                             "k_gather_gemm<128, 128>", "k_gather_gemm<128, 64>", "k_gather_gemm<64, 128>",
                                             "k_gather_gemm<64, 64>", "k_wgrad_dma<128, 128>", "k_wgrad_dma<128, 64>",
                                             "k_wgrad_dma<64, 128>", "k_wgrad_dma<64, 64>", "k_wgrad<128, 128>", "k_wgrad<128, 64>",
-                                            "k_wgrad<64, 128>", "k_wgrad<64, 64>"};
+                                            "k_wgrad<64, 128>", "k_wgrad<64, 64>", "k_conv_dma<128, 128, true>",
+                                            "k_conv_dma<128, 64, true>", "k_conv_dma<64, 128, true>", "k_conv_dma<64, 64, true>"};
 void prof_mark_begin(int kind, double flops, hipStream_t s) {
     if (!g_prof_on) return;
     g_prof_mu.lock();

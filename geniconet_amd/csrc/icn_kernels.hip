@@ -796,7 +796,8 @@ static void launch_conv_dma_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
     const size_t nb = a.segs.nseg > 0 ? (size_t)a.segs.B : (size_t)(a.M / a.Pd);          // samples
     const unsigned src_bytes = (unsigned)(nb * a.Ps * Ks * 4);
     const unsigned side_bytes = (unsigned)(nb * a.n_slots * Ks * 4);
-    prof_mark_begin(BM == 64 ? (BN == 128 ? PROF_DMA_64x128 : PROF_DMA_64x64) : (BN == 128 ? PROF_DMA_128x128 : PROF_DMA_128x64),
+    prof_mark_begin((BM == 64 ? (BN == 128 ? PROF_DMA_64x128 : PROF_DMA_64x64) : (BN == 128 ? PROF_DMA_128x128 : PROF_DMA_128x64)) +
+                        (SEG ? PROF_DMAS_128x128 - PROF_DMA_128x128 : 0),
                     a.algo_flops, s);
     hipLaunchKernelGGL((k_conv_dma<BM, BN, SEG>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2,
                        a.dcode, a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.mask32, a.M,

@@ -590,7 +590,7 @@ def test_upconv_pair_matches_oracle_upsample_then_convs(case):
     _lib.profile_start(64)
     yg = ico_upconv_pair(xg, wg[0], bg[0], wg[1], bg[1], r, mode)
     prof = _lib.profile_stop()
-    assert sum(e['launches'] for e in prof) == 1 and prof[0]['kernel'].startswith('k_conv_dma'), prof
+    assert sum(e['launches'] for e in prof) == 1 and prof[0]['kernel'].startswith('k_conv_dma') and 'true' in prof[0]['kernel'], prof
     torch.autograd.backward(yg, [gy.cuda() for gy in gys])
     pairs = {'y0': (yg[0], yr[0]), 'y1': (yg[1], yr[1]), 'dx': (xg.grad, xr.grad), 'dw0': (wg[0].grad, wr[0].grad),
              'dw1': (wg[1].grad, wr[1].grad)}

@@ -28,7 +28,9 @@ def timed(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-print('%-24s %8s | %10s %6s | %10s %6s | %6s' % ('block', 'GFLOP', 'separate us', 'TF/s', 'composite us', 'TF/s', 'ratio'))
+print('forward: upsample -> pair convolution (round 1) vs icn_upconv_fwd (ICN_UPCONV_FWD=composite|dense picks the method);')
+print('backward: whole autograd backward of ico_upconv_pair (icn_upconv_bwd, or the separate operators with ICN_NO_UPCONV_BWD=1)')
+print('%-24s %8s | %10s %6s | %10s %6s | %6s | %10s' % ('block', 'GFLOP', 'separate us', 'TF/s', 'upconv us', 'TF/s', 'ratio', 'backward us'))
 for name, cin, cout, dr in (('up1 256->2x256', 256, 256, -3), ('up2 256->2x128', 256, 128, -2), ('up3 128->2x64', 128, 64, -1)):
     r = a.R + dr
     n = 2 ** r
@@ -39,5 +41,11 @@ for name, cin, cout, dr in (('up1 256->2x256', 256, 256, -3), ('up2 256->2x128',
     with torch.no_grad():
         t_sep = timed(lambda: ico_conv_pair(ico_upsample(x, r, 'average'), w0, b0, w1, b1, r + 1, 1, 'average'), a.iters)
         t_cmp = timed(lambda: ico_upconv_pair(x, w0, b0, w1, b1, r, 'average'), a.iters)
-    print('%-24s %8.2f | %10.1f %6.1f | %10.1f %6.1f | %6.3f' % (name, gflop, t_sep * 1e6, gflop / t_sep / 1e3, t_cmp * 1e6,
-                                                             gflop / t_cmp / 1e3, t_cmp / t_sep))
+    xg = x.clone().requires_grad_()
+    wg = [w0.clone().requires_grad_(), w1.clone().requires_grad_()]
+    bg = [b0.clone().requires_grad_(), b1.clone().requires_grad_()]
+    ys = ico_upconv_pair(xg, wg[0], bg[0], wg[1], bg[1], r, 'average')
+    gys = [torch.randn_like(y) for y in ys]
+    t_bwd = timed(lambda: torch.autograd.grad(ys, [xg] + wg + bg, gys, retain_graph=True), a.iters)
+    print('%-24s %8.2f | %10.1f %6.1f | %10.1f %6.1f | %6.3f | %10.1f' % (name, gflop, t_sep * 1e6, gflop / t_sep / 1e3, t_cmp * 1e6,
+                                                                       gflop / t_cmp / 1e3, t_cmp / t_sep, t_bwd * 1e6))
