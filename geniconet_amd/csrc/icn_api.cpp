@@ -124,8 +124,10 @@ EllSplitDev upload_ell_split(const icn::Ell& e, int W_main) {
 // icn_upconv_fwd) as split ELL matrices; iota = identity table [Pc] (the coarse-level GEMMs do not gather)
 struct UpconvBwdDev {
     int Pc = 0, Pf = 0;
-    EllSplitDev gather, scatter;
+    EllSplitDev gather, scatter;   // gather: the rows of the pixels the per-pixel kernel cannot take (main part unused, W = 0)
     int32_t* iota = nullptr;
+    int32_t* px_srcs = nullptr;    // [Pc][20] fine rows of a coarse pixel's 7 aggregates (-1 padded; all -1: generic kernel)
+    float* px_coef = nullptr;      // [Pc][20][8] coefficient of source k in tap t (7 used)
 };
 
 std::mutex g_mu;
@@ -252,8 +254,50 @@ const UpconvBwdDev& upconv_bwd_tables(int r_in, int mode) {
     UpconvBwdDev d;
     d.Pc = icn::pixels(r_in);
     d.Pf = 4 * d.Pc;
-    d.gather = upload_ell_split(e, 8);             // 7 entries per row away from the singular vertices
-    d.scatter = upload_ell_split(f, 16);           // 12-13
+    {   // per-pixel form of dy -> g: the 7 rows of a coarse pixel share <= 20 fine source rows (19 away from the singular
+        // vertices); a pixel with more keeps the generic row-by-row form (all 7 rows, full width, as "overflow" rows)
+        constexpr int NS = 20;
+        std::vector<int32_t> srcs((size_t)d.Pc * NS, icn::IDX_ZERO);
+        std::vector<float> coefd((size_t)d.Pc * NS * 8, 0.f);
+        icn::Ell rest;
+        rest.width = e.width;
+        std::vector<int32_t> rest_rows;
+        for (int sp = 0; sp < d.Pc; ++sp) {
+            std::vector<int32_t> uniq;
+            for (int t = 0; t < 7; ++t)
+                for (int k = 0; k < e.width; ++k) {
+                    const int32_t p = e.idx[((size_t)sp * 7 + t) * e.width + k];
+                    if (p >= 0 && std::find(uniq.begin(), uniq.end(), p) == uniq.end()) uniq.push_back(p);
+                }
+            if ((int)uniq.size() <= NS) {
+                std::sort(uniq.begin(), uniq.end());
+                for (size_t k = 0; k < uniq.size(); ++k) srcs[(size_t)sp * NS + k] = uniq[k];
+                for (int t = 0; t < 7; ++t)
+                    for (int k = 0; k < e.width; ++k) {
+                        const int32_t p = e.idx[((size_t)sp * 7 + t) * e.width + k];
+                        if (p < 0) continue;
+                        const size_t slot = std::lower_bound(uniq.begin(), uniq.end(), p) - uniq.begin();
+                        coefd[((size_t)sp * NS + slot) * 8 + t] += e.coef[((size_t)sp * 7 + t) * e.width + k];
+                    }
+            } else {
+                for (int t = 0; t < 7; ++t) {
+                    rest_rows.push_back(sp * 7 + t);
+                    rest.idx.insert(rest.idx.end(), e.idx.begin() + ((size_t)sp * 7 + t) * e.width, e.idx.begin() + ((size_t)sp * 7 + t + 1) * e.width);
+                    rest.coef.insert(rest.coef.end(), e.coef.begin() + ((size_t)sp * 7 + t) * e.width, e.coef.begin() + ((size_t)sp * 7 + t + 1) * e.width);
+                }
+            }
+        }
+        rest.rows = (int)rest_rows.size();
+        d.px_srcs = upload(srcs);
+        d.px_coef = upload(coefd);
+        d.gather = EllSplitDev{};
+        d.gather.n_ovf = rest.rows;
+        d.gather.W_ovf = rest.width;
+        d.gather.ovf_rows = upload(rest_rows);
+        d.gather.ovf_idx = upload(rest.idx);
+        d.gather.ovf_coef = upload(rest.coef);
+    }
+    d.scatter = upload_ell_split(f, 16);           // 12-13 entries per fine pixel
     std::vector<int32_t> iota(d.Pc);
     for (int i = 0; i < d.Pc; ++i) iota[i] = i;
     d.iota = upload(iota);
@@ -873,8 +917,8 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
         float* g = reinterpret_cast<float*>(at(ws, wo.g));
         // 1. g[b, s, t, :] = sum_p U[nbr_t(p), s] [dy0 | dy1][b, p, :]
         const EllSplitDev& ga = t.gather;
-        icn::launch_upconv_gather(dy0, dy1, g, ga.idx, ga.coef, nullptr, B, t.Pf, 7 * t.Pc, 7 * t.Pc, Cout0, Cout1, ga.W, 0, s);
-        icn::launch_upconv_gather(dy0, dy1, g, ga.ovf_idx, ga.ovf_coef, ga.ovf_rows, B, t.Pf, ga.n_ovf, 7 * t.Pc, Cout0, Cout1, ga.W_ovf, 1, s);
+        icn::launch_upconv_gather_px(dy0, dy1, g, t.px_srcs, t.px_coef, B, t.Pf, t.Pc, Cout0, Cout1, s);
+        icn::launch_upconv_gather(dy0, dy1, g, ga.ovf_idx, ga.ovf_coef, ga.ovf_rows, B, t.Pf, ga.n_ovf, 7 * t.Pc, Cout0, Cout1, ga.W_ovf, 0, s);
         if (dx) {
             // 2. dx[b, s, :] = g[b, s, (t, c)] . Wb[(t, c), :]: a dense GEMM, K = 7 * C (one "tap" whose gather is the identity)
             float* wb = reinterpret_cast<float*>(at(ws, wo.wb));

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ p
 bool head_supported(int Cin, int Cout) {
     return Cout >= 1 && Cout <= HEAD_MAX_OUT && (Cin == 16 || Cin == 32 || Cin == 64 || Cin == 128 || Cin == 256);
 }
-int head_chunks(int M) { return std::min(4096, (M + 63) / 64); }
+int head_chunks(int M) { return std::min(1024, (M + 63) / 64); }   // 4 blocks per CU; the reduce walks the chunks
 
 #define ICN_HEAD_DISPATCH(KERNEL, ...)                                                  \
     switch (Cin) {                                                                      \

@@ -1581,6 +1581,26 @@ __global__ void k_spmm_ell(const float* __restrict__ in, float* __restrict__ out
     }
 }
 
+// Grid-stride walk that keeps an XCD on ONE contiguous eighth of the items: blocks b and b + 8 share an XCD (and its L2), so
+// block b walks the (b % 8)-th eighth with the other blocks of its XCD.  For the sparse row mixes below neighbouring output
+// rows share source rows; dealt round-robin over the 8 L2s, every shared row is fetched from HBM by several of them.
+struct XcdWalk {
+    size_t pos, end, step;
+    __device__ XcdWalk(size_t total) {
+        const unsigned x = blockIdx.x % 8, nb = gridDim.x / 8;            // launches round the grid up to a multiple of 8
+        const size_t per = (total + 7) / 8;
+        pos = (size_t)x * per + (size_t)(blockIdx.x / 8) * blockDim.x + threadIdx.x;
+        end = (x + 1) * per < total ? (x + 1) * per : total;
+        step = (size_t)nb * blockDim.x;
+    }
+};
+static unsigned xcd_grid(size_t total, unsigned cap) {
+    static const int force = getenv("ICN_XCD_GRID") ? atoi(getenv("ICN_XCD_GRID")) : 0;      // developer sweep
+    if (force > 0) cap = (unsigned)force;
+    const size_t per = (total + 7) / 8, nb = (per + 255) / 256;
+    return 8u * (unsigned)std::max<size_t>(1, std::min<size_t>(nb, cap / 8));
+}
+
 // Aggregate of the composite backward (icn_upconv_bwd):  g[b, row, c] (+)= sum_e coef[r][e] * dy[b, idx[r][e], c]  with the
 // channel axis c over [dy0 | dy1] (C0 + C1 channels, a pair's two output gradients side by side), row = rows ? rows[r] : r.
 // Main pass: every row of the width-8 table; second pass (acc = 1): the few rows with more than 8 entries (next to the
@@ -1628,8 +1648,8 @@ __global__ __launch_bounds__(256) void k_upconv_scatter(const float* __restrict_
                                                          const int32_t* __restrict__ rows, int B, int zrows, int nrows, int Pout,
                                                          int C0, int C1, int W, int acc) {
     const int C = C0 + C1, cv = C / 4;
-    const size_t total = (size_t)B * nrows * cv;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    for (XcdWalk w_((size_t)B * nrows * cv); w_.pos < w_.end; w_.pos += w_.step) {
+        const size_t i = w_.pos;
         const int c = (int)(i % cv) * 4;
         const size_t br = i / cv;
         const int r = (int)(br % nrows), b = (int)(br / nrows);
@@ -1662,8 +1682,62 @@ void launch_upconv_scatter(const float* z, const float* bias, float* y0, float* 
                            const int32_t* rows, int B, int zrows, int nrows, int Pout, int C0, int C1, int W, int acc, hipStream_t s) {
     if (nrows <= 0) return;
     const size_t total = (size_t)B * nrows * ((C0 + C1) / 4);
-    hipLaunchKernelGGL(k_upconv_scatter, dim3((unsigned)std::min((size_t)16384, (total + 255) / 256)), dim3(256), 0, s, z, bias, y0, y1,
+    hipLaunchKernelGGL(k_upconv_scatter, dim3(xcd_grid(total, 16384)), dim3(256), 0, s, z, bias, y0, y1,
                        idx, coef, rows, B, zrows, nrows, Pout, C0, C1, W, acc);
+}
+
+// Same aggregate, one thread per (sample, coarse pixel, 4 channels) for ALL 7 taps: the 7 rows g_t[s] of a pixel draw on the
+// same <= 20 fine rows (the two-ring of its site), each needed by 2-3 of the taps, so they are loaded once (20 loads instead
+// of 49) and spread over the taps with a dense (20 x 7, mostly zero) coefficient block.  k_upconv_gather above is bound by
+// the vector-memory pipe (2.6 GB of 16-byte loads for the r = 4 -> 5 block), not by HBM.  srcs [Pc][20] (-1 padded; pixels with
+// more sources are left to the generic kernel and have all -1 here), coefd [Pc][20][8] (7 used).
+constexpr int UG_SRC = 20;
+__global__ __launch_bounds__(256) void k_upconv_gather_px(const float* __restrict__ dy0, const float* __restrict__ dy1,
+                                                           float* __restrict__ g, const int32_t* __restrict__ srcs,
+                                                           const float* __restrict__ coefd, int B, int Pin, int Pc, int C0, int C1) {
+    const int C = C0 + C1, cv = C / 4;
+    for (XcdWalk w_((size_t)B * Pc * cv); w_.pos < w_.end; w_.pos += w_.step) {
+        const size_t i = w_.pos;
+        const int c = (int)(i % cv) * 4;
+        const size_t bs = i / cv;
+        const int sp = (int)(bs % Pc), b = (int)(bs / Pc);
+        const bool second = c >= C0;
+        const float* src = (second ? dy1 : dy0) + (size_t)b * Pin * (second ? C1 : C0) + (second ? c - C0 : c);
+        const int stride = second ? C1 : C0;
+        f32x4 acc[7];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int32_t* sj = srcs + (size_t)sp * UG_SRC;
+        const float* cf = coefd + (size_t)sp * UG_SRC * 8;
+#pragma unroll 1                                       // one chunk of 5 sources in flight: ~100 VGPRs, 4-5 waves per SIMD
+        for (int k0 = 0; k0 < UG_SRC; k0 += 5) {
+            int32_t j[5];
+            f32x4 x[5], ca[5], cb[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) j[k] = sj[k0 + k];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                x[k] = j[k] >= 0 ? ld4(src + (size_t)j[k] * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+                ca[k] = ld4(cf + (k0 + k) * 8);
+                cb[k] = ld4(cf + (k0 + k) * 8 + 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                acc[0] += ca[k][0] * x[k]; acc[1] += ca[k][1] * x[k]; acc[2] += ca[k][2] * x[k]; acc[3] += ca[k][3] * x[k];
+                acc[4] += cb[k][0] * x[k]; acc[5] += cb[k][1] * x[k]; acc[6] += cb[k][2] * x[k];
+            }
+        }
+        float* o = g + ((size_t)b * Pc + sp) * 7 * C + c;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) *reinterpret_cast<f32x4*>(o + (size_t)t * C) = acc[t];
+    }
+}
+
+void launch_upconv_gather_px(const float* dy0, const float* dy1, float* g, const int32_t* srcs, const float* coefd, int B, int Pin,
+                             int Pc, int C0, int C1, hipStream_t s) {
+    const size_t total = (size_t)B * Pc * ((C0 + C1) / 4);
+    hipLaunchKernelGGL(k_upconv_gather_px, dim3(xcd_grid(total, 16384)), dim3(256), 0, s, dy0, dy1, g, srcs,
+                       coefd, B, Pin, Pc, C0, C1);
 }
 
 void launch_upconv_gather(const float* dy0, const float* dy1, float* g, const int32_t* idx, const float* coef, const int32_t* rows,

@@ -81,6 +81,10 @@ void launch_stem_fwd(const float* x, const float* w, const float* bias, float* y
 void launch_upconv_gather(const float* dy0, const float* dy1, float* g, const int32_t* idx, const float* coef, const int32_t* rows,
                           int B, int Pin, int nrows, int rows_total, int C0, int C1, int W, int acc, hipStream_t s);
 
+// the same aggregate per coarse pixel for all 7 taps at once: srcs [Pc][20] fine rows (-1 padded), coefd [Pc][20][8]
+void launch_upconv_gather_px(const float* dy0, const float* dy1, float* g, const int32_t* srcs, const float* coefd, int B, int Pin,
+                             int Pc, int C0, int C1, hipStream_t s);
+
 // [y0 | y1][b, rows ? rows[r] : r, :] (+)= bias + sum_e coef[r][e] * z[b, idx[r][e], :]   (dense forward path of
 // icn_upconv_fwd; z has zrows rows of C0 + C1 channels per sample, the outputs Pout rows of C0 / C1 channels)
 void launch_upconv_scatter(const float* z, const float* bias, float* y0, float* y1, const int32_t* idx, const float* coef,
