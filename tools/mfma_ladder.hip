@@ -118,6 +118,109 @@ __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_b
 #endif
 }
 
+// "BK = 64 as two stages": 4 ring slots = 2 double-stages; at the top of a double-step the two stages of the NEXT double-step
+// are issued, both stages are computed, then vmcnt(0) + one barrier -- half the barriers per FLOP, 2 blocks per CU for 64x64.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_ladder2(const float* src, unsigned src_bytes, float* out, int steps, int rows_total) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TM = BM / 64, TN = BN / 64, RA = BM / 32, RB = BN / 32, NST = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);
+    float* Bs = As + NST * BM * BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5, rsub = lane >> 3, pc = lane & 7;
+    for (int i = tid; i < NST * (BM + BN) * BK; i += 256) As[i] = 1e-3f * (float)((i * 37) % 101 - 50);
+    __syncthreads();
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+    const int a_rows = 92160;
+    const unsigned b_base = (unsigned)a_rows * 1024u;
+    const int shift[7] = {0, 64, 1, -63, -64, -1, 63};
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fl = swz(l31);
+    f32x4 fa[2][TM], fb[2][TN];
+    auto dma = [&](int slot, int step) {
+        const int tile = (blockIdx.x + (step / 56) * gridDim.x) % (a_rows / BM);
+        const int t = step % 7, kc = (step / 7) % 8;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int row = tile * BM + 8 * (wave + 4 * i) + rsub + shift[t];
+            row = row < 0 ? row + a_rows : (row >= a_rows ? row - a_rows : row);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(As + slot * BM * BK + 8 * (wave + 4 * i) * BK), 16,
+                                                     (unsigned)row * 1024u + 16u * pc, kc * 128, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(Bs + slot * BN * BK + 8 * (wave + 4 * i) * BK), 16,
+                                                     b_base + (unsigned)(t * BN + 8 * (wave + 4 * i) + rsub) * 1024u + 16u * pc,
+                                                     kc * 128, 0, 0);
+    };
+    auto compute = [&](int ring) {
+        const float* a_base = As + ring * BM * BK + (wr * (BM / 2) + l31) * BK;
+        const float* b_base = Bs + ring * BN * BK + (wc * (BN / 2) + l31) * BK;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + 4 * (h ^ fl));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BK + 4 * (h ^ fl));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                const int off = 4 * ((2 * (kk + 1) + h) ^ fl);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[(kk + 1) & 1][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + off);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[(kk + 1) & 1][j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BK + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i][s], fb[kk & 1][j][s], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    dma(0, 0);
+    dma(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int half = 0;                                   // slots {0,1} or {2,3} hold the double-stage being computed
+    for (int step = 0; step < steps; step += 2) {
+        dma(2 * (half ^ 1), step + 2);
+        dma(2 * (half ^ 1) + 1, step + 3);
+        compute(2 * half);
+        compute(2 * half + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        half ^= 1;
+    }
+    float sum = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = sum;
+#endif
+}
+
+template <int BM, int BN>
+void run2(int blocks_per_cu, const float* src, unsigned src_bytes, float* out) {
+    const int blocks = 256 * blocks_per_cu, steps = 4000 / blocks_per_cu;
+    const size_t lds = (size_t)4 * (BM + BN) * BK * 4;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ladder2<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_ladder2<BM, BN>), dim3(blocks), dim3(256), lds, 0, src, src_bytes, out, steps, (int)(src_bytes / 1024));
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+    }
+    const double flops = (double)blocks * steps * 2.0 * BM * BN * BK;
+    printf("tile %3dx%-3d level 4  double-step (barrier every 2 K-steps, 4 slots)  %d block(s)/CU  %.3f ms  %.1f TFLOP/s\n", BM, BN, blocks_per_cu, best, flops / best / 1e9);
+}
+
 template <int BM, int BN, int LEVEL, int NST = 3>
 void run(int blocks_per_cu, const float* src, unsigned src_bytes, float* out) {
     const int blocks = 256 * blocks_per_cu, steps = 4000 / blocks_per_cu;
@@ -161,6 +264,18 @@ int main(int argc, char** argv) {
             run<64, 128, 4, 2>(3, src, src_bytes, out);
             run<64, 64, 4, 2>(3, src, src_bytes, out);      // 32 KB: control at production occupancy
             run<64, 64, 4, 2>(4, src, src_bytes, out);      // ... and with the freed LDS spent on a 4th block
+        }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'd') {   // barrier every second K-step (BK = 64 as two stages) against the production configs
+        for (int rep = 0; rep < 2; ++rep) {
+            run<64, 64, 4, 3>(3, src, src_bytes, out);      // production: 48 KB, 3 blocks / CU
+            run2<64, 64>(2, src, src_bytes, out);           // 64 KB, 2 blocks / CU
+            run2<64, 64>(1, src, src_bytes, out);
+            run<64, 128, 4, 3>(2, src, src_bytes, out);     // production: 72 KB, 2 blocks / CU
+            run2<64, 128>(1, src, src_bytes, out);          // 96 KB, 1 block / CU
+            run<128, 64, 4, 3>(2, src, src_bytes, out);
+            run2<128, 64>(1, src, src_bytes, out);
         }
         return 0;
     }
