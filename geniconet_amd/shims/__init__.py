@@ -54,6 +54,17 @@ def install(tensorboard_stub=None):
     import numpy as np
     if 'Inf' not in np.__dict__:                       # run.py:342,433,459 use np.Inf, which NumPy 2.0 removed
         np.Inf = np.inf
+    # run.py:356 loads its checkpoints with a bare torch.load(); they hold 'loss' as a numpy scalar (np.average, run.py:311),
+    # which torch >= 2.6 refuses under its weights_only default unless the numpy scalar types are allow-listed
+    try:
+        import torch
+        safe = [np.dtype, type(np.dtype('float64')), type(np.dtype('float32')), type(np.dtype('int64'))]
+        scalar = getattr(getattr(np, '_core', None), 'multiarray', None)
+        if scalar is not None and hasattr(scalar, 'scalar'):
+            safe.append(scalar.scalar)
+        torch.serialization.add_safe_globals(safe)
+    except (ImportError, AttributeError):
+        pass
     if tensorboard_stub is False:
         return
     if tensorboard_stub is None:

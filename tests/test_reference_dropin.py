@@ -112,6 +112,27 @@ def test_reference_run_py_trains_end_to_end_with_this_package(reference_env, tmp
     for k, v in ours.state_dict().items():
         assert torch.equal(v, ck['model_state_dict'][k]), k
 
+    # ... and `--process test` (run.py:499-536) on the model it has just saved: loadModel picks the newest '_EB' file, the
+    # forward runs with BatchNorm in training mode (run.py:516), ico_utils.computeDistance writes the output mesh through
+    # python_utils.writeOffMesh and takes the point-to-mesh distance through the kaolin stand-in, saveDistance the CSV.
+    for k in REF_MODULES:
+        sys.modules.pop(k, None)
+    argv = ['run.py', '--model', 'ico2ico', '--process', 'test', '--data_instance', 'val', '--quickLearn', '1', '--batch_size', '1',
+            '--test_mode', 'point2mesh', '--write_output_mesh', '--logDir', str(log_dir), '--dataPth', str(tmp_path / 'data')]
+    monkeypatch.setattr(sys, 'argv', argv)
+    runpy.run_path(os.path.join(REFERENCE, 'run.py'), run_name='__main__')
+    out_root = log_dir / 'data' / 'ico2ico'
+    csvs = [os.path.join(r_, f) for r_, _, fs in os.walk(out_root) for f in fs if f.endswith('.csv')]
+    offs = [os.path.join(r_, f) for r_, _, fs in os.walk(out_root) for f in fs if f.endswith('.off')]
+    assert len(csvs) == 1 and len(offs) == 1, (csvs, offs)
+    rows = open(csvs[0]).read().strip().splitlines()
+    assert rows[0] == 'Name,Distance' and len(rows) == 2
+    dist = float(rows[1].split(',')[1])
+    assert np.isfinite(dist) and 0 < dist < 4.0                                  # mean squared distance inside the unit ball
+    import python_utils
+    v, f = python_utils.read_off(offs[0])
+    assert len(v) == 10242 and len(f) == 20480
+
 
 def test_shim_helpers():
     """The small helpers on their own: natural sort, OFF round trip, free file names, row-normalised adjacency."""
