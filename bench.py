@@ -146,18 +146,30 @@ def main():
                 dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tr.step(x, t)
+    # HIP events around EVERY MFMA launch cost the step ~2.5 % (a marker packet between back-to-back kernels).  So: all
+    # kernels are timed during the last warm-up steps (table of kernels, executed FLOPs per step, which kernel dominates),
+    # and in the timed region only the dominant kernel carries events -- that is the `roofline` measurement.
     events = not args.no_kernel_events
+    n_survey = min(2, args.warmup) if events else 0
+    for _ in range(args.warmup - n_survey):
+        tr.step(x, t)
+    survey = []
+    if n_survey:
+        torch.cuda.synchronize()
+        _lib.profile_start(200 * n_survey)
+        for _ in range(n_survey):
+            tr.step(x, t)
+        survey = _lib.profile_stop()
+    dominant = max(survey, key=lambda e: e['total_ms'])['kernel'] if survey else None
     barrier()
-    if events:
-        _lib.profile_start(200 * args.steps)
+    if dominant:
+        _lib.profile_start(100 * args.steps, only=dominant)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = tr.step(x, t)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = _lib.profile_stop() if events else []
+    prof = _lib.profile_stop() if dominant else []
     el = torch.tensor([elapsed], device='cpu' if rehearsal else device, dtype=torch.float64)   # gloo: host tensors only
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -184,7 +196,7 @@ def main():
                 pass
             per_launch_ms = dom['total_ms'] / dom['launches']
             achieved = dom['total_flops'] / (dom['total_ms'] * 1e-3) / 1e12
-            mfma_ms = sum(e['total_ms'] for e in prof)
+            mfma_ms = sum(e['total_ms'] for e in survey)
             roofline = {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
@@ -194,17 +206,18 @@ def main():
                 # per-kernel figures count the FLOPs a launch executes (= algorithmic for ordinary convolutions; the composite
                 # upsample+conv launches of the decoder execute 0.68 x / 0.25 x of the operators they replace), so frac <= 1
                 'flops_counted': 'executed',
-                'all_mfma_kernels': [{'kernel': e['kernel'], 'launches_per_step': e['launches'] / args.steps,
+                # the other MFMA kernels: from the 2 surveyed warm-up steps (events around every launch)
+                'all_mfma_kernels': [{'kernel': e['kernel'], 'launches_per_step': e['launches'] / n_survey,
                                       'avg_launch_us': round(e['total_ms'] / e['launches'] * 1e3, 2),
-                                      'tflops': round(e['total_flops'] / (e['total_ms'] * 1e-3) / 1e12, 2)} for e in prof],
-                'mfma_kernels_ms_per_step': round(mfma_ms / args.steps, 3),
+                                      'tflops': round(e['total_flops'] / (e['total_ms'] * 1e-3) / 1e12, 2)} for e in survey],
+                'mfma_kernels_ms_per_step': round(mfma_ms / n_survey, 3),
                 'step_tflops': round(value * TRAIN_GFLOP_PER_MESH[(cfg['model'], cfg['R'])] / 1e3, 2),
                 'step_frac_of_mfma_peak': round(value * TRAIN_GFLOP_PER_MESH[(cfg['model'], cfg['R'])] / 1e3
                                                 / PEAK_FP32_MFMA_TFLOPS / world, 4),
                 # step_tflops is ALGORITHMIC (3 x forward conv FLOPs of the reference's operator graph);
                 # the MFMA launches of this implementation execute fewer (composite decoder blocks):
-                'step_executed_tflops': round(sum(e['total_flops'] for e in prof) / args.steps / (elapsed / args.steps) / 1e12, 2),
-                'step_executed_gflop': round(sum(e['total_flops'] for e in prof) / args.steps / 1e9, 1),
+                'step_executed_tflops': round(sum(e['total_flops'] for e in survey) / n_survey / (elapsed / args.steps) / 1e12, 2),
+                'step_executed_gflop': round(sum(e['total_flops'] for e in survey) / n_survey / 1e9, 1),
                 # the HBM side of the same step (SURVEY 8d asks for both fractions; the binding one is MFMA)
                 'achieved_hbm': round(value * TRAIN_MB_PER_MESH[(cfg['model'], cfg['R'])] / 1e3 / world, 1),
                 'peak_hbm': PEAK_HBM_GBPS, 'unit_hbm': 'GB/s',

@@ -80,6 +80,7 @@ class ProfileEntry(ctypes.Structure):
 
 SIGNATURES['icn_profile_start'] = (ctypes.c_int, [ctypes.c_int])
 SIGNATURES['icn_profile_stop'] = (ctypes.c_int, [ctypes.POINTER(ProfileEntry), ctypes.c_int])
+SIGNATURES['icn_profile_select'] = (ctypes.c_int, [ctypes.c_char_p])
 
 _lib = None
 
@@ -201,7 +202,10 @@ def table_upconv_bwd(r_in, corner_mode):
     return idx.reshape(-1, w.value), coef.reshape(-1, w.value)
 
 
-def profile_start(max_launches=4096):
+def profile_start(max_launches=4096, only=None):
+    """Start timing MFMA launches with HIP events; only='k_conv_dma<64, 64, false>' restricts it to one kernel (an event pair
+    around every launch of a step costs about 2.5 % of it)."""
+    check(lib().icn_profile_select(only.encode() if only else None), 'icn_profile_select')
     check(lib().icn_profile_start(max_launches), 'icn_profile_start')
 
 

@@ -325,6 +325,7 @@ struct ProfRec { int kind; double flops; hipEvent_t e0, e1; };
 std::vector<ProfRec> g_prof;          // pre-created events, reused by every start / stop
 size_t g_prof_used = 0;
 bool g_prof_on = false, g_prof_open = false;
+int g_prof_only = -1;                 // >= 0: only launches of this kind are timed (icn_profile_select)
 std::mutex g_prof_mu;                 // held from prof_mark_begin to prof_mark_end: launches may come from the forward
                                       // thread and from the autograd thread
 
@@ -523,7 +524,7 @@ const char* const PROF_NAMES[PROF_KINDS] = {"k_conv_dma<128, 128, false>", "k_co
 void prof_mark_begin(int kind, double flops, hipStream_t s) {
     if (!g_prof_on) return;
     g_prof_mu.lock();
-    if (!g_prof_on || g_prof_used >= g_prof.size()) { g_prof_mu.unlock(); return; }
+    if (!g_prof_on || g_prof_used >= g_prof.size() || (g_prof_only >= 0 && kind != g_prof_only)) { g_prof_mu.unlock(); return; }
     ProfRec& r = g_prof[g_prof_used];
     r.kind = kind;
     r.flops = flops;
@@ -557,6 +558,15 @@ int icn_profile_start(int max_launches) {
     } catch (const std::exception& e) {
         return fail(e.what());
     }
+}
+
+int icn_profile_select(const char* kernel) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_only = -1;
+    if (kernel == nullptr || kernel[0] == 0) return 0;
+    for (int k = 0; k < icn::PROF_KINDS; ++k)
+        if (std::strcmp(kernel, icn::PROF_NAMES[k]) == 0) { g_prof_only = k; return 0; }
+    return fail(std::string("icn_profile_select: unknown kernel ") + kernel);
 }
 
 int icn_profile_stop(icn_profile_entry* out, int cap) {

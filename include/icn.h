@@ -221,6 +221,9 @@ typedef struct icn_profile_entry {
 } icn_profile_entry;
 int icn_profile_start(int max_launches);
 int icn_profile_stop(icn_profile_entry* out, int cap);
+/* Time only the launches of one kernel (a name as icn_profile_stop reports it); NULL or "": all MFMA kernels again.  An event
+ * pair around EVERY launch costs the step about 2.5 % (a marker packet between back-to-back kernels, ~2.5 us each). */
+int icn_profile_select(const char* kernel);
 
 /* Developer routing flags (same bits as the ICN_DEBUG environment variable, which only sets the initial value):
  * 16 = convolutions on the register-staged fallback kernel, 32 = weight gradients on it.  Returns the previous flags. */
