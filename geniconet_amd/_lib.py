@@ -60,6 +60,7 @@ SIGNATURES = {
     'icn_kld_bwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_size_t] + [_c_float_p] * 2 + [ctypes.c_void_p]),
     'icn_reparam_fwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_size_t] + [_c_float_p] + [ctypes.c_void_p]),
     'icn_reparam_bwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_size_t] + [_c_float_p] * 2 + [ctypes.c_void_p]),
+    'icn_adam_step': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_double] * 4 + [ctypes.c_void_p]),
     'icn_set_debug_flags': (ctypes.c_int, [ctypes.c_int]),
     'icn_point_to_mesh': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [ctypes.c_void_p]),
     'icn_table_conv_fwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t]),

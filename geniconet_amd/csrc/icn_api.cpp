@@ -1086,6 +1086,26 @@ int icn_point_to_mesh(const float* points, const float* vertices, const int32_t*
     }
 }
 
+int icn_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                  const size_t* numel, const float* step_size, const float* bc2_sqrt, double beta1, double beta2, double eps,
+                  double weight_decay, void* stream) {
+    try {
+        if (count < 0 || (count > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !step_size || !bc2_sqrt)))
+            throw std::invalid_argument("icn_adam_step: bad arguments");
+        for (int i = 0; i < count; ++i)
+            if (numel[i] > 0 && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]))
+                throw std::invalid_argument("icn_adam_step: null tensor pointer");
+        if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0))
+            throw std::invalid_argument("icn_adam_step: betas must lie in [0, 1), eps must not be negative");
+        icn::launch_adam(count, params, grads, exp_avg, exp_avg_sq, numel, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay,
+                         static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
 int icn_set_debug_flags(int flags) { return icn::set_debug_flags(flags); }
 
 // ---- fused BatchNorm + ReLU ---------------------------------------------------------------------------------

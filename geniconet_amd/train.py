@@ -18,7 +18,7 @@ import re
 import torch
 import torch.distributed as dist
 
-from . import losses, models
+from . import losses, models, optim
 
 GRAD_BUCKET_MB = 5   # ~4 buckets for the 18.5 MB (AE) / 24 MB (VAE) of fp32 gradients, decoder first
 
@@ -93,7 +93,7 @@ class Trainer:
                 broadcast_buffers=False, init_sync=not staged)
             if staged:
                 self.net.register_comm_hook(None, _host_staged_allreduce_hook(self.world))
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=cfg['lr'])               # run.py:446
+        self.optimizer = optim.Adam(self.model.parameters(), lr=cfg['lr'])    # run.py:446 (torch.optim.Adam, step on HIP)
         self.scheduler = None
         if 'lr_base' in cfg and 'lr_max' in cfg:                                               # run.py:448-450
             self.scheduler = torch.optim.lr_scheduler.CyclicLR(self.optimizer, cfg['lr_base'], cfg['lr_max'],

@@ -191,6 +191,18 @@ int icn_reparam_bwd(const float* dz, const float* logvar, const float* eps, size
 int icn_point_to_mesh(const float* points, const float* vertices, const int32_t* faces, int B, int P, int V, int F, float* dist2,
                       int32_t* face, int32_t* kind, void* stream);
 
+/* Adam step (reference run.py:253 `optimizer.step()` on the optimiser of run.py:446, torch.optim.Adam without amsgrad /
+ * maximize) over `count` fp32 tensors in one launch per 64 tensors.  The four pointer arrays and numel / step_size / bc2_sqrt
+ * are HOST arrays of length count; the pointers in them are device pointers (param, grad, exp_avg, exp_avg_sq of tensor i,
+ * numel[i] contiguous elements each).  Per tensor, as torch computes them on the host in double precision:
+ * step_size[i] = lr / (1 - beta1^t_i), bc2_sqrt[i] = sqrt(1 - beta2^t_i), t_i = the tensor's step count AFTER this step.
+ *   g' = g + weight_decay * p;  m += (g' - m) * (1 - beta1);  v = v * beta2 + (1 - beta2) * g' * g';
+ *   p -= step_size * m / (sqrt(v) / bc2_sqrt + eps)
+ * HBM-bound: 28 bytes per parameter. */
+int icn_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                  const size_t* numel, const float* step_size, const float* bc2_sqrt, double beta1, double beta2, double eps,
+                  double weight_decay, void* stream);
+
 /* Host-side introspection (no device needed).  Each writes at most `cap` elements and returns the element
  * count required (negative on error). */
 long icn_table_conv_fwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap);      /* [7][P_out]     */
