@@ -127,7 +127,9 @@ struct UpconvBwdDev {
     EllSplitDev gather, scatter;   // gather: the rows of the pixels the per-pixel kernel cannot take (main part unused, W = 0)
     int32_t* iota = nullptr;
     int32_t* px_srcs = nullptr;    // [Pc][20] fine rows of a coarse pixel's 7 aggregates (-1 padded; all -1: generic kernel)
-    float* px_coef = nullptr;      // [Pc][20][8] coefficient of source k in tap t (7 used)
+    int32_t* px_cls = nullptr;     // [Pc] coefficient class of the pixel
+    float* cls_coef = nullptr;     // [n_cls][20][8] coefficient of source k in tap t (7 used); class 0 = all zero
+    int n_cls = 0;
 };
 
 std::mutex g_mu;
@@ -288,8 +290,35 @@ const UpconvBwdDev& upconv_bwd_tables(int r_in, int mode) {
             }
         }
         rest.rows = (int)rest_rows.size();
+        // the coefficient blocks fall into a handful of classes (the sorted order of a pixel's sources follows the chart
+        // layout): a class id per pixel and one table; pixels beyond the kernel's class capacity go the generic way too
+        std::vector<int32_t> cls(d.Pc, 0);
+        std::vector<float> cls_coef(NS * 8, 0.f);                 // class 0: no sources
+        std::map<std::vector<float>, int> seen;
+        seen.emplace(std::vector<float>(NS * 8, 0.f), 0);
+        for (int sp = 0; sp < d.Pc; ++sp) {
+            std::vector<float> blk(coefd.begin() + (size_t)sp * NS * 8, coefd.begin() + (size_t)(sp + 1) * NS * 8);
+            auto found = seen.find(blk);
+            if (found == seen.end()) {
+                if ((int)seen.size() >= icn::UPCONV_PX_CLASSES) {  // does not happen on the icosahedral charts (19 classes)
+                    for (int k = 0; k < NS; ++k) srcs[(size_t)sp * NS + k] = icn::IDX_ZERO;
+                    for (int t = 0; t < 7; ++t) {
+                        rest_rows.push_back(sp * 7 + t);
+                        rest.idx.insert(rest.idx.end(), e.idx.begin() + ((size_t)sp * 7 + t) * e.width, e.idx.begin() + ((size_t)sp * 7 + t + 1) * e.width);
+                        rest.coef.insert(rest.coef.end(), e.coef.begin() + ((size_t)sp * 7 + t) * e.width, e.coef.begin() + ((size_t)sp * 7 + t + 1) * e.width);
+                    }
+                    continue;
+                }
+                found = seen.emplace(blk, (int)seen.size()).first;
+                cls_coef.insert(cls_coef.end(), blk.begin(), blk.end());
+            }
+            cls[sp] = found->second;
+        }
+        rest.rows = (int)rest_rows.size();
+        d.n_cls = (int)seen.size();
         d.px_srcs = upload(srcs);
-        d.px_coef = upload(coefd);
+        d.px_cls = upload(cls);
+        d.cls_coef = upload(cls_coef);
         d.gather = EllSplitDev{};
         d.gather.n_ovf = rest.rows;
         d.gather.W_ovf = rest.width;
@@ -927,7 +956,7 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
         float* g = reinterpret_cast<float*>(at(ws, wo.g));
         // 1. g[b, s, t, :] = sum_p U[nbr_t(p), s] [dy0 | dy1][b, p, :]
         const EllSplitDev& ga = t.gather;
-        icn::launch_upconv_gather_px(dy0, dy1, g, t.px_srcs, t.px_coef, B, t.Pf, t.Pc, Cout0, Cout1, s);
+        icn::launch_upconv_gather_px(dy0, dy1, g, t.px_srcs, t.px_cls, t.cls_coef, t.n_cls, B, t.Pf, t.Pc, Cout0, Cout1, s);
         icn::launch_upconv_gather(dy0, dy1, g, ga.ovf_idx, ga.ovf_coef, ga.ovf_rows, B, t.Pf, ga.n_ovf, 7 * t.Pc, Cout0, Cout1, ga.W_ovf, 0, s);
         if (dx) {
             // 2. dx[b, s, :] = g[b, s, (t, c)] . Wb[(t, c), :]: a dense GEMM, K = 7 * C (one "tap" whose gather is the identity)

@@ -1690,11 +1690,19 @@ void launch_upconv_scatter(const float* z, const float* bias, float* y0, float* 
 // same <= 20 fine rows (the two-ring of its site), each needed by 2-3 of the taps, so they are loaded once (20 loads instead
 // of 49) and spread over the taps with a dense (20 x 7, mostly zero) coefficient block.  k_upconv_gather above is bound by
 // the vector-memory pipe (2.6 GB of 16-byte loads for the r = 4 -> 5 block), not by HBM.  srcs [Pc][20] (-1 padded; pixels with
-// more sources are left to the generic kernel and have all -1 here), coefd [Pc][20][8] (7 used).
+// more sources are left to the generic kernel and have all -1 here).  The coefficient blocks come in a handful of classes
+// (19 at every level >= 2: the interior pattern covers 87 % of the pixels at r = 4): cls [Pc] names a pixel's class and the
+// class table [ncls][20][8] (7 used) sits in LDS -- read per lane from global memory the blocks were two thirds of the
+// kernel's vector-memory traffic (40 of 60 16-byte loads per thread, every lane of a pixel fetching the same values).
 constexpr int UG_SRC = 20;
+constexpr int UG_CLS_MAX = UPCONV_PX_CLASSES;
 __global__ __launch_bounds__(256) void k_upconv_gather_px(const float* __restrict__ dy0, const float* __restrict__ dy1,
                                                            float* __restrict__ g, const int32_t* __restrict__ srcs,
-                                                           const float* __restrict__ coefd, int B, int Pin, int Pc, int C0, int C1) {
+                                                           const int32_t* __restrict__ cls, const float* __restrict__ cls_coef,
+                                                           int ncls, int B, int Pin, int Pc, int C0, int C1) {
+    __shared__ f32x4 ctab[UG_CLS_MAX * UG_SRC * 2];
+    for (int i = threadIdx.x; i < ncls * UG_SRC * 2; i += 256) ctab[i] = ld4(cls_coef + 4 * i);
+    __syncthreads();
     const int C = C0 + C1, cv = C / 4;
     for (XcdWalk w_((size_t)B * Pc * cv); w_.pos < w_.end; w_.pos += w_.step) {
         const size_t i = w_.pos;
@@ -1708,23 +1716,20 @@ __global__ __launch_bounds__(256) void k_upconv_gather_px(const float* __restric
 #pragma unroll
         for (int t = 0; t < 7; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int32_t* sj = srcs + (size_t)sp * UG_SRC;
-        const float* cf = coefd + (size_t)sp * UG_SRC * 8;
-#pragma unroll 1                                       // one chunk of 5 sources in flight: ~100 VGPRs, 4-5 waves per SIMD
+        const f32x4* cf = ctab + cls[sp] * (UG_SRC * 2);
+#pragma unroll 1                                       // one chunk of 5 sources in flight: 4-5 waves per SIMD
         for (int k0 = 0; k0 < UG_SRC; k0 += 5) {
             int32_t j[5];
-            f32x4 x[5], ca[5], cb[5];
+            f32x4 x[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) j[k] = sj[k0 + k];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                x[k] = j[k] >= 0 ? ld4(src + (size_t)j[k] * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
-                ca[k] = ld4(cf + (k0 + k) * 8);
-                cb[k] = ld4(cf + (k0 + k) * 8 + 4);
-            }
+            for (int k = 0; k < 5; ++k) x[k] = j[k] >= 0 ? ld4(src + (size_t)j[k] * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                acc[0] += ca[k][0] * x[k]; acc[1] += ca[k][1] * x[k]; acc[2] += ca[k][2] * x[k]; acc[3] += ca[k][3] * x[k];
-                acc[4] += cb[k][0] * x[k]; acc[5] += cb[k][1] * x[k]; acc[6] += cb[k][2] * x[k];
+                const f32x4 ca = cf[(k0 + k) * 2], cb = cf[(k0 + k) * 2 + 1];
+                acc[0] += ca[0] * x[k]; acc[1] += ca[1] * x[k]; acc[2] += ca[2] * x[k]; acc[3] += ca[3] * x[k];
+                acc[4] += cb[0] * x[k]; acc[5] += cb[1] * x[k]; acc[6] += cb[2] * x[k];
             }
         }
         float* o = g + ((size_t)b * Pc + sp) * 7 * C + c;
@@ -1733,11 +1738,12 @@ __global__ __launch_bounds__(256) void k_upconv_gather_px(const float* __restric
     }
 }
 
-void launch_upconv_gather_px(const float* dy0, const float* dy1, float* g, const int32_t* srcs, const float* coefd, int B, int Pin,
-                             int Pc, int C0, int C1, hipStream_t s) {
+void launch_upconv_gather_px(const float* dy0, const float* dy1, float* g, const int32_t* srcs, const int32_t* cls,
+                             const float* cls_coef, int ncls, int B, int Pin, int Pc, int C0, int C1, hipStream_t s) {
+    if (ncls < 1 || ncls > UG_CLS_MAX) throw std::invalid_argument("icn: coefficient classes of the per-pixel aggregate out of range");
     const size_t total = (size_t)B * Pc * ((C0 + C1) / 4);
-    hipLaunchKernelGGL(k_upconv_gather_px, dim3(xcd_grid(total, 16384)), dim3(256), 0, s, dy0, dy1, g, srcs,
-                       coefd, B, Pin, Pc, C0, C1);
+    hipLaunchKernelGGL(k_upconv_gather_px, dim3(xcd_grid(total, 16384)), dim3(256), 0, s, dy0, dy1, g, srcs, cls, cls_coef, ncls,
+                       B, Pin, Pc, C0, C1);
 }
 
 void launch_upconv_gather(const float* dy0, const float* dy1, float* g, const int32_t* idx, const float* coef, const int32_t* rows,

@@ -82,8 +82,9 @@ void launch_upconv_gather(const float* dy0, const float* dy1, float* g, const in
                           int B, int Pin, int nrows, int rows_total, int C0, int C1, int W, int acc, hipStream_t s);
 
 // the same aggregate per coarse pixel for all 7 taps at once: srcs [Pc][20] fine rows (-1 padded), coefd [Pc][20][8]
-void launch_upconv_gather_px(const float* dy0, const float* dy1, float* g, const int32_t* srcs, const float* coefd, int B, int Pin,
-                             int Pc, int C0, int C1, hipStream_t s);
+constexpr int UPCONV_PX_CLASSES = 32;   // capacity of k_upconv_gather_px's LDS coefficient-class table
+void launch_upconv_gather_px(const float* dy0, const float* dy1, float* g, const int32_t* srcs, const int32_t* cls,
+                             const float* cls_coef, int ncls, int B, int Pin, int Pc, int C0, int C1, hipStream_t s);
 
 // [y0 | y1][b, rows ? rows[r] : r, :] (+)= bias + sum_e coef[r][e] * z[b, idx[r][e], :]   (dense forward path of
 // icn_upconv_fwd; z has zrows rows of C0 + C1 channels per sample, the outputs Pout rows of C0 / C1 channels)
