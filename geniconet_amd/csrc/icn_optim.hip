@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <stdexcept>
+#include <vector>
 
 #include "icn_launch.h"
 
@@ -27,9 +28,8 @@ struct AdamTable {
     float* v[ADAM_MAX_TENSORS];
     unsigned n[ADAM_MAX_TENSORS];
     unsigned first_block[ADAM_MAX_TENSORS + 1];   // prefix sums of the tensors' chunk counts
-    float step_size[ADAM_MAX_TENSORS];
-    float bc2_sqrt[ADAM_MAX_TENSORS];
     int count;
+    float step_size, bc2_sqrt;                    // one launch = tensors with the same step count
 };
 static_assert(sizeof(AdamTable) <= 4000, "kernel arguments are limited to 4 KB");
 
@@ -43,7 +43,7 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 __global__ __launch_bounds__(256) void k_adam(const AdamTable t, float b1c, float b2, float b2c, float eps, float wd) {
-    // tensor of this block: the table is wave-uniform, so this is a scalar binary search over <= 64 entries
+    // tensor of this block: the table is wave-uniform, so this is a scalar binary search over <= 96 entries
     int lo = 0, hi = t.count - 1;
     const unsigned blk = blockIdx.x;
     while (lo < hi) {
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_adam(const AdamTable t, float b1c, floa
     const float* __restrict__ g = t.g[lo];
     float* __restrict__ m = t.m[lo];
     float* __restrict__ v = t.v[lo];
-    const float ss = t.step_size[lo], bc = t.bc2_sqrt[lo];
+    const float ss = t.step_size, bc = t.bc2_sqrt;
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                        reinterpret_cast<uintptr_t>(v)) & 15) == 0;
 #pragma unroll
@@ -86,24 +86,36 @@ __global__ __launch_bounds__(256) void k_adam(const AdamTable t, float b1c, floa
 
 void launch_adam(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const size_t* numel,
                  const float* step_size, const float* bc2_sqrt, double beta1, double beta2, double eps, double weight_decay, hipStream_t s) {
-    for (int first = 0; first < count; first += ADAM_MAX_TENSORS) {
+    // one launch per group of tensors that share (step_size, bc2_sqrt), i.e. the step count -- normally all of them
+    std::vector<char> done(count, 0);
+    for (int lead = 0; lead < count; ++lead) {
+        if (done[lead]) continue;
         AdamTable t{};
-        t.count = std::min(ADAM_MAX_TENSORS, count - first);
+        t.step_size = step_size[lead];
+        t.bc2_sqrt = bc2_sqrt[lead];
         unsigned blocks = 0;
-        for (int i = 0; i < t.count; ++i) {
-            const size_t n = numel[first + i];
+        auto flush = [&]() {
+            t.first_block[t.count] = blocks;
+            if (blocks)
+                hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, t, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                                   (float)eps, (float)weight_decay);
+            t.count = 0;
+            blocks = 0;
+        };
+        for (int i = lead; i < count; ++i) {
+            if (done[i] || step_size[i] != t.step_size || bc2_sqrt[i] != t.bc2_sqrt) continue;
+            done[i] = 1;
+            const size_t n = numel[i];
             if (n >= ((size_t)1 << 32) - ADAM_CHUNK) throw std::invalid_argument("icn_adam_step: tensor beyond 2^32 elements");
-            t.p[i] = p[first + i]; t.g[i] = g[first + i]; t.m[i] = m[first + i]; t.v[i] = v[first + i];
-            t.n[i] = (unsigned)n;
-            t.step_size[i] = step_size[first + i];
-            t.bc2_sqrt[i] = bc2_sqrt[first + i];
-            t.first_block[i] = blocks;
+            if (n == 0) continue;
+            const int k = t.count++;
+            t.p[k] = p[i]; t.g[k] = g[i]; t.m[k] = m[i]; t.v[k] = v[i];
+            t.n[k] = (unsigned)n;
+            t.first_block[k] = blocks;
             blocks += (unsigned)((n + ADAM_CHUNK - 1) / ADAM_CHUNK);
+            if (t.count == ADAM_MAX_TENSORS) flush();
         }
-        t.first_block[t.count] = blocks;
-        if (blocks == 0) continue;
-        hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, t, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                           (float)weight_decay);
+        flush();
     }
 }
 

@@ -192,7 +192,7 @@ int icn_point_to_mesh(const float* points, const float* vertices, const int32_t*
                       int32_t* face, int32_t* kind, void* stream);
 
 /* Adam step (reference run.py:253 `optimizer.step()` on the optimiser of run.py:446, torch.optim.Adam without amsgrad /
- * maximize) over `count` fp32 tensors in one launch per 64 tensors.  The four pointer arrays and numel / step_size / bc2_sqrt
+ * maximize) over `count` fp32 tensors, one launch per 96 tensors that share a step count (normally: one launch).  The four pointer arrays and numel / step_size / bc2_sqrt
  * are HOST arrays of length count; the pointers in them are device pointers (param, grad, exp_avg, exp_avg_sq of tensor i,
  * numel[i] contiguous elements each).  Per tensor, as torch computes them on the host in double precision:
  * step_size[i] = lr / (1 - beta1^t_i), bc2_sqrt[i] = sqrt(1 - beta2^t_i), t_i = the tensor's step count AFTER this step.
