@@ -176,21 +176,8 @@ def test_tensors_beyond_2gib_take_the_fallback_kernels_and_agree_with_half_batch
     assert close(dw, dw_sum) and close(db, db_sum)
 
 
-def test_register_staged_fallback_kernels_stay_correct():
-    """k_gather_gemm and the non-DMA k_wgrad serve only tensors beyond 2 GiB and tiles with fewer than 4 K-steps, so the
-    normal suite hardly reaches them.  ICN_DEBUG=48 routes every convolution to them; the switch is read once per process,
-    hence a child process running a few of the conv cases above (MFMA tiles of all shapes, stride 2, an odd width)."""
-    import os
-    import subprocess
-    import sys
-    pick = 'r2_s1_64x64_b2 or r3_s2_128x256_b2 or r4_s1_128x64_b2 or r4_s1_64x320_b1 or r5_s1_128x128_b1 or r3_s1_256x128_b2'
-    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
-                          '-k', 'test_conv_forward_backward and (%s)' % pick],
-                         env={**os.environ, 'ICN_DEBUG': '48'}, capture_output=True, text=True, timeout=600,
-                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    tail = out.stdout[-600:] + out.stderr[-300:]
-    assert out.returncode == 0, tail
-    assert '6 passed' in out.stdout, tail
+# (the register-staged fallback kernels are exercised in-process through icn_set_debug_flags:
+# tests/test_gpu_training_parity.py::test_register_staged_fallback_kernels_stay_correct)
 
 
 def test_conv_without_bias_and_noncontiguous_input():
