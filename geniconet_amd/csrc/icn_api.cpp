@@ -429,9 +429,11 @@ bool pair_supported(int B, int Cin, int C0, int C1, int r_in, int stride) {
 }
 
 // Workspace layouts (each piece 256-byte aligned), C = C0 + C1 (C1 = 0: single convolution):
-//   fwd        [packed weights 7 x Cin x C][pair: concatenated bias C][side buffer (B, slots_fwd, Cin)]
-//   bwd-data   [packed weights][stride 1: virtual-row GEMM result (B, nvp, Cin)][side buffer(s) (B, slots_bwd, C0) per dy]
+//   fwd        [packed weights 7 x Cin x C][pair: concatenated bias C][side buffer (B, slots_fwd, Cin)][stream-K scratch]
+//   bwd-data   [packed weights][stride 1: virtual-row GEMM result (B, nvp, Cin)][side buffer(s) (B, slots_bwd, C0) per dy][stream-K]
+//   stream-K scratch = [flag words CONV_SK_FLAGS][partial-tile slots]: the persistent GEMM's last round cut in K (k_conv_dma_sk)
 //   bwd-weight [partial slabs S x 7 x Cin x C][bias partials S x C][side buffer (B, slots_fwd, Cin)]
+size_t sk_ws_bytes() { return align256((size_t)icn::CONV_SK_FLAGS * sizeof(int)) + align256(icn::conv_sk_part_bytes()); }
 size_t conv_ws_bytes(int op, int B, int Cin, int C0, int C1, int r_in, int stride) {
     const int C = C0 + C1, n_out = (1 << r_in) / stride, M = B * 10 * n_out * n_out;
     const size_t wbytes = align256((size_t)7 * Cin * C * sizeof(float));
@@ -439,12 +441,12 @@ size_t conv_ws_bytes(int op, int B, int Cin, int C0, int C1, int r_in, int strid
         case ICN_OP_CONV_FWD:
             if (!icn::gather_gemm_supported(Cin, C)) return 0;
             return wbytes + (C1 ? align256((size_t)C * sizeof(float)) : 0) +
-                   align256((size_t)B * table_counts(r_in, stride).slots_fwd * Cin * sizeof(float));
+                   align256((size_t)B * table_counts(r_in, stride).slots_fwd * Cin * sizeof(float)) + sk_ws_bytes();
         case ICN_OP_CONV_BWD_DATA: {
             if (!icn::gather_gemm_supported(C, Cin)) return 0;
             const TableCounts c = table_counts(r_in, stride);
             return wbytes + align256((size_t)B * c.nv * Cin * sizeof(float)) +
-                   (C1 ? 2 : 1) * align256((size_t)B * c.slots_bwd * C0 * sizeof(float));
+                   (C1 ? 2 : 1) * align256((size_t)B * c.slots_bwd * C0 * sizeof(float)) + sk_ws_bytes();
         }
         case ICN_OP_CONV_BWD_WEIGHT:
             return wgrad_partial_bytes(M, Cin, C, C0) + wgrad_bias_partial_bytes(M, Cin, C, C0) +
@@ -457,13 +459,17 @@ char* at(void* ws, size_t off) { return static_cast<char*>(ws) + off; }
 
 // ---- the three passes; w1 == nullptr: one convolution, else a pair sharing x (C1 = its output channels) -------------
 void conv_fwd_impl(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, float* y0, float* y1, int B,
-                   int Cin, int C0, int C1, const ConvTables& t, void* ws, hipStream_t s) {
+                   int Cin, int C0, int C1, int r_in, int stride, const ConvTables& t, void* ws, hipStream_t s) {
     const int C = C0 + C1;
     const size_t wbytes = align256((size_t)7 * Cin * C * sizeof(float));
     float* wf = static_cast<float*>(ws);
     float* bias_cat = (w1 && b0) ? reinterpret_cast<float*>(at(ws, wbytes)) : nullptr;
-    float* side = reinterpret_cast<float*>(at(ws, wbytes + (w1 ? align256((size_t)C * sizeof(float)) : 0)));
+    const size_t side_off = wbytes + (w1 ? align256((size_t)C * sizeof(float)) : 0);
+    float* side = reinterpret_cast<float*>(at(ws, side_off));
+    int* sk_flag = reinterpret_cast<int*>(at(ws, side_off + align256((size_t)B * table_counts(r_in, stride).slots_fwd * Cin * sizeof(float))));
+    float* sk_part = reinterpret_cast<float*>(reinterpret_cast<char*>(sk_flag) + align256((size_t)icn::CONV_SK_FLAGS * sizeof(int)));
     icn::PrologueArgs p{};
+    p.zero = sk_flag; p.n_zero = icn::CONV_SK_FLAGS;
     p.w = w0; p.w2 = w1; p.packed = wf; p.Cout = C0; p.Cout2 = C1; p.Cin = Cin; p.transpose = 0;
     p.bias = b0; p.bias2 = b1; p.bias_cat = bias_cat;
     p.src = x; p.slots = t.d_fwd.slots; p.side = side; p.n_slots = t.d_fwd.n_slots; p.E = 1; p.B = B; p.Ps = t.Pin; p.K = Cin;
@@ -474,6 +480,7 @@ void conv_fwd_impl(const float* x, const float* w0, const float* b0, const float
     a.idx = t.fwd; a.dcode = t.d_fwd.code; a.side = side; a.n_slots = t.d_fwd.n_slots;
     a.M = B * t.Pout; a.Ps = t.Pin; a.Pd = t.Pout; a.K = Cin; a.N = C; a.E = 1; a.ns = t.n_in;
     a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pout;
+    a.sk_part = sk_part; a.sk_flag = sk_flag;
     icn::launch_gather_gemm_auto(a, s);
 }
 
@@ -487,6 +494,8 @@ void conv_bwd_data_impl(const float* dy0, const float* dy1, const float* w0, con
     float* vout = reinterpret_cast<float*>(at(ws, wbytes));
     float* side = reinterpret_cast<float*>(at(ws, wbytes + align256((size_t)B * tc.nv * Cin * sizeof(float))));
     float* side2 = dy1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(side) + side_bytes) : nullptr;
+    int* sk_flag = reinterpret_cast<int*>(reinterpret_cast<char*>(side) + (dy1 ? 2 : 1) * side_bytes);
+    float* sk_part = reinterpret_cast<float*>(reinterpret_cast<char*>(sk_flag) + align256((size_t)icn::CONV_SK_FLAGS * sizeof(int)));
     // source = dy at the output level (pole corners of THAT level), rows = input pixels
     // Stride 1: the transposed gather has extra entries (duplicates / pole means) along the chart seams.
     // Where they are few (fine levels) the main GEMM gathers only the primary entries and a second, small GEMM
@@ -499,6 +508,7 @@ void conv_bwd_data_impl(const float* dy0, const float* dy1, const float* w0, con
     p.w = w0; p.w2 = w1; p.packed = wb; p.Cout = C0; p.Cout2 = C1; p.Cin = Cin; p.transpose = 1;
     p.src = dy0; p.src2 = dy1; p.slots = ds.slots; p.side = side; p.side2 = side2; p.n_slots = ds.n_slots; p.E = ds.E; p.B = B;
     p.Ps = t.Pout; p.K = C0; p.ns = t.n_out;
+    p.zero = sk_flag; p.n_zero = icn::CONV_SK_FLAGS;
     icn::launch_conv_prologue(p, s);
     icn::GatherGemmArgs a{};
     a.src = dy0; a.src2 = dy1; a.wt = wb; a.dst = dx; a.N0 = Cin;
@@ -506,10 +516,12 @@ void conv_bwd_data_impl(const float* dy0, const float* dy1, const float* w0, con
     a.n_slots = dm.n_slots; a.perm = t.perm; a.mask32 = t.mask32;
     a.M = B * t.Pin; a.Ps = t.Pout; a.Pd = t.Pin; a.K = C; a.N = Cin; a.E = split ? 1 : t.E; a.ns = t.n_out;
     a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pout;
+    a.sk_part = sk_part; a.sk_flag = sk_flag;             // (only the main launch: the flags are cleared once per call)
     icn::launch_gather_gemm_auto(a, s);
     if (split) {
         // second, small GEMM over the virtual rows, then dx[b, vq[v], :] += result[b, v, :]
         icn::GatherGemmArgs v = a;
+        v.sk_part = nullptr; v.sk_flag = nullptr;
         v.dst = vout; v.idx = t.vidx; v.dcode = t.d_virt.code; v.n_slots = t.d_virt.n_slots; v.perm = t.vorder; v.mask32 = t.vmask32;
         v.M = B * t.nvp; v.Pd = t.nvp; v.E = 1;
         v.algo_flops = 0.0;   // the main launch above already carries the layer's algorithmic FLOPs; this one adds time only
@@ -549,7 +561,8 @@ const char* const PROF_NAMES[PROF_KINDS] = {"k_conv_dma<128, 128, false>", "k_co
                                             "k_gather_gemm<64, 64>", "k_wgrad_dma<128, 128>", "k_wgrad_dma<128, 64>",
                                             "k_wgrad_dma<64, 128>", "k_wgrad_dma<64, 64>", "k_wgrad<128, 128>", "k_wgrad<128, 64>",
                                             "k_wgrad<64, 128>", "k_wgrad<64, 64>", "k_conv_dma<128, 128, true>",
-                                            "k_conv_dma<128, 64, true>", "k_conv_dma<64, 128, true>", "k_conv_dma<64, 64, true>"};
+                                            "k_conv_dma<128, 64, true>", "k_conv_dma<64, 128, true>", "k_conv_dma<64, 64, true>",
+                                            "k_conv_dma_sk<64, 128>", "k_conv_dma_sk<64, 64>"};
 void prof_mark_begin(int kind, double flops, hipStream_t s) {
     if (!g_prof_on) return;
     g_prof_mu.lock();
@@ -663,7 +676,7 @@ int icn_conv_fwd(const float* x, const float* w, const float* bias, float* y, in
         if (icn::gather_gemm_supported(Cin, Cout)) {
             if (!ws || ws_bytes < conv_ws_bytes(ICN_OP_CONV_FWD, B, Cin, Cout, 0, r_in, stride))
                 throw std::invalid_argument("icn_conv_fwd: workspace too small");
-            conv_fwd_impl(x, w, bias, nullptr, nullptr, y, nullptr, B, Cin, Cout, 0, t, ws, s);
+            conv_fwd_impl(x, w, bias, nullptr, nullptr, y, nullptr, B, Cin, Cout, 0, r_in, stride, t, ws, s);
         } else if (icn::stem_supported(Cin, Cout)) {
             icn::launch_stem_fwd(x, w, bias, y, t.fwd, B * t.Pout, t.Pin, t.Pout, Cin, Cout, t.n_in, s);
         } else {
@@ -743,7 +756,7 @@ int icn_conv_pair_fwd(const float* x, const float* w0, const float* bias0, const
         if (!ws || ws_bytes < conv_ws_bytes(ICN_OP_CONV_FWD, B, Cin, Cout0, Cout1, r_in, stride))
             throw std::invalid_argument("icn_conv_pair_fwd: workspace too small");
         const ConvTables& t = conv_tables(r_in, stride, corner_mode);
-        conv_fwd_impl(x, w0, bias0, w1, bias1, y0, y1, B, Cin, Cout0, Cout1, t, ws, static_cast<hipStream_t>(stream));
+        conv_fwd_impl(x, w0, bias0, w1, bias1, y0, y1, B, Cin, Cout0, Cout1, r_in, stride, t, ws, static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());
         return 0;
     } catch (const std::exception& e) {

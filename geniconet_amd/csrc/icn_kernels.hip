@@ -61,6 +61,8 @@ __device__ __forceinline__ float gather1(const float* src, int32_t code, int b, 
 // [7][N][K] (k-contiguous) and concatenate the biases; blocks [npack, npack + nsrc * B * n_slots) fill the side buffer(s)
 // of a DmaTable:  side[b][s][:] = sum_e gather(slots[s][e])   (pixels / pole means of the source tensor; icn_geometry.h).
 __global__ __launch_bounds__(256) void k_conv_prologue(PrologueArgs a, int npack) {
+    if (a.zero && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.n_zero; i += 256) a.zero[i] = 0;
     if ((int)blockIdx.x < npack) {
         const int Ct = a.Cout + a.Cout2, total = Ct * a.Cin * 7;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += npack * 256) {
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256) void k_conv_prologue(PrologueArgs a, int npack
             for (int c = threadIdx.x; c < Ct; c += 256) a.bias_cat[c] = c < a.Cout ? a.bias[c] : a.bias2[c - a.Cout];
         return;
     }
+    if (a.n_slots <= 0 || !a.side) return;                // (a launch that only clears the flag words)
     int j = blockIdx.x - npack;
     const float* src = a.src;
     float* side = a.side;
@@ -343,6 +346,7 @@ bool gather_gemm_supported(int K, int N) { return K % BK == 0 && N % 64 == 0 && 
 //     up to whole dispatch waves.
 // ---------------------------------------------------------------------------------------------------------
 using lds_ptr_t = __attribute__((address_space(3))) void*;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Row offsets of the DMA kernels: < 2^31 byte offset into the source tensor; SIDE_FLAG | offset (< 2^30) a row of the side
 // buffer; NOTHING_OFFSET a row of zeros.  Both flagged forms are out of range for the source resource (tensors < 2 GiB) and
@@ -350,8 +354,27 @@ using lds_ptr_t = __attribute__((address_space(3))) void*;
 constexpr unsigned SIDE_FLAG = 0x80000000u;
 constexpr unsigned NOTHING_OFFSET = 0xC0000000u;
 
-template <int BM, int BN, bool SEG>   // SEG: class-major rows + virtual taps of a composite table (icn_upconv_*)
-__global__ __launch_bounds__(256) void k_conv_dma(
+// Stream-K plan of one XCD's share of a launch (q_x tiles for GL persistent blocks, nk k-chunks of 7 K-steps per tile).
+// Whole tiles are dealt round-robin as before (local tile indices < dp_l); the last 1 + frac rounds (nsk tiles) are cut into
+// GL equal ranges of k-chunks, so a block's tail is never a mostly idle round.  Host and device use the same function.
+struct SkPlan { int dp_l, nsk; };
+__host__ __device__ inline SkPlan sk_plan(int q_x, int GL, int nk) {
+    const int R = q_x / GL, frac = q_x - R * GL;
+    SkPlan p{q_x, 0};
+    if (frac == 0) return p;                              // whole rounds: nothing to balance
+    if (R >= 1) {                                         // ranges of 1 .. 2 tiles: a tile is shared by at most 3 blocks
+        p.dp_l = (R - 1) * GL;
+        p.nsk = GL + frac;
+    } else if ((long)frac * nk >= 2L * GL && 4 * frac >= GL) {
+        p.dp_l = 0;                                       // fewer tiles than blocks: >= 2 k-chunks per block, <= 5 blocks per tile
+        p.nsk = frac;
+    }
+    return p;
+}
+
+// (body of the two kernels below: k_conv_dma<BM, BN, SEG> and its stream-K form k_conv_dma_sk<BM, BN>)
+template <int BM, int BN, bool SEG, bool SK>   // SEG: class-major rows + virtual taps of a composite table (icn_upconv_*)
+__device__ __forceinline__ void conv_dma_body(
     const float* __restrict__ src,      // (B, Ps, Ks)   Ks = K, or K / 2 with src2
     const float* __restrict__ src2,     // second half of the K axis (pair bwd-data), or null
     const float* __restrict__ wt,       // [7][N][K]
@@ -364,7 +387,9 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     const int32_t* __restrict__ perm,   // [Pd] row -> dst pixel, or null (identity)
     const uint32_t* __restrict__ mask32,// [Pd/32] taps in use per 32 rows, or null (all 7)
     int M, int Ps, int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles, int T_arg,
-    const RowSegs segs) {
+    const RowSegs segs,
+    float* __restrict__ sk_part,        // SK: one BM x BN partial-accumulator slot per block (raw register layout)
+    int* __restrict__ sk_flag) {        // SK: CONV_SK_FLAGS words zeroed by the prologue: [b] = 1: block b's piece is parked; error word; tickets
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
     // T taps in wt / dcode (7 hex taps, or the virtual taps of a composite table); a tile runs at most 7 of them (its tap
     // mask), and the LDS offset table is indexed by a tap's RANK inside that mask.
@@ -570,17 +595,60 @@ __global__ __launch_bounds__(256) void k_conv_dma(
     // those with `s_waitcnt vmcnt(0)`, which drains the ring.
     // All loop state is kept in plain ints and passed through readfirstlane: hipcc must see the DMA's LDS base
     // and scalar offset as wave-uniform or it wraps every DMA in a waterfall loop.
+    // SK: a block's work is a list of SEGMENTS (tile, k-chunk range [k0, k1) of its nk): whole tiles b, b + G, ... first, then
+    // its range of the split tiles (sk_plan above), walked BACK TO FRONT.  seg_fetch hands out the next one; everything below
+    // that says "tile" means the segment's tile, and the K-step loop, the DMA pointer and the epilogue respect the
+    // segment's k-chunk range.
+    // Who waits for whom: of a tile cut in K, the block holding its LAST k-chunks finishes it; that piece lies at the front
+    // of the block's range, i.e. it is the last thing the block does, while the other pieces lie at the back of LOWER-numbered
+    // blocks' ranges, i.e. they are the first thing those blocks do after their whole tiles.  A block therefore only ever
+    // waits for lower block ids of its own launch -- dispatched before it, whatever else shares the GPU -- and those never
+    // wait for anything before parking their piece.  (A ticket drawn from an atomic counter instead of blockIdx would not
+    // even need in-order dispatch; its round trip at the top of every launch cost half of what stream-K gains.)
+    int sk_round = 0, sk_u0 = 0, sk_pos = 0, sk_dp_l = 0; // DP round; start of the range / walk position (k-chunk units); first split tile
+    long sk_U = 0;                                        // k-chunk units of this XCD's split tiles
+    const int sk_bl = blockIdx.x / 8;                     // rank within the XCD residue class
+    const int sk_x = blockIdx.x % 8, sk_GL = gridDim.x / 8;
+    if constexpr (SK) {
+        const SkPlan pl = sk_plan(ntiles / 8 + (sk_x < ntiles % 8 ? 1 : 0), sk_GL, nk);
+        sk_dp_l = pl.dp_l;
+        sk_U = (long)pl.nsk * nk;
+        sk_u0 = (int)(sk_U * sk_bl / sk_GL);
+        sk_pos = (int)(sk_U * (sk_bl + 1) / sk_GL);
+    }
+    auto seg_fetch = [&](int& tile_, int& k0_, int& k1_) __attribute__((always_inline)) {
+        const int li = sk_bl + sk_round * sk_GL;
+        if (li < sk_dp_l) {
+            ++sk_round;
+            tile_ = li * 8 + sk_x; k0_ = 0; k1_ = nk;
+            return 1;
+        }
+        if (sk_pos > sk_u0) {
+            const int lt = (sk_pos - 1) / nk;
+            k1_ = sk_pos - lt * nk;
+            k0_ = k1_ - min(k1_, sk_pos - sk_u0);
+            sk_pos -= k1_ - k0_;
+            tile_ = (sk_dp_l + lt) * 8 + sk_x;
+            return 1;
+        }
+        return 0;
+    };
     int tile = blockIdx.x, m0, n0;
+    int c_k0 = 0, c_k1 = nk, n_k0 = 0, n_k1 = nk;         // k-chunk range of the compute / next segment (SK; else whole tiles)
+    if constexpr (SK) {
+        if (!seg_fetch(tile, c_k0, c_k1)) return;         // more blocks than work (block-uniform, before any barrier)
+    }
     tile_origin(tile, m0, n0);
     build_first(m0, n0, tile_taps(m0));
     __syncthreads();
     int slot = 0, eslot = 0;                              // offset-table slot / epilogue-table slot of the compute tile
     int next_tile = tile + gridDim.x;
     int has_next = next_tile < ntiles;
+    if constexpr (SK) has_next = seg_fetch(next_tile, n_k0, n_k1);
     int nm0 = m0, nn0 = n0;
     if (has_next) tile_origin(next_tile, nm0, nn0);
     unsigned mask_c = tile_taps(m0), mask_n = has_next ? tile_taps(nm0) : 0x7fu;   // taps of the compute / next tile
-    int i_t = __ffs(mask_c) - 1, i_kc = 0, i_ring = 0, i_own = 1, i_live = 1;       // DMA pointer; i_own: inside compute tile
+    int i_t = __ffs(mask_c) - 1, i_kc = SK ? c_k0 : 0, i_ring = 0, i_own = 1, i_live = 1;   // DMA pointer; i_own: inside compute tile
     unsigned pbase[RA];                                   // row offsets of the next stage to be issued (prefetched)
 #pragma unroll
     for (int i = 0; i < RA; ++i) pbase[i] = otab[(SEG ? 0 : i_t) * BM + 8 * (wave + 4 * i) + rsub];   // SEG: rank 0
@@ -632,8 +700,8 @@ _Pragma("unroll") \
                 if (higher_) { \
                     i_t = __ffs(higher_) - 1; \
                 } else { \
-                    if (++i_kc == nk) { \
-                        i_kc = 0; \
+                    if (++i_kc == (SK ? (i_own ? c_k1 : n_k1) : nk)) { \
+                        i_kc = SK ? n_k0 : 0; \
                         if (i_own && has_next) { i_own = 0; mk_ = mask_n; } \
                         else i_live = 0; \
                     } \
@@ -719,7 +787,7 @@ _Pragma("unroll") \
     zero_acc();
     int c_ring = 0;
     for (;;) {
-        const int S = __popc(mask_c) * nk;                // K-steps of this tile
+        const int S = SK ? 7 * (c_k1 - c_k0) : __popc(mask_c) * nk;   // K-steps of this tile (SK: of this segment)
         for (int step = 0; step < S; ++step) {
             const bool meta = step == 0 && has_next;      // wave-uniform
             frag0(c_ring);
@@ -728,6 +796,67 @@ _Pragma("unroll") \
             compute(c_ring);
             ICN_RETIRE_AND_PUBLISH(meta);                 // stage s+1 landed and visible
             c_ring = c_ring == 2 ? 0 : c_ring + 1;
+        }
+        bool sk_store = true;
+        if constexpr (SK) {
+            // A tile cut in K: the block holding its FIRST k-chunks finishes it (that segment is the last thing the block does,
+            // the other pieces are the first thing later blocks do, so they are long done).  The others park their raw
+            // accumulators in their slot and raise their flag; the finisher adds the slots in block order -- a fixed order,
+            // so the result does not depend on timing.
+            // Slots and flags cross XCDs (one L2 each, not coherent with one another for ordinary accesses): every access to
+            // them is a system-scope one (sc0 sc1: written through / fetched past the caches), ordered by hand -- the data
+            // stores have completed (vmcnt) on every wave before the flag is raised, the data loads are issued after the
+            // flag was seen.  Release / acquire FENCES would do the same by writing back and invalidating the whole L2 of
+            // the XCD, once per block: measured, that made every launch 10 - 50 % slower.
+            constexpr int SYS = 17;                       // cache policy bits of the buffer builtins: sc0 | sc1
+            const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc(sk_part, 0, (int)(gridDim.x * (unsigned)(BM * BN * 4)), 0x00020000);
+            const int me = sk_bl * 8 + sk_x;               // this block's slot / flag
+            if (c_k1 < nk) {                               // a piece that does not reach the tile's end: park it
+                const unsigned base = (unsigned)me * (unsigned)(BM * BN * 4) + tid * 16u;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const f32x4 v = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_k,
+                                                                   base + ((i * TN + j) * 4 + r4) * 4096u, 0, SYS);
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(sk_flag + me, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                sk_store = false;
+            } else if (c_k0 > 0) {                         // the tile's last k-chunks: add the earlier blocks' pieces, nearest first
+                const int lt = tile / 8 - sk_dp_l;
+                int pos = lt * nk + c_k0, nb = sk_bl - 1;  // units [lt * nk, pos) are parked in the slots of blocks nb, nb - 1, ...
+                while (pos > lt * nk) {
+                    const int blk = nb * 8 + sk_x;
+                    int spins = 0;
+                    while (__hip_atomic_load(sk_flag + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1 << 22)) {        // seconds: a partner that never arrives is a bug, not a reason to hang the GPU
+                            if (tid == 0) atomicOr(sk_flag + CONV_SK_ERROR, 1);
+                            break;
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                    const unsigned base = (unsigned)blk * (unsigned)(BM * BN * 4) + tid * 16u;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4) {
+                                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                               rsrc_k, base + ((i * TN + j) * 4 + r4) * 4096u, 0, SYS));
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += v[e];
+                            }
+                    pos = max(lt * nk, (int)(sk_U * nb / sk_GL));   // block nb's range starts there
+                    --nb;
+                }
+            }
         }
         // ---- tile epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -746,7 +875,7 @@ _Pragma("unroll") \
                     if constexpr (SEG) {
                         const unsigned drow = drow_s[eslot * BM + rl];
                         if (drow != INVALID_ROW) dcol[(size_t)drow * dstride] = acc[i][j][r] + bv;
-                    } else if (m < M) {
+                    } else if (m < M && sk_store) {
                         const size_t drow = perm ? (size_t)drow_s[eslot * BM + rl] : (size_t)m;
                         dcol[drow * dstride] = acc[i][j][r] + bv;
                     }
@@ -763,6 +892,11 @@ _Pragma("unroll") \
         i_own = 1;                                        // the DMA pointer is already inside this tile
         next_tile = tile + gridDim.x;
         has_next = next_tile < ntiles;
+        if constexpr (SK) {
+            c_k0 = n_k0;
+            c_k1 = n_k1;
+            has_next = seg_fetch(next_tile, n_k0, n_k1);
+        }
         if (has_next) {
             tile_origin(next_tile, nm0, nn0);
             mask_n = tile_taps(nm0);
@@ -773,6 +907,35 @@ _Pragma("unroll") \
 #undef ICN_META_CONVERT
 #undef ICN_RETIRE_AND_PUBLISH
 #endif
+}
+
+template <int BM, int BN, bool SEG>
+__global__ __launch_bounds__(256) void k_conv_dma(const float* __restrict__ src, const float* __restrict__ src2,
+                                                   const float* __restrict__ wt, const float* __restrict__ bias,
+                                                   float* __restrict__ dst, float* __restrict__ dst2,
+                                                   const int32_t* __restrict__ dcode, const float* __restrict__ side,
+                                                   const float* __restrict__ side2, const int32_t* __restrict__ perm,
+                                                   const uint32_t* __restrict__ mask32, int M, int Ps, int Pd, int K, int N, int N0,
+                                                   int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles, int T_arg,
+                                                   const RowSegs segs) {
+    conv_dma_body<BM, BN, SEG, false>(src, src2, wt, bias, dst, dst2, dcode, side, side2, perm, mask32, M, Ps, Pd, K, N, N0, n_slots,
+                                      src_bytes, side_bytes, ntiles, T_arg, segs, nullptr, nullptr);
+}
+
+// Stream-K form for the plain 7-tap launches without row permutation: same tiles, same K-step pipeline; the last 1 + frac rounds
+// of tiles are cut into equal k-chunk ranges (sk_plan), so that a launch of 2.8 rounds takes 2.8 and not 3 tile times, and a
+// launch with fewer tiles than block slots (the 256 -> 256 layer at r = 2: 360 tiles for 768 slots) still uses every CU.
+// All blocks of the grid must be able to be resident at once (grid <= occupancy x CUs: the launcher's contract).
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv_dma_sk(const float* __restrict__ src, const float* __restrict__ src2,
+                                                      const float* __restrict__ wt, const float* __restrict__ bias,
+                                                      float* __restrict__ dst, float* __restrict__ dst2,
+                                                      const int32_t* __restrict__ dcode, const float* __restrict__ side,
+                                                      const float* __restrict__ side2, int M, int Ps, int Pd, int K, int N, int N0,
+                                                      int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles,
+                                                      float* __restrict__ sk_part, int* __restrict__ sk_flag) {
+    conv_dma_body<BM, BN, false, true>(src, src2, wt, bias, dst, dst2, dcode, side, side2, nullptr, nullptr, M, Ps, Pd, K, N, N0,
+                                       n_slots, src_bytes, side_bytes, ntiles, 7, RowSegs{}, sk_part, sk_flag);
 }
 
 // dynamic LDS of k_conv_dma: A/B rings, offset table, destination-row table (row permutation only), bias (bias only)
@@ -802,6 +965,42 @@ static void launch_conv_dma_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
     hipLaunchKernelGGL((k_conv_dma<BM, BN, SEG>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2,
                        a.dcode, a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.mask32, a.M,
                        a.Ps, a.Pd, a.K, a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs);
+    prof_mark_end(s);
+}
+
+// ---- stream-K form (k_conv_dma_sk) -------------------------------------------------------------------------------------------
+size_t conv_sk_part_bytes() { return (size_t)512 * 64 * 128 * sizeof(float); }   // 2 x 256 slots of 64x128 (>= 3 x 256 of 64x64)
+
+// Would the stream-K kernel split anything for this launch?  (XCD 0 has the most tiles; the kernel plans per XCD.)
+static bool conv_sk_splits(long ntiles, int slots, int nk) {
+    if (slots % 8 != 0 || ntiles < 8) return false;
+    return sk_plan((int)((ntiles + 7) / 8), slots / 8, nk).nsk > 0;
+}
+static bool conv_sk_eligible(const GatherGemmArgs& a) {
+    return a.sk_part != nullptr && a.sk_flag != nullptr && a.perm == nullptr && a.mask32 == nullptr && a.segs.nseg == 0 &&
+           (a.T == 0 || a.T == 7) && !(dbg_flags() & 128);
+}
+
+template <int BM, int BN>
+static void launch_conv_dma_sk(const GatherGemmArgs& a, int occ, hipStream_t s) {
+    const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+    const int grid = 256 * occ;                           // every block slot of the chip: all of them resident at once
+    if ((size_t)grid * BM * BN * sizeof(float) > conv_sk_part_bytes() || grid > CONV_SK_ERROR)
+        throw std::invalid_argument("icn: stream-K grid beyond its scratch");
+    const size_t lds = conv_dma_lds(BM, BN, false, a.bias != nullptr);
+    static std::atomic<uint64_t> attr_devices{0};
+    if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_dma_sk<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
+    }
+    const int Ks = a.src2 ? a.K / 2 : a.K;
+    const size_t nb = (size_t)(a.M / a.Pd);
+    const unsigned src_bytes = (unsigned)(nb * a.Ps * Ks * 4), side_bytes = (unsigned)(nb * a.n_slots * Ks * 4);
+    prof_mark_begin(BN == 128 ? PROF_DMAK_64x128 : PROF_DMAK_64x64, a.algo_flops, s);
+    hipLaunchKernelGGL((k_conv_dma_sk<BM, BN>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,
+                       a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.M, a.Ps, a.Pd, a.K, a.N,
+                       a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.sk_part, a.sk_flag);
     prof_mark_end(s);
 }
 
@@ -868,9 +1067,18 @@ static void launch_conv_dma_auto(const GatherGemmArgs& a, hipStream_t s) {
         const long rows = a.segs.nseg > 0 ? seg_rows(a.segs, c.bm, nullptr) : a.M;
         const long tiles = ((rows + c.bm - 1) / c.bm) * (a.N / c.bn);
         const long slots = 256L * occ;
-        double cost = (double)((tiles + slots - 1) / slots) * occ * c.bm * c.bn / (c.eff * occ / c.occ);
+        // rounds of tiles a block runs: whole rounds, unless the stream-K form evens out the last one (64-row tiles only)
+        const bool sk = c.bm == 64 && conv_sk_eligible(a) && conv_sk_splits(tiles, (int)slots, a.K / BK);
+        const double rounds = sk ? (double)tiles / slots : (double)((tiles + slots - 1) / slots);
+        double cost = rounds * occ * c.bm * c.bn / (c.eff * occ / c.occ);
         if (force && atoi(force) == i) cost = -1;
         if (best < 0 || cost < best_cost) { best = i; best_cost = cost; best_occ = occ; }
+    }
+    if (best >= 2 && conv_sk_eligible(a)) {
+        const DmaCfg& c = kDma[best];
+        const long tiles = ((long)(a.M + c.bm - 1) / c.bm) * (a.N / c.bn);
+        if (conv_sk_splits(tiles, 256 * best_occ, a.K / BK))
+            return best == 2 ? launch_conv_dma_sk<64, 128>(a, best_occ, s) : launch_conv_dma_sk<64, 64>(a, best_occ, s);
     }
     switch (best) {
         case 0: return launch_conv_dma<128, 128>(a, best_occ, s);
@@ -1867,8 +2075,8 @@ void launch_upconv_prologue(const UpconvPrologueArgs& a, hipStream_t s) {
 void launch_conv_prologue(const PrologueArgs& a, hipStream_t s) {
     const int npack = a.w ? std::min(2048, ((a.Cout + a.Cout2) * a.Cin * 7 + 255) / 256) : 0;
     const int nside = (a.side && a.n_slots > 0) ? a.B * a.n_slots * (a.src2 ? 2 : 1) : 0;
-    if (npack + nside == 0) return;
-    hipLaunchKernelGGL(k_conv_prologue, dim3(npack + nside), dim3(256), 0, s, a, npack);
+    if (npack + nside == 0 && !a.zero) return;
+    hipLaunchKernelGGL(k_conv_prologue, dim3(std::max(1, npack + nside)), dim3(256), 0, s, a, npack);
 }
 
 }  // namespace icn

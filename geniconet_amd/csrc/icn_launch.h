@@ -41,7 +41,13 @@ struct GatherGemmArgs {
     double algo_flops;      // algorithmic FLOPs of this launch (profiling only)
     int T;                  // taps of wt / dcode: 0 = the 7 hex taps; > 7: virtual taps of a composite table (LDS-DMA kernel only)
     RowSegs segs;           // nseg > 0: class-major rows (M = padded row count, perm = list position -> dst pixel)
+    float* sk_part;         // stream-K scratch: conv_sk_part_bytes() bytes, or null (no stream-K)
+    int* sk_flag;           // CONV_SK_FLAGS ints zeroed before the launch (PrologueArgs::zero), with sk_part
 };
+constexpr int CONV_SK_ERROR = 1024;                        // flag words: [0, 1024) one per block, then the error word
+constexpr int CONV_SK_FLAGS = 1032;
+size_t conv_sk_part_bytes();                               // partial-tile slots of the largest stream-K grid
+
 
 struct WgradArgs {
     const float* x;         // (B, Ps, Cin)
@@ -109,6 +115,7 @@ struct PrologueArgs {
     const float* w; const float* w2; float* packed; int Cout, Cout2, Cin, transpose;
     const float* bias; const float* bias2; float* bias_cat;
     const float* src; const float* src2; const int32_t* slots; float* side; float* side2; int n_slots, E, B, Ps, K, ns;
+    int* zero; int n_zero;  // words to clear (the stream-K flags of the GEMM this prologue precedes), or null
 };
 void launch_conv_prologue(const PrologueArgs& a, hipStream_t s);
 
@@ -170,6 +177,7 @@ enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA
                 PROF_GG_64x128, PROF_GG_64x64, PROF_WGD_128x128, PROF_WGD_128x64, PROF_WGD_64x128, PROF_WGD_64x64, PROF_WG_128x128,
                 PROF_WG_128x64, PROF_WG_64x128, PROF_WG_64x64,
                 PROF_DMAS_128x128, PROF_DMAS_128x64, PROF_DMAS_64x128, PROF_DMAS_64x64,   // k_conv_dma<.., true>: class-major rows
+                PROF_DMAK_64x128, PROF_DMAK_64x64,                                        // k_conv_dma_sk: stream-K form
                 PROF_KINDS };
 extern const char* const PROF_NAMES[PROF_KINDS];
 void prof_mark_begin(int kind, double flops, hipStream_t s);   // no-ops unless profiling is on

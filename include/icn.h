@@ -238,7 +238,8 @@ int icn_profile_stop(icn_profile_entry* out, int cap);
 int icn_profile_select(const char* kernel);
 
 /* Developer routing flags (same bits as the ICN_DEBUG environment variable, which only sets the initial value):
- * 16 = convolutions on the register-staged fallback kernel, 32 = weight gradients on it.  Returns the previous flags. */
+ * 16 = convolutions on the register-staged fallback kernel, 32 = weight gradients on it, 128 = no stream-K (every tile of
+ * the persistent GEMM computed whole by one workgroup).  Returns the previous flags. */
 int icn_set_debug_flags(int flags);
 
 #ifdef __cplusplus

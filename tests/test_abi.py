@@ -34,7 +34,9 @@ def test_workspace_query_is_host_only():
     L = _lib.lib()
     # AE I5/B36 largest layers: packed weights + the side buffer of the two pole means per mesh (fwd) and split-K slabs
     # (bwd-weight) are bounded
-    assert L.icn_conv_workspace_bytes(_lib.OP_CONV_FWD, 36, 128, 64, 5, 1) == 7 * 128 * 64 * 4 + 36 * 2 * 128 * 4
+    # ... + the stream-K scratch (flag words and 512 partial 64x128 tiles, include/icn.h)
+    sk = (1032 * 4 + 255) // 256 * 256 + 512 * 64 * 128 * 4
+    assert L.icn_conv_workspace_bytes(_lib.OP_CONV_FWD, 36, 128, 64, 5, 1) == 7 * 128 * 64 * 4 + 36 * 2 * 128 * 4 + sk
     assert L.icn_conv_workspace_bytes(_lib.OP_CONV_FWD, 36, 3, 64, 5, 1) == 0
     assert 0 < L.icn_conv_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, 36, 256, 256, 3, 1) < 256 << 20
     assert L.icn_conv_workspace_bytes(7, 36, 256, 256, 3, 1) == 0

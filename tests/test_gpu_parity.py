@@ -180,6 +180,56 @@ def test_tensors_beyond_2gib_take_the_fallback_kernels_and_agree_with_half_batch
 # tests/test_gpu_training_parity.py::test_register_staged_fallback_kernels_stay_correct)
 
 
+# Stream-K form of the persistent GEMM (k_conv_dma_sk): the last rounds of tiles cut in K across blocks, partial tiles combined in
+# a fixed order.  Shapes chosen to hit each plan at batch 36: 2.8 rounds of 64x128 tiles (r = 4, 128 -> 128), fewer tiles than
+# block slots (r = 2, 256 -> 256: 360 tiles, every tile shared by 2-3 blocks), a pair (two outputs / two gradient tensors),
+# 7.5 rounds of 64x64 tiles with two k-chunks per tile (r = 5, 64 -> 64, batch 12: 2.5 rounds).
+SK_CASES = [(4, 128, 128, 36, False), (2, 256, 256, 36, False), (3, 128, 128, 36, True), (5, 64, 64, 12, False), (3, 256, 256, 7, False)]
+
+
+@pytest.mark.parametrize('r,cin,cout,B,pair', SK_CASES, ids=lambda v: str(v))
+def test_stream_k_equals_whole_tile_schedule(r, cin, cout, B, pair):
+    from geniconet_amd import _lib
+    from geniconet_amd.ico_conv import ico_conv, ico_conv_pair
+    g = torch.Generator().manual_seed(r * 100 + cin)
+    n = 2 ** r
+    x = torch.randn(B, cin, 5 * n, 2 * n, generator=g).cuda()
+    ws = [(torch.randn(cout, cin, 7, generator=g) / (7 * cin) ** 0.5).cuda() for _ in range(2)]
+    bs = [torch.randn(cout, generator=g).cuda() for _ in range(2)]
+    gy = [torch.randn(B, cout, 5 * n, 2 * n, generator=g).cuda() for _ in range(2)]
+
+    def run(flags):
+        nonlocal x, gy
+        old = _lib.lib().icn_set_debug_flags(flags)
+        try:
+            xs = x.clone().requires_grad_()
+            _lib.profile_start(64)
+            if pair:
+                ys = ico_conv_pair(xs, ws[0], bs[0], ws[1], bs[1], r, 1, 'average')
+            else:
+                ys = (ico_conv(xs, ws[0], bs[0], r, 1, 'average'),)
+            torch.autograd.backward(ys, gy[:len(ys)])
+            torch.cuda.synchronize()
+            kernels = {e['kernel'].split('<')[0] for e in _lib.profile_stop()}
+            return [y.detach() for y in ys] + [xs.grad], kernels
+        finally:
+            _lib.lib().icn_set_debug_flags(old)
+
+    for trial in range(3):
+        # new data every time: the partial-tile slots are reused from launch to launch, so a block that read a stale copy of
+        # a neighbour's slot (the slots cross the XCDs' L2s) would show up here as a mismatch
+        x = torch.randn(B, cin, 5 * n, 2 * n, generator=g).cuda()
+        gy = [torch.randn(B, cout, 5 * n, 2 * n, generator=g).cuda() for _ in range(2)]
+        got, k_sk = run(0)
+        want, k_plain = run(128)
+        assert 'k_conv_dma_sk' in k_sk and 'k_conv_dma_sk' not in k_plain, (k_sk, k_plain)
+        for a, b in zip(got, want):
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, trial
+        again, _ = run(0)                                    # fixed summation order: bit-identical when repeated
+        for a, b in zip(got, again):
+            assert torch.equal(a, b), trial
+
+
 def test_conv_without_bias_and_noncontiguous_input():
     from geniconet_amd.ico_conv import ico_conv
     for k, (got, want) in conv_both(2, 1, 64, 64, 2, 'average', seed=5, bias=False).items():
@@ -298,8 +348,17 @@ def test_full_size_linearity_and_chart_equivariance(name, r, B, cin, cout, strid
     lin = 1.5 * (y1 - y0) + (y2 - y0) + y0
     assert float((y12 - lin).norm() / lin.norm()) < 1e-5
     ys = f(torch.roll(x1, n, dims=2))
-    # same arithmetic on another chart; only the pole mean sums its 5 corners in a rotated order (1-ulp effects)
     d = (ys - torch.roll(y1, n // stride, dims=2)).abs()
+    assert float(d.max()) < 1e-5
+    # With every tile computed whole by one workgroup (stream-K off: it cuts some tiles' K range at positions that depend on
+    # the tile, i.e. on the chart) it is the same arithmetic on another chart; only the pole mean sums its 5 corners in a
+    # rotated order (1-ulp effects).
+    from geniconet_amd import _lib
+    old = _lib.lib().icn_set_debug_flags(128)
+    try:
+        d = (f(torch.roll(x1, n, dims=2)) - torch.roll(f(x1), n // stride, dims=2)).abs()
+    finally:
+        _lib.lib().icn_set_debug_flags(old)
     assert float(d.max()) < 1e-5
     assert int((d > 0).sum()) <= B * cout * 10 * 3
 
