@@ -562,7 +562,8 @@ const char* const PROF_NAMES[PROF_KINDS] = {"k_conv_dma<128, 128, false>", "k_co
                                             "k_wgrad_dma<64, 128>", "k_wgrad_dma<64, 64>", "k_wgrad<128, 128>", "k_wgrad<128, 64>",
                                             "k_wgrad<64, 128>", "k_wgrad<64, 64>", "k_conv_dma<128, 128, true>",
                                             "k_conv_dma<128, 64, true>", "k_conv_dma<64, 128, true>", "k_conv_dma<64, 64, true>",
-                                            "k_conv_dma_sk<64, 128>", "k_conv_dma_sk<64, 64>"};
+                                            "k_conv_dma_sk<64, 128, false>", "k_conv_dma_sk<64, 64, false>", "k_conv_dma_sk<64, 128, true>",
+                                            "k_conv_dma_sk<64, 64, true>"};
 void prof_mark_begin(int kind, double flops, hipStream_t s) {
     if (!g_prof_on) return;
     g_prof_mu.lock();
@@ -830,7 +831,7 @@ size_t upconv_ws_bytes(int B, int Cin, int C0, int C1, int r_in) {
     const size_t composite = align256((size_t)icn::UPCONV_TAPS * C * Cin * sizeof(float)) + align256(C * sizeof(float)) +
                              align256((size_t)B * upconv_slots(r_in) * Cin * sizeof(float));
     const size_t dense = align256((size_t)7 * C * Cin * sizeof(float)) + align256(C * sizeof(float)) +
-                         align256((size_t)B * icn::pixels(r_in) * 7 * C * sizeof(float));
+                         align256((size_t)B * icn::pixels(r_in) * 7 * C * sizeof(float)) + sk_ws_bytes();
     return upconv_dense_ok(B, Cin, C0, C1, r_in) ? std::max(composite, dense) : composite;
 }
 }  // namespace
@@ -868,7 +869,9 @@ int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const fl
             float* wf = static_cast<float*>(ws);
             float* bias_cat = (w1 && bias0) ? reinterpret_cast<float*>(at(ws, wb)) : nullptr;
             float* z = reinterpret_cast<float*>(at(ws, wb + bb));
+            int* sk_flag = reinterpret_cast<int*>(at(ws, wb + bb + align256((size_t)B * d.Pc * 7 * C * sizeof(float))));
             icn::PrologueArgs p{};                     // [7][C][Cin] = the B operand [1][N = 7 * C][K = Cin] of one dense GEMM
+            p.zero = sk_flag; p.n_zero = icn::CONV_SK_FLAGS;
             p.w = w0; p.w2 = w1; p.packed = wf; p.Cout = Cout0; p.Cout2 = Cout1; p.Cin = Cin; p.transpose = 0;
             p.bias = bias0; p.bias2 = bias1; p.bias_cat = bias_cat;
             icn::launch_conv_prologue(p, s);
@@ -877,6 +880,8 @@ int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const fl
             a.Ps = d.Pc; a.Pd = d.Pc; a.K = Cin; a.N = 7 * C; a.E = 1; a.T = 1; a.M = B * d.Pc;
             a.segs.nseg = 1; a.segs.B = B; a.segs.cnt[0] = d.Pc; a.segs.off[0] = 0; a.segs.mask[0] = 1u;
             a.algo_flops = 2.0 * 7 * Cin * C * (double)B * d.Pc;                  // executed: a quarter of the fine-level forward
+            a.sk_flag = sk_flag;
+            a.sk_part = reinterpret_cast<float*>(reinterpret_cast<char*>(sk_flag) + align256((size_t)icn::CONV_SK_FLAGS * sizeof(int)));
             icn::launch_gather_gemm_auto(a, s);
             const EllSplitDev& sc = d.scatter;
             const float* bias = w1 ? bias_cat : bias0;
@@ -924,7 +929,7 @@ bool upconv_bwd_supported(int B, int Cin, int C0, int C1, int r_in, int corner_m
     if ((size_t)7 * C * Cin * 4 >= lim) return false;
     return icn::gather_gemm_supported((int)(7 * C), Cin) && icn::wgrad_supported(Cin, (int)C);
 }
-struct UpconvBwdWs { size_t g, wb, partial, bpart, total; };
+struct UpconvBwdWs { size_t g, wb, partial, bpart, sk, total; };
 UpconvBwdWs upconv_bwd_ws(int B, int Cin, int C0, int C1, int r_in) {
     const int C = C0 + C1, M = B * icn::pixels(r_in);
     UpconvBwdWs w{};
@@ -932,7 +937,8 @@ UpconvBwdWs upconv_bwd_ws(int B, int Cin, int C0, int C1, int r_in) {
     w.wb = align256((size_t)M * 7 * C * sizeof(float));
     w.partial = w.wb + align256((size_t)7 * C * Cin * sizeof(float));
     w.bpart = w.partial + wgrad_partial_bytes(M, Cin, C, C1 ? C0 : C);
-    w.total = w.bpart + wgrad_bias_partial_bytes(M, Cin, C, C1 ? C0 : C);
+    w.sk = w.bpart + wgrad_bias_partial_bytes(M, Cin, C, C1 ? C0 : C);   // stream-K scratch of the dx GEMM
+    w.total = w.sk + sk_ws_bytes();
     return w;
 }
 }  // namespace
@@ -976,12 +982,16 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
             float* wb = reinterpret_cast<float*>(at(ws, wo.wb));
             icn::PrologueArgs p{};
             p.w = w0; p.w2 = w1; p.packed = wb; p.Cout = Cout0; p.Cout2 = Cout1; p.Cin = Cin; p.transpose = 2;
+            int* sk_flag = reinterpret_cast<int*>(at(ws, wo.sk));
+            p.zero = sk_flag; p.n_zero = icn::CONV_SK_FLAGS;
             icn::launch_conv_prologue(p, s);
             icn::GatherGemmArgs a{};
             a.src = g; a.wt = wb; a.dst = dx; a.N0 = Cin; a.dcode = t.iota; a.perm = t.iota;
             a.Ps = t.Pc; a.Pd = t.Pc; a.K = 7 * C; a.N = Cin; a.E = 1; a.T = 1; a.M = M;
             a.segs.nseg = 1; a.segs.B = B; a.segs.cnt[0] = t.Pc; a.segs.off[0] = 0; a.segs.mask[0] = 1u;
             a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pc;            // executed: a quarter of the fine-level bwd-data it replaces
+            a.sk_flag = sk_flag;
+            a.sk_part = reinterpret_cast<float*>(reinterpret_cast<char*>(sk_flag) + align256((size_t)icn::CONV_SK_FLAGS * sizeof(int)));
             icn::launch_gather_gemm_auto(a, s);
         }
         if (dw0) {

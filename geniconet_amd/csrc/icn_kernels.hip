@@ -388,6 +388,7 @@ __device__ __forceinline__ void conv_dma_body(
     const uint32_t* __restrict__ mask32,// [Pd/32] taps in use per 32 rows, or null (all 7)
     int M, int Ps, int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles, int T_arg,
     const RowSegs segs,
+    int sk_ku,                          // SK: k-chunks per unit of the split (1 with 7 taps per k-chunk; 4 for a one-tap launch: >= 4 K-steps)
     float* __restrict__ sk_part,        // SK: one BM x BN partial-accumulator slot per block (raw register layout)
     int* __restrict__ sk_flag) {        // SK: CONV_SK_FLAGS words zeroed by the prologue: [b] = 1: block b's piece is parked; error word; tickets
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
@@ -610,9 +611,9 @@ __device__ __forceinline__ void conv_dma_body(
     const int sk_bl = blockIdx.x / 8;                     // rank within the XCD residue class
     const int sk_x = blockIdx.x % 8, sk_GL = gridDim.x / 8;
     if constexpr (SK) {
-        const SkPlan pl = sk_plan(ntiles / 8 + (sk_x < ntiles % 8 ? 1 : 0), sk_GL, nk);
+        const SkPlan pl = sk_plan(ntiles / 8 + (sk_x < ntiles % 8 ? 1 : 0), sk_GL, nk / sk_ku);
         sk_dp_l = pl.dp_l;
-        sk_U = (long)pl.nsk * nk;
+        sk_U = (long)pl.nsk * (nk / sk_ku);
         sk_u0 = (int)(sk_U * sk_bl / sk_GL);
         sk_pos = (int)(sk_U * (sk_bl + 1) / sk_GL);
     }
@@ -624,10 +625,10 @@ __device__ __forceinline__ void conv_dma_body(
             return 1;
         }
         if (sk_pos > sk_u0) {
-            const int lt = (sk_pos - 1) / nk;
-            k1_ = sk_pos - lt * nk;
-            k0_ = k1_ - min(k1_, sk_pos - sk_u0);
-            sk_pos -= k1_ - k0_;
+            const int nku = nk / sk_ku, lt = (sk_pos - 1) / nku;
+            const int u1 = sk_pos - lt * nku, u0 = u1 - min(u1, sk_pos - sk_u0);
+            sk_pos -= u1 - u0;
+            k0_ = u0 * sk_ku; k1_ = u1 * sk_ku;
             tile_ = (sk_dp_l + lt) * 8 + sk_x;
             return 1;
         }
@@ -787,7 +788,7 @@ _Pragma("unroll") \
     zero_acc();
     int c_ring = 0;
     for (;;) {
-        const int S = SK ? 7 * (c_k1 - c_k0) : __popc(mask_c) * nk;   // K-steps of this tile (SK: of this segment)
+        const int S = __popc(mask_c) * (SK ? c_k1 - c_k0 : nk);      // K-steps of this tile (SK: of this segment)
         for (int step = 0; step < S; ++step) {
             const bool meta = step == 0 && has_next;      // wave-uniform
             frag0(c_ring);
@@ -828,9 +829,9 @@ _Pragma("unroll") \
                 if (tid == 0) __hip_atomic_store(sk_flag + me, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 sk_store = false;
             } else if (c_k0 > 0) {                         // the tile's last k-chunks: add the earlier blocks' pieces, nearest first
-                const int lt = tile / 8 - sk_dp_l;
-                int pos = lt * nk + c_k0, nb = sk_bl - 1;  // units [lt * nk, pos) are parked in the slots of blocks nb, nb - 1, ...
-                while (pos > lt * nk) {
+                const int nku = nk / sk_ku, lt = tile / 8 - sk_dp_l;
+                int pos = lt * nku + c_k0 / sk_ku, nb = sk_bl - 1;   // units [lt * nku, pos) are parked in the slots of blocks nb, nb - 1, ...
+                while (pos > lt * nku) {
                     const int blk = nb * 8 + sk_x;
                     int spins = 0;
                     while (__hip_atomic_load(sk_flag + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
@@ -853,7 +854,7 @@ _Pragma("unroll") \
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += v[e];
                             }
-                    pos = max(lt * nk, (int)(sk_U * nb / sk_GL));   // block nb's range starts there
+                    pos = max(lt * nku, (int)(sk_U * nb / sk_GL));  // block nb's range starts there
                     --nb;
                 }
             }
@@ -874,7 +875,7 @@ _Pragma("unroll") \
                     const int rl = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, m = m0 + rl;
                     if constexpr (SEG) {
                         const unsigned drow = drow_s[eslot * BM + rl];
-                        if (drow != INVALID_ROW) dcol[(size_t)drow * dstride] = acc[i][j][r] + bv;
+                        if (drow != INVALID_ROW && sk_store) dcol[(size_t)drow * dstride] = acc[i][j][r] + bv;
                     } else if (m < M && sk_store) {
                         const size_t drow = perm ? (size_t)drow_s[eslot * BM + rl] : (size_t)m;
                         dcol[drow * dstride] = acc[i][j][r] + bv;
@@ -919,23 +920,24 @@ __global__ __launch_bounds__(256) void k_conv_dma(const float* __restrict__ src,
                                                    int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles, int T_arg,
                                                    const RowSegs segs) {
     conv_dma_body<BM, BN, SEG, false>(src, src2, wt, bias, dst, dst2, dcode, side, side2, perm, mask32, M, Ps, Pd, K, N, N0, n_slots,
-                                      src_bytes, side_bytes, ntiles, T_arg, segs, nullptr, nullptr);
+                                      src_bytes, side_bytes, ntiles, T_arg, segs, 1, nullptr, nullptr);
 }
 
-// Stream-K form for the plain 7-tap launches without row permutation: same tiles, same K-step pipeline; the last 1 + frac rounds
-// of tiles are cut into equal k-chunk ranges (sk_plan), so that a launch of 2.8 rounds takes 2.8 and not 3 tile times, and a
-// launch with fewer tiles than block slots (the 256 -> 256 layer at r = 2: 360 tiles for 768 slots) still uses every CU.
-// All blocks of the grid must be able to be resident at once (grid <= occupancy x CUs: the launcher's contract).
-template <int BM, int BN>
+// Stream-K form: same tiles, same K-step pipeline; the last 1 + frac rounds of tiles are cut into equal k-chunk ranges (sk_plan),
+// so that a launch of 2.8 rounds takes 2.8 and not 3 tile times, and a launch with fewer tiles than block slots (the 256 -> 256
+// layer at r = 2: 360 tiles for 768 slots) still uses every CU.  For launches whose tiles all run the same taps: the plain
+// 7-tap convolutions without row permutation (SEG = false), and the one-tap dense GEMMs of the decoder heads (SEG = true).
+template <int BM, int BN, bool SEG>
 __global__ __launch_bounds__(256) void k_conv_dma_sk(const float* __restrict__ src, const float* __restrict__ src2,
                                                       const float* __restrict__ wt, const float* __restrict__ bias,
                                                       float* __restrict__ dst, float* __restrict__ dst2,
                                                       const int32_t* __restrict__ dcode, const float* __restrict__ side,
-                                                      const float* __restrict__ side2, int M, int Ps, int Pd, int K, int N, int N0,
-                                                      int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles,
+                                                      const float* __restrict__ side2, const int32_t* __restrict__ perm, int M, int Ps,
+                                                      int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes,
+                                                      unsigned side_bytes, int ntiles, int T_arg, const RowSegs segs, int sk_ku,
                                                       float* __restrict__ sk_part, int* __restrict__ sk_flag) {
-    conv_dma_body<BM, BN, false, true>(src, src2, wt, bias, dst, dst2, dcode, side, side2, nullptr, nullptr, M, Ps, Pd, K, N, N0,
-                                       n_slots, src_bytes, side_bytes, ntiles, 7, RowSegs{}, sk_part, sk_flag);
+    conv_dma_body<BM, BN, SEG, true>(src, src2, wt, bias, dst, dst2, dcode, side, side2, SEG ? perm : nullptr, nullptr, M, Ps, Pd, K, N, N0, n_slots,
+                                     src_bytes, side_bytes, ntiles, T_arg, segs, sk_ku, sk_part, sk_flag);
 }
 
 // dynamic LDS of k_conv_dma: A/B rings, offset table, destination-row table (row permutation only), bias (bias only)
@@ -976,31 +978,35 @@ static bool conv_sk_splits(long ntiles, int slots, int nk) {
     if (slots % 8 != 0 || ntiles < 8) return false;
     return sk_plan((int)((ntiles + 7) / 8), slots / 8, nk).nsk > 0;
 }
+// k-chunks per unit of the split: a piece must run >= 4 K-steps (the ring's fill and the metadata look-ahead)
+static int conv_sk_ku(const GatherGemmArgs& a) { return a.segs.nseg > 0 ? 4 : 1; }
 static bool conv_sk_eligible(const GatherGemmArgs& a) {
-    return a.sk_part != nullptr && a.sk_flag != nullptr && a.perm == nullptr && a.mask32 == nullptr && a.segs.nseg == 0 &&
-           (a.T == 0 || a.T == 7) && !(dbg_flags() & 128);
+    if (a.sk_part == nullptr || a.sk_flag == nullptr || a.mask32 != nullptr || (dbg_flags() & 128)) return false;
+    if (a.segs.nseg == 0) return a.perm == nullptr && (a.T == 0 || a.T == 7);           // plain 7-tap convolution
+    return a.segs.nseg == 1 && a.T == 1 && a.segs.mask[0] == 1u && (a.K / BK) % 4 == 0;  // one-tap dense GEMM
 }
 
-template <int BM, int BN>
-static void launch_conv_dma_sk(const GatherGemmArgs& a, int occ, hipStream_t s) {
-    const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+template <int BM, int BN, bool SEG>
+static void launch_conv_dma_sk_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
+    const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);   // SEG: M is the padded row count
     const int grid = 256 * occ;                           // every block slot of the chip: all of them resident at once
     if ((size_t)grid * BM * BN * sizeof(float) > conv_sk_part_bytes() || grid > CONV_SK_ERROR)
         throw std::invalid_argument("icn: stream-K grid beyond its scratch");
-    const size_t lds = conv_dma_lds(BM, BN, false, a.bias != nullptr);
+    const size_t lds = conv_dma_lds(BM, BN, a.perm != nullptr, a.bias != nullptr);
     static std::atomic<uint64_t> attr_devices{0};
     if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_dma_sk<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_dma_sk<BM, BN, SEG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
     }
     const int Ks = a.src2 ? a.K / 2 : a.K;
-    const size_t nb = (size_t)(a.M / a.Pd);
+    const size_t nb = SEG ? (size_t)a.segs.B : (size_t)(a.M / a.Pd);
     const unsigned src_bytes = (unsigned)(nb * a.Ps * Ks * 4), side_bytes = (unsigned)(nb * a.n_slots * Ks * 4);
-    prof_mark_begin(BN == 128 ? PROF_DMAK_64x128 : PROF_DMAK_64x64, a.algo_flops, s);
-    hipLaunchKernelGGL((k_conv_dma_sk<BM, BN>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,
-                       a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.M, a.Ps, a.Pd, a.K, a.N,
-                       a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.sk_part, a.sk_flag);
+    prof_mark_begin((SEG ? PROF_DMAKS_64x128 : PROF_DMAK_64x128) + (BN == 128 ? 0 : 1), a.algo_flops, s);
+    hipLaunchKernelGGL((k_conv_dma_sk<BM, BN, SEG>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,
+                       a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.M, a.Ps, a.Pd, a.K,
+                       a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs, conv_sk_ku(a),
+                       a.sk_part, a.sk_flag);
     prof_mark_end(s);
 }
 
@@ -1021,6 +1027,14 @@ static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
     GatherGemmArgs b = a;
     b.M = (int)seg_rows(a.segs, BM, b.segs.row0);
     launch_conv_dma_t<BM, BN, true>(b, occ, s);
+}
+
+template <int BM, int BN>
+static void launch_conv_dma_sk(const GatherGemmArgs& a, int occ, hipStream_t s) {
+    if (a.segs.nseg == 0) return launch_conv_dma_sk_t<BM, BN, false>(a, occ, s);
+    GatherGemmArgs b = a;
+    b.M = (int)seg_rows(a.segs, BM, b.segs.row0);
+    launch_conv_dma_sk_t<BM, BN, true>(b, occ, s);
 }
 
 bool conv_dma_usable(const GatherGemmArgs& a) {
@@ -1068,7 +1082,7 @@ static void launch_conv_dma_auto(const GatherGemmArgs& a, hipStream_t s) {
         const long tiles = ((rows + c.bm - 1) / c.bm) * (a.N / c.bn);
         const long slots = 256L * occ;
         // rounds of tiles a block runs: whole rounds, unless the stream-K form evens out the last one (64-row tiles only)
-        const bool sk = c.bm == 64 && conv_sk_eligible(a) && conv_sk_splits(tiles, (int)slots, a.K / BK);
+        const bool sk = c.bm == 64 && conv_sk_eligible(a) && conv_sk_splits(tiles, (int)slots, a.K / BK / conv_sk_ku(a));
         const double rounds = sk ? (double)tiles / slots : (double)((tiles + slots - 1) / slots);
         double cost = rounds * occ * c.bm * c.bn / (c.eff * occ / c.occ);
         if (force && atoi(force) == i) cost = -1;
@@ -1076,8 +1090,9 @@ static void launch_conv_dma_auto(const GatherGemmArgs& a, hipStream_t s) {
     }
     if (best >= 2 && conv_sk_eligible(a)) {
         const DmaCfg& c = kDma[best];
-        const long tiles = ((long)(a.M + c.bm - 1) / c.bm) * (a.N / c.bn);
-        if (conv_sk_splits(tiles, 256 * best_occ, a.K / BK))
+        const long rows = a.segs.nseg > 0 ? seg_rows(a.segs, c.bm, nullptr) : a.M;
+        const long tiles = ((rows + c.bm - 1) / c.bm) * (a.N / c.bn);
+        if (conv_sk_splits(tiles, 256 * best_occ, a.K / BK / conv_sk_ku(a)))
             return best == 2 ? launch_conv_dma_sk<64, 128>(a, best_occ, s) : launch_conv_dma_sk<64, 64>(a, best_occ, s);
     }
     switch (best) {

@@ -177,7 +177,7 @@ enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA
                 PROF_GG_64x128, PROF_GG_64x64, PROF_WGD_128x128, PROF_WGD_128x64, PROF_WGD_64x128, PROF_WGD_64x64, PROF_WG_128x128,
                 PROF_WG_128x64, PROF_WG_64x128, PROF_WG_64x64,
                 PROF_DMAS_128x128, PROF_DMAS_128x64, PROF_DMAS_64x128, PROF_DMAS_64x64,   // k_conv_dma<.., true>: class-major rows
-                PROF_DMAK_64x128, PROF_DMAK_64x64,                                        // k_conv_dma_sk: stream-K form
+                PROF_DMAK_64x128, PROF_DMAK_64x64, PROF_DMAKS_64x128, PROF_DMAKS_64x64,    // k_conv_dma_sk<.., SEG>: stream-K form
                 PROF_KINDS };
 extern const char* const PROF_NAMES[PROF_KINDS];
 void prof_mark_begin(int kind, double flops, hipStream_t s);   // no-ops unless profiling is on

@@ -230,6 +230,46 @@ def test_stream_k_equals_whole_tile_schedule(r, cin, cout, B, pair):
             assert torch.equal(a, b), trial
 
 
+@pytest.mark.parametrize('r,cin,cout,B', [(2, 256, 256, 36), (3, 256, 128, 36), (4, 128, 64, 9)])
+def test_stream_k_in_the_decoder_heads_dense_gemms(r, cin, cout, B):
+    """The one-tap dense GEMMs of icn_upconv_fwd / icn_upconv_bwd (k_conv_dma_sk<.., true>: class-major rows, destination
+    rows through the permutation table) against the whole-tile schedule, new data each trial."""
+    from geniconet_amd import _lib
+    from geniconet_amd.ico_conv import ico_upconv_pair
+    g = torch.Generator().manual_seed(r * 7 + cin)
+    n = 2 ** r
+    ws = [(torch.randn(cout, cin, 7, generator=g) / (7 * cin) ** 0.5).cuda().requires_grad_() for _ in range(2)]
+    bs = [torch.randn(cout, generator=g).cuda().requires_grad_() for _ in range(2)]
+
+    def run(flags, x, gy):
+        old = _lib.lib().icn_set_debug_flags(flags)
+        try:
+            xs = x.clone().requires_grad_()
+            _lib.profile_start(64)
+            ys = ico_upconv_pair(xs, ws[0], bs[0], ws[1], bs[1], r, 'average')
+            grads = torch.autograd.grad(ys, [xs] + ws + bs, gy)
+            torch.cuda.synchronize()
+            kernels = {e['kernel'] for e in _lib.profile_stop()}
+            return [y.detach() for y in ys] + list(grads), kernels
+        finally:
+            _lib.lib().icn_set_debug_flags(old)
+
+    seen = set()
+    for trial in range(3):
+        x = torch.randn(B, cin, 5 * n, 2 * n, generator=g).cuda()
+        gy = [torch.randn(B, cout, 10 * n, 4 * n, generator=g).cuda() for _ in range(2)]
+        got, k_sk = run(0, x, gy)
+        want, k_plain = run(128, x, gy)
+        seen |= k_sk
+        assert not any(k.startswith('k_conv_dma_sk') for k in k_plain), k_plain
+        for a, b in zip(got, want):
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, trial
+        again, _ = run(0, x, gy)
+        for a, b in zip(got, again):
+            assert torch.equal(a, b), trial
+    assert any(k.startswith('k_conv_dma_sk') and k.endswith('true>') for k in seen), seen
+
+
 def test_conv_without_bias_and_noncontiguous_input():
     from geniconet_amd.ico_conv import ico_conv
     for k, (got, want) in conv_both(2, 1, 64, 64, 2, 'average', seed=5, bias=False).items():
