@@ -52,7 +52,9 @@ const char* icn_last_error(void);
 int icn_prepare_conv(int r_in, int stride, int corner_mode);
 int icn_prepare_upsample(int r_in, int corner_mode);
 
-/* Bytes of caller-provided workspace an op needs (0 is a valid answer). */
+/* Bytes of caller-provided workspace an op needs (0 is a valid answer).  For the forward and data-gradient ops of the MFMA
+ * path this includes ~17 MB of stream-K scratch: the persistent GEMM cuts the tiles of its last rounds in K across
+ * workgroups, which park partial tiles there; the contents need not survive the call. */
 size_t icn_conv_workspace_bytes(int op, int B, int Cin, int Cout, int r_in, int stride);
 
 /* y[b,p,co] = bias[co] + sum_t sum_ci w[co,ci,t] * x[b, nbr_t(p), ci]         (IcoConvS2S.forward) */
