@@ -831,6 +831,7 @@ _Pragma("unroll") \
             } else if (c_k0 > 0) {                         // the tile's last k-chunks: add the earlier blocks' pieces, nearest first
                 const int nku = nk / sk_ku, lt = tile / 8 - sk_dp_l;
                 int pos = lt * nku + c_k0 / sk_ku, nb = sk_bl - 1;   // units [lt * nku, pos) are parked in the slots of blocks nb, nb - 1, ...
+                bool sk_lost = false;
                 while (pos > lt * nku) {
                     const int blk = nb * 8 + sk_x;
                     int spins = 0;
@@ -838,6 +839,7 @@ _Pragma("unroll") \
                         __builtin_amdgcn_s_sleep(8);
                         if (++spins > (1 << 22)) {        // seconds: a partner that never arrives is a bug, not a reason to hang the GPU
                             if (tid == 0) atomicOr(sk_flag + CONV_SK_ERROR, 1);
+                            sk_lost = true;
                             break;
                         }
                     }
@@ -856,6 +858,14 @@ _Pragma("unroll") \
                             }
                     pos = max(lt * nku, (int)(sk_U * nb / sk_GL));  // block nb's range starts there
                     --nb;
+                }
+                if (sk_lost) {                             // make the failure loud: the tile becomes NaN, and so does the loss
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_nanf("");
                 }
             }
         }
