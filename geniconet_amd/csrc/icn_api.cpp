@@ -1149,6 +1149,7 @@ int icn_adam_step(int count, float* const* params, const float* const* grads, fl
                 throw std::invalid_argument("icn_adam_step: null tensor pointer");
         if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0))
             throw std::invalid_argument("icn_adam_step: betas must lie in [0, 1), eps must not be negative");
+        if (count == 0) return 0;
         icn::launch_adam(count, params, grads, exp_avg, exp_avg_sq, numel, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay,
                          static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());

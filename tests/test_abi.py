@@ -40,3 +40,22 @@ def test_workspace_query_is_host_only():
     assert L.icn_conv_workspace_bytes(_lib.OP_CONV_FWD, 36, 3, 64, 5, 1) == 0
     assert 0 < L.icn_conv_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, 36, 256, 256, 3, 1) < 256 << 20
     assert L.icn_conv_workspace_bytes(7, 36, 256, 256, 3, 1) == 0
+
+
+def test_adam_step_rejects_bad_arguments_before_touching_a_device():
+    """icn_adam_step validates its host-side arguments first (include/icn.h); nothing here reaches a kernel launch."""
+    import ctypes
+    L = _lib.lib()
+    one = (ctypes.c_void_p * 1)(0x1000)
+    n1 = (ctypes.c_size_t * 1)(4)
+    f1 = (ctypes.c_float * 1)(1e-3)
+    assert L.icn_adam_step(0, None, None, None, None, None, None, None, 0.9, 0.999, 1e-8, 0.0, None) == 0   # nothing to do
+    assert L.icn_adam_step(-1, one, one, one, one, n1, f1, f1, 0.9, 0.999, 1e-8, 0.0, None) != 0
+    assert L.icn_adam_step(1, None, one, one, one, n1, f1, f1, 0.9, 0.999, 1e-8, 0.0, None) != 0
+    null = (ctypes.c_void_p * 1)(None)
+    assert L.icn_adam_step(1, one, null, one, one, n1, f1, f1, 0.9, 0.999, 1e-8, 0.0, None) != 0
+    assert b'null tensor' in L.icn_last_error()
+    assert L.icn_adam_step(1, one, one, one, one, n1, f1, f1, 1.0, 0.999, 1e-8, 0.0, None) != 0            # beta1 must be < 1
+    assert L.icn_adam_step(1, one, one, one, one, n1, f1, f1, 0.9, 0.999, -1.0, 0.0, None) != 0            # eps >= 0
+    assert b'betas' in L.icn_last_error()
+
