@@ -118,6 +118,108 @@ __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_b
 #endif
 }
 
+// Waves per block: the production kernels run 4 waves (2 x 2) per block; NW = 8 arranges them WR x WC over the tile, each wave a
+// (BM / WR) x (BN / WC) sub-tile of 32 x 32 MFMA tiles -- same LDS per block, twice the waves per SIMD to cover a block's barrier.
+// Level-4 traffic only (the conv's real gather), 3-stage ring.
+template <int BM, int BN, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC) void k_ladder_w(const float* src, unsigned src_bytes, float* out, int steps, int rows_total) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WR * WC, NST = 3;
+    constexpr int TM = BM / WR / 32, TN = BN / WC / 32, RA = BM / 8 / NW, RB = BN / 8 / NW, NDMA = RA + RB;
+    static_assert(TM >= 1 && TN >= 1 && RA >= 1 && RB >= 1, "tile too small for this wave grid");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);
+    float* Bs = As + NST * BM * BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC, l31 = lane & 31, h = lane >> 5, rsub = lane >> 3, pc = lane & 7;
+    for (int i = tid; i < NST * (BM + BN) * BK; i += 64 * NW) As[i] = 1e-3f * (float)((i * 37) % 101 - 50);
+    __syncthreads();
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+    const int a_rows = 92160;
+    const unsigned b_base = (unsigned)a_rows * 1024u;
+    const int shift[7] = {0, 64, 1, -63, -64, -1, 63};
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fl = swz(l31);
+    f32x4 fa[2][TM], fb[2][TN];
+    int ring = 0, iring = NST - 1;
+    auto dma = [&](int slot, int step) {
+        const int tile = (blockIdx.x + (step / 56) * gridDim.x) % (a_rows / BM);
+        const int t = step % 7, kc = (step / 7) % 8;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int row = tile * BM + 8 * (wave + NW * i) + rsub + shift[t];
+            row = row < 0 ? row + a_rows : (row >= a_rows ? row - a_rows : row);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(As + slot * BM * BK + 8 * (wave + NW * i) * BK), 16,
+                                                     (unsigned)row * 1024u + 16u * (pc ^ swz(8 * (wave + NW * i) + rsub)), kc * 128, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(Bs + slot * BN * BK + 8 * (wave + NW * i) * BK), 16,
+                                                     b_base + (unsigned)(t * BN + 8 * (wave + NW * i) + rsub) * 1024u +
+                                                         16u * (pc ^ swz(8 * (wave + NW * i) + rsub)), kc * 128, 0, 0);
+    };
+#pragma unroll
+    for (int q = 0; q < NST - 1; ++q) dma(q, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int step = 0; step < steps; ++step) {
+        const float* a_base = As + ring * BM * BK + (wr * (BM / WR) + l31) * BK;
+        const float* b_base = Bs + ring * BN * BK + (wc * (BN / WC) + l31) * BK;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + 4 * (h ^ fl));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BK + 4 * (h ^ fl));
+        dma(iring, step + NST - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                const int off = 4 * ((2 * (kk + 1) + h) ^ fl);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[(kk + 1) & 1][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + off);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[(kk + 1) & 1][j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BK + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i][s], fb[kk & 1][j][s], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NDMA) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ring = ring == NST - 1 ? 0 : ring + 1;
+        iring = iring == NST - 1 ? 0 : iring + 1;
+    }
+    float sum = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    out[(blockIdx.x * 64 * NW + tid) % (1024 * 256)] = sum;
+#endif
+}
+
+template <int BM, int BN, int WR, int WC>
+void run_w(int blocks_per_cu, const float* src, unsigned src_bytes, float* out) {
+    const int blocks = 256 * blocks_per_cu, steps = 4000 / blocks_per_cu * 8192 / (BM * BN) ;
+    const size_t lds = (size_t)3 * (BM + BN) * BK * 4;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ladder_w<BM, BN, WR, WC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_ladder_w<BM, BN, WR, WC>), dim3(blocks), dim3(64 * WR * WC), lds, 0, src, src_bytes, out, steps, (int)(src_bytes / 1024));
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+    }
+    const double flops = (double)blocks * steps * 2.0 * BM * BN * BK;
+    printf("tile %3dx%-3d  %d waves (%d x %d)  %d block(s)/CU  %.3f ms  %.1f TFLOP/s\n", BM, BN, WR * WC, WR, WC, blocks_per_cu, best, flops / best / 1e9);
+}
+
 // "BK = 64 as two stages": 4 ring slots = 2 double-stages; at the top of a double-step the two stages of the NEXT double-step
 // are issued, both stages are computed, then vmcnt(0) + one barrier -- half the barriers per FLOP, 2 blocks per CU for 64x64.
 template <int BM, int BN>
@@ -276,6 +378,20 @@ int main(int argc, char** argv) {
             run2<64, 128>(1, src, src_bytes, out);          // 96 KB, 1 block / CU
             run<128, 64, 4, 3>(2, src, src_bytes, out);
             run2<128, 64>(1, src, src_bytes, out);
+        }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'w') {   // waves per block at the conv's real traffic
+        for (int rep = 0; rep < 2; ++rep) {
+            run_w<64, 128, 2, 2>(2, src, src_bytes, out);     // production shape
+            run_w<64, 128, 2, 4>(2, src, src_bytes, out);     // 8 waves of 32 x 32
+            run_w<64, 64, 2, 2>(3, src, src_bytes, out);      // production shape
+            run_w<128, 64, 2, 2>(2, src, src_bytes, out);
+            run_w<128, 64, 4, 2>(2, src, src_bytes, out);     // 8 waves of 32 x 32
+            run_w<128, 128, 2, 2>(1, src, src_bytes, out);
+            run_w<128, 128, 2, 4>(1, src, src_bytes, out);    // 8 waves of 64 x 32
+            run_w<128, 128, 4, 4>(1, src, src_bytes, out);    // 16 waves of 32 x 32
+            run_w<128, 256, 2, 4>(1, src, src_bytes, out);    // 144 KB: 8 waves of 64 x 64
         }
         return 0;
     }
