@@ -1624,44 +1624,64 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x,
                                                      const int32_t* __restrict__ idx, float* __restrict__ partial,
                                                      float* __restrict__ bias_partial, int M, int Ps, int Pd, int Cout, int ns,
                                                      int rows_per_block) {
+    // A thread owns 4 output channels (one 16-byte load of dy per row: a wave streams 1 KiB per instruction instead of 256 B)
+    // and every (256 / (Cout / 4))-th row of the 64-pixel group; the gathered inputs come from LDS as broadcasts.
     constexpr int KT = 7 * CIN, NA = KT + 1;           // 7*CIN weight sums + 1 bias sum
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);        // [STEM_PIX][KT]
-    float* red = xs + STEM_PIX * KT;                   // [G][NA][Cout]
-    const int G = 256 / Cout, g = threadIdx.x / Cout, co = threadIdx.x % Cout;
+    f32x4* red = reinterpret_cast<f32x4*>(xs + STEM_PIX * KT);   // [G][NA][Cout / 4]
+    const int q = Cout / 4, G = 256 / q, g = threadIdx.x / q, c4 = threadIdx.x % q;
     const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
-    float acc[NA];
+    f32x4 acc[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+    for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int m0 = mb; m0 < me; m0 += STEM_PIX) {
         __syncthreads();
         stem_gather<CIN>(x, idx, xs, m0, me, Ps, Pd, ns);
         __syncthreads();
         const int nrow = min(STEM_PIX, me - m0);
-        // 4 rows per iteration: their dy loads are independent (the sums stay in ascending row order), so a wave has 4 loads
-        // in flight instead of one -- with a single 256-byte load per wave and iteration the kernel ran at 1.2 TB/s
-        for (int row = g; row < nrow; row += 4 * G) {
-            float dyv[4];
+        // up to 4 rows per thread and group of 64 pixels (G >= 16): all loads issued before the first add, ascending row order
+        f32x4 dyv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dyv[u] = row + u * G < nrow ? dy[(size_t)(m0 + row + u * G) * Cout + co] : 0.f;
+        for (int u = 0; u < 4; ++u) {
+            const int row = g + u * G;
+            dyv[u] = (row < nrow && u * G < STEM_PIX) ? ld4(dy + (size_t)(m0 + row) * Cout + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (row + u * G >= nrow) break;
-                acc[KT] += dyv[u];
+        for (int u = 0; u < 4; ++u) {
+            const int row = g + u * G;
+            if (row >= nrow || u * G >= STEM_PIX) break;
+            acc[KT] += dyv[u];
 #pragma unroll
-                for (int k = 0; k < KT; ++k) acc[k] += dyv[u] * xs[(row + u * G) * KT + k];
-            }
+            for (int k = 0; k < KT; ++k) acc[k] += dyv[u] * xs[row * KT + k];
+        }
+        for (int row = g + 4 * G; row < nrow; row += G) {       // (G < 16: Cout > 64)
+            const f32x4 d = ld4(dy + (size_t)(m0 + row) * Cout + 4 * c4);
+            acc[KT] += d;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) acc[k] += d * xs[row * KT + k];
         }
     }
+    // the row groups of a wave (64 / q of them, q a power of two) are combined with shuffles, the (at most) 4 waves through LDS:
+    // fixed orders, deterministic
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wq = q < 64 ? q : 64;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) red[(g * NA + i) * Cout + co] = acc[i];
+    for (int i = 0; i < NA; ++i)
+        for (int off = wq; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][e] += __shfl_xor(acc[i][e], off, 64);
+    const int nwv = q <= 64 ? 4 : 256 / q;              // partial results per (i, c4): one per wave (q <= 64), else per group
+    if (lane < wq) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) red[((q <= 64 ? wave : g) * NA + i) * q + c4] = acc[i];
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < NA * Cout; i += 256) {
-        float s = 0.f;
-        for (int k = 0; k < G; ++k) s += red[k * NA * Cout + i];
-        const int a = i / Cout, c = i % Cout;
-        if (a < KT) partial[((size_t)blockIdx.x * KT + a) * Cout + c] = s;               // [S][t][ci][co]
-        else if (bias_partial) bias_partial[(size_t)blockIdx.x * Cout + c] = s;
+    for (int i = threadIdx.x; i < NA * q; i += 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nwv; ++k) s += red[k * NA * q + i];
+        const int a = i / q, c = (i % q) * 4;
+        if (a < KT) *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * KT + a) * Cout + c) = s;   // [S][t][ci][co]
+        else if (bias_partial) *reinterpret_cast<f32x4*>(bias_partial + (size_t)blockIdx.x * Cout + c) = s;
     }
 }
 
@@ -1757,7 +1777,7 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
 #undef ICN_WG
     } else if (stem_supported(a.Cin, a.Cout)) {
         const int rows = (a.M + S - 1) / S;
-        const size_t lds = ((size_t)STEM_PIX * 7 * a.Cin + (size_t)(256 / a.Cout) * (7 * a.Cin + 1) * a.Cout) * 4;
+        const size_t lds = ((size_t)STEM_PIX * 7 * a.Cin + (size_t)4 * (7 * a.Cin + 1) * a.Cout) * 4;   // xs + one partial per wave
 #define ICN_SW(C)                                                                                                    \
     hipLaunchKernelGGL((k_stem_wgrad<C>), dim3(S), dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M, \
                        a.Ps, a.Pd, a.Cout, a.ns, rows)
