@@ -112,31 +112,43 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
     }
 }
 
-// sum over chunks of partial[chunk][k][C] for 16 channels per block: 16 slices of the chunk range per channel, combined
-// through LDS in a fixed order (deterministic).  Returns the total in every thread with slice == 0.
-__device__ __forceinline__ double chunk_sum(const float* __restrict__ partial, int chunks, int NS, int k, int C, int c,
-                                            int slice, double (*red)[16]) {
-    // 16 slices x 4 independent float chains per thread (the loads pipeline), combined in double
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+// sums over the chunks of partial[chunk][k0 + q][C], q < NQ, for 16 channels per block: 16 slices of the chunk range per
+// channel, combined through LDS in a fixed order (deterministic).  out[] is valid in the threads with slice == 0.
+// A thread's loads of one round (8 chunks x NQ quantities) are all issued before the first add: 512 chunks are 4 rounds of
+// memory latency (the first version walked them in 8 rounds of 4 loads, one quantity after the other).
+template <int NQ>
+__device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, int chunks, int NS, int k0, int C, int c, int slice,
+                                           double (*red)[16], double* out) {
+    float s[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[q][e] = 0.f;
     if (c < C) {
-        const float* p = partial + (size_t)k * C + c;
+        const float* p = partial + (size_t)k0 * C + c;
         const size_t st = (size_t)NS * C;
-        int j = slice;
-        for (; j + 48 < chunks; j += 64) {
-            s0 += p[(size_t)j * st];
-            s1 += p[(size_t)(j + 16) * st];
-            s2 += p[(size_t)(j + 32) * st];
-            s3 += p[(size_t)(j + 48) * st];
+        for (int j = slice; j < chunks; j += 128) {
+            float v[NQ][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) v[q][u] = j + 16 * u < chunks ? p[(size_t)(j + 16 * u) * st + (size_t)q * C] : 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[q][u & 3] += v[q][u];
         }
-        for (; j < chunks; j += 16) s0 += p[(size_t)j * st];
     }
-    red[slice][threadIdx.x % 16] = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
-    __syncthreads();
-    double t = 0.0;
-    if (slice == 0)
-        for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x % 16];
-    __syncthreads();
-    return t;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        red[slice][threadIdx.x % 16] = ((double)s[q][0] + (double)s[q][1]) + ((double)s[q][2] + (double)s[q][3]);
+        __syncthreads();
+        double t = 0.0;
+        if (slice == 0)
+            for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x % 16];
+        __syncthreads();
+        out[q] = t;
+    }
 }
 
 // forward finalize: mean / invstd of the batch, running statistics (momentum, unbiased variance); 16 channels per block
@@ -146,8 +158,9 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict
                                                           float* __restrict__ stat) {
     __shared__ double red[16][16];
     const int c = blockIdx.x * 16 + threadIdx.x % 16, slice = threadIdx.x / 16;
-    const double s = chunk_sum(partial, chunks, 2, 0, C, c, slice, red);
-    const double s2 = chunk_sum(partial, chunks, 2, 1, C, c, slice, red);
+    double sums[2];
+    chunk_sums<2>(partial, chunks, 2, 0, C, c, slice, red, sums);
+    const double s = sums[0], s2 = sums[1];
     if (slice != 0 || c >= C) return;
     const double ms = s / M;                              // mean of x - x0 (x0 = first row: the shift of k_bn_partial<0>)
     const double mean = (double)x[c] + ms;
@@ -167,7 +180,8 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict
                                                           float* __restrict__ sums) {
     __shared__ double red[16][16];
     const int c = blockIdx.x * 16 + threadIdx.x % 16, slice = threadIdx.x / 16, k = blockIdx.y;
-    const double s = chunk_sum(partial, chunks, NS, k, C, c, slice, red);
+    double s;
+    chunk_sums<1>(partial, chunks, NS, k, C, c, slice, red, &s);
     if (slice == 0 && c < C) sums[k * C + c] = (float)s;
 }
 
