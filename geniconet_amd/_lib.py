@@ -45,6 +45,7 @@ SIGNATURES = {
     'icn_upsample_fwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'icn_upsample_bwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'icn_bn_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),
+    'icn_bn_stats2': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int] + ([ctypes.c_float] * 2 + [_c_float_p] * 3) * 2 + [_c_float_p, ctypes.c_void_p]),
     'icn_bn_stats': (ctypes.c_int, [_c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float] + [_c_float_p] * 4 + [ctypes.c_void_p]),
     'icn_bn_relu_fwd': (ctypes.c_int, [_c_float_p] * 9 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     'icn_bn_relu_bwd': (ctypes.c_int, [_c_float_p] * 13 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),

@@ -1162,7 +1162,7 @@ int icn_adam_step(int count, float* const* params, const float* const* grads, fl
 int icn_set_debug_flags(int flags) { return icn::set_debug_flags(flags); }
 
 // ---- fused BatchNorm + ReLU ---------------------------------------------------------------------------------
-size_t icn_bn_workspace_floats(int M, int C) { return (M < 1 || C < 1) ? 0 : (size_t)icn::bn_chunks(M) * 3 * C; }
+size_t icn_bn_workspace_floats(int M, int C) { return (M < 1 || C < 1) ? 0 : (size_t)icn::bn_chunks(M) * 4 * C; }
 
 int icn_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
                  float* ws, void* stream) {
@@ -1170,6 +1170,23 @@ int icn_bn_stats(const float* x, int M, int C, float eps, float momentum, float*
         if (!x || !stat || !ws || M < 1) throw std::invalid_argument("icn_bn_stats: bad arguments");
         if (!icn::bn_supported(C)) throw std::invalid_argument("icn_bn_stats: unsupported channel count");
         icn::launch_bn_stats(x, M, C, eps, momentum, running_mean, running_var, stat, ws, static_cast<hipStream_t>(stream));
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_bn_stats2(const float* a, const float* b, int M, int C, float eps_a, float momentum_a, float* running_mean_a,
+                  float* running_var_a, float* stat_a, float eps_b, float momentum_b, float* running_mean_b, float* running_var_b,
+                  float* stat_b, float* ws, void* stream) {
+    try {
+        if (!a || !b || !stat_a || !stat_b || !ws || M < 1) throw std::invalid_argument("icn_bn_stats2: bad arguments");
+        if ((running_mean_a == nullptr) != (running_var_a == nullptr) || (running_mean_b == nullptr) != (running_var_b == nullptr))
+            throw std::invalid_argument("icn_bn_stats2: running mean and variance go together");
+        if (!icn::bn_supported(C)) throw std::invalid_argument("icn_bn_stats2: unsupported channel count");
+        icn::launch_bn_stats2(a, b, M, C, eps_a, momentum_a, running_mean_a, running_var_a, stat_a, eps_b, momentum_b, running_mean_b,
+                              running_var_b, stat_b, ws, static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());
         return 0;
     } catch (const std::exception& e) {

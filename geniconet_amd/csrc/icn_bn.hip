@@ -33,6 +33,8 @@ __device__ __forceinline__ f32x4 bn_pre4(f32x4 a, f32x4 mean_a, f32x4 scale_a, f
 //   MODE 0 (forward stats of x):                 k0 = sum (x - x0), k1 = sum (x - x0)^2       x0 = row 0 of x (per channel)
 //          The shift keeps var = E[(x-x0)^2] - E[x-x0]^2 free of cancellation when |mean| >> std (torch uses Welford;
 //          a plain E[x^2] - mean^2 in fp32 loses the variance of e.g. x = 100 + randn).
+//   MODE 3 (forward stats of two tensors a, b in one pass: the two inputs of a residual BatchNorm): k0, k1 as MODE 0 for
+//          p0 = a, k2, k3 the same for p2 = b
 //   MODE 1 (backward of relu(bn(x))):            k0 = sum g,        k1 = sum g * xhat         g = dy * (v > 0)
 //   MODE 2 (backward of relu(bn_a(a)+bn_b(b))):  k0 = sum g,        k1 = sum g * ahat,  k2 = sum g * bhat
 //          v = the pre-activation, RECOMPUTED from a (and b) with the forward's own expression (bn_pre4) instead of reading
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
                                                      const float* __restrict__ ba, const float* __restrict__ gb,
                                                      const float* __restrict__ bb, float* __restrict__ partial, int M, int C,
                                                      int rows_per_chunk) {
-    constexpr int NS = MODE == 2 ? 3 : 2;
+    constexpr int NS = MODE == 3 ? 4 : (MODE == 2 ? 3 : 2);
     __shared__ f32x4 red[NS][256];
     const int c4n = C / 4, stripes = 256 / c4n;
     const int cq = threadIdx.x % c4n, stripe = threadIdx.x / c4n, c = cq * 4;
@@ -59,10 +61,11 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
 #pragma unroll
         for (int k = 0; k < NS; ++k) s[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 mean_a{}, inv_a{}, mean_b{}, inv_b{}, sc_a{}, sc_b{}, be_a{}, be_b{};
-    if (MODE >= 1) { mean_a = ldv(stat_a + c); inv_a = ldv(stat_a + C + c); sc_a = inv_a * ldv(ga + c); be_a = ldv(ba + c); }
+    if (MODE == 1 || MODE == 2) { mean_a = ldv(stat_a + c); inv_a = ldv(stat_a + C + c); sc_a = inv_a * ldv(ga + c); be_a = ldv(ba + c); }
     if (MODE == 2) { mean_b = ldv(stat_b + c); inv_b = ldv(stat_b + C + c); sc_b = inv_b * ldv(gb + c); be_b = ldv(bb + c); }
-    f32x4 shift{};
-    if (MODE == 0) shift = ldv(p0 + c);
+    f32x4 shift{}, shift_b{};
+    if (MODE == 0 || MODE == 3) shift = ldv(p0 + c);
+    if (MODE == 3) shift_b = ldv(p2 + c);
     if (stripe < stripes) {
         for (int r = r0 + stripe; r < r1; r += UN * stripes) {
             f32x4 x0[UN], x2[UN], x3[UN];
@@ -77,10 +80,15 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 if (r + u * stripes >= r1) continue;
-                if (MODE == 0) {
+                if (MODE == 0 || MODE == 3) {
                     const f32x4 x = x0[u] - shift;
                     s[u][0] += x;
                     s[u][1] += x * x;
+                    if (MODE == 3) {
+                        const f32x4 xb = x2[u] - shift_b;
+                        s[u][NS - 2] += xb;
+                        s[u][NS - 1] += xb * xb;
+                    }
                 } else {
                     // p0 = dy, p2 = x / a, p3 = b
                     const f32x4 dy = x0[u], av = x2[u];
@@ -175,6 +183,29 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict
     }
 }
 
+// the same for the two inputs of a residual BatchNorm after a MODE 3 partial pass (4 sums per chunk); blockIdx.y = input
+struct BnFin { const float* x; float eps, momentum; float* running_mean; float* running_var; float* stat; };
+__global__ __launch_bounds__(256) void k_bn_finalize_fwd2(const BnFin fa, const BnFin fb, const float* __restrict__ partial, int chunks,
+                                                           int M, int C) {
+    __shared__ double red[16][16];
+    const BnFin f = blockIdx.y ? fb : fa;
+    const int c = blockIdx.x * 16 + threadIdx.x % 16, slice = threadIdx.x / 16;
+    double sums[2];
+    chunk_sums<2>(partial, chunks, 4, 2 * blockIdx.y, C, c, slice, red, sums);
+    if (slice != 0 || c >= C) return;
+    const double ms = sums[0] / M;
+    const double mean = (double)f.x[c] + ms;
+    double var = sums[1] / M - ms * ms;
+    if (var < 0.0) var = 0.0;
+    f.stat[c] = (float)mean;
+    f.stat[C + c] = (float)(1.0 / sqrt(var + (double)f.eps));
+    if (f.running_mean) {
+        const double unbiased = M > 1 ? var * M / (M - 1) : var;
+        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+    }
+}
+
 // backward finalize: sums[k][C] = sum over chunks (k < NS); blockIdx.y = k
 __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict__ partial, int chunks, int C, int NS,
                                                           float* __restrict__ sums) {
@@ -241,6 +272,15 @@ void launch_bn_stats(const float* x, int M, int C, float eps, float momentum, fl
                        nullptr, ws, M, C, rows);
     hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 15) / 16), dim3(256), 0, s, x, ws, chunks, M, C, eps, momentum, running_mean,
                        running_var, stat);
+}
+
+void launch_bn_stats2(const float* a, const float* b, int M, int C, float eps_a, float mom_a, float* rm_a, float* rv_a, float* stat_a,
+                      float eps_b, float mom_b, float* rm_b, float* rv_b, float* stat_b, float* ws, hipStream_t s) {
+    const int chunks = bn_chunks(M), rows = (M + chunks - 1) / chunks;
+    hipLaunchKernelGGL(k_bn_partial<3>, dim3(chunks), dim3(256), 0, s, a, b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, ws, M, C, rows);
+    hipLaunchKernelGGL(k_bn_finalize_fwd2, dim3((C + 15) / 16, 2), dim3(256), 0, s, BnFin{a, eps_a, mom_a, rm_a, rv_a, stat_a},
+                       BnFin{b, eps_b, mom_b, rm_b, rv_b, stat_b}, ws, chunks, M, C);
 }
 
 void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga, const float* ba,

@@ -128,11 +128,13 @@ struct UpconvPrologueArgs {
 };
 void launch_upconv_prologue(const UpconvPrologueArgs& a, hipStream_t s);
 
-// ---- fused BatchNorm (+ residual) + ReLU (icn_bn.hip); stat = [mean | invstd] (2*C), sums = NS*C, ws = chunks*NS*C floats
+// ---- fused BatchNorm (+ residual) + ReLU (icn_bn.hip); stat = [mean | invstd] (2*C), sums = NS*C, ws = chunks*NS*C floats (NS <= 4)
 bool bn_supported(int C);
 int bn_chunks(int M);
 void launch_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
                      float* ws, hipStream_t s);
+void launch_bn_stats2(const float* a, const float* b, int M, int C, float eps_a, float mom_a, float* rm_a, float* rv_a, float* stat_a,
+                      float eps_b, float mom_b, float* rm_b, float* rv_b, float* stat_b, float* ws, hipStream_t s);   // ws: chunks * 4 * C
 void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga, const float* ba,
                         const float* gb, const float* bb, float* y, int M, int C, hipStream_t s);
 void launch_bn_relu_bwd(const float* dy, const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga,

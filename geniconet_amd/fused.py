@@ -96,11 +96,13 @@ class _BnReluFn(torch.autograd.Function):
         y = torch.empty_like(ap)
         with torch.cuda.device(dev):
             st = _stream()
-            _lib.check(L.icn_bn_stats(ap.data_ptr(), M, C, eps_a, mom_a, rm_a.data_ptr(), rv_a.data_ptr(), stat_a.data_ptr(),
-                                      ws.data_ptr(), st), 'icn_bn_stats')
-            if dual:
-                _lib.check(L.icn_bn_stats(bp.data_ptr(), M, C, eps_b, mom_b, rm_b.data_ptr(), rv_b.data_ptr(),
-                                          stat_b.data_ptr(), ws.data_ptr(), st), 'icn_bn_stats')
+            if dual:      # both inputs' statistics in one pass
+                _lib.check(L.icn_bn_stats2(ap.data_ptr(), bp.data_ptr(), M, C, eps_a, mom_a, rm_a.data_ptr(), rv_a.data_ptr(),
+                                           stat_a.data_ptr(), eps_b, mom_b, rm_b.data_ptr(), rv_b.data_ptr(), stat_b.data_ptr(),
+                                           ws.data_ptr(), st), 'icn_bn_stats2')
+            else:
+                _lib.check(L.icn_bn_stats(ap.data_ptr(), M, C, eps_a, mom_a, rm_a.data_ptr(), rv_a.data_ptr(), stat_a.data_ptr(),
+                                          ws.data_ptr(), st), 'icn_bn_stats')
             _lib.check(L.icn_bn_relu_fwd(ap.data_ptr(), bp.data_ptr() if dual else None, stat_a.data_ptr(),
                                          stat_b.data_ptr() if dual else None, ga.data_ptr(), ba.data_ptr(),
                                          gb.data_ptr() if dual else None, bb.data_ptr() if dual else None, y.data_ptr(), M, C,

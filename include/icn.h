@@ -129,6 +129,11 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
  *                   recomputed from a (, b) and the affine parameters with the forward's own expression, so the saved
  *                   output y is not read (one tensor less to stream in each of the two backward passes).              */
 size_t icn_bn_workspace_floats(int M, int C);
+/* icn_bn_stats2: the statistics of the two inputs of relu(bn_a(a) + bn_b(b)) in one pass (two launches instead of four);
+ * same results as two icn_bn_stats calls. */
+int icn_bn_stats2(const float* a, const float* b, int M, int C, float eps_a, float momentum_a, float* running_mean_a,
+                  float* running_var_a, float* stat_a, float eps_b, float momentum_b, float* running_mean_b, float* running_var_b,
+                  float* stat_b, float* ws, void* stream);
 int icn_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
                  float* ws, void* stream);
 int icn_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* gamma_a,

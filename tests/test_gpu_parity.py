@@ -456,6 +456,35 @@ def test_fused_bn_relu_matches_torch_builtins(C, dual):
     assert not fused.can_fuse(a1, bn_a)
 
 
+def test_bn_stats_of_two_tensors_in_one_pass_equal_two_single_passes():
+    """icn_bn_stats2 (the two inputs of a residual BatchNorm in one partial + one finalize launch) runs the same arithmetic per
+    tensor as icn_bn_stats: statistics and running statistics must be bit-identical."""
+    from geniconet_amd import _lib
+    L = _lib.lib()
+    M, C = 36 * 640 + 13, 128
+    g = torch.Generator().manual_seed(4)
+    a = (torch.randn(M, C, generator=g) * 2 + 3).cuda()
+    b = (torch.randn(M, C, generator=g) * 0.1 - 50).cuda()
+    ws = torch.empty(L.icn_bn_workspace_floats(M, C), device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fresh():
+        return [torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.empty(2 * C, device='cuda')]
+    one_a, one_b, two_a, two_b = fresh(), fresh(), fresh(), fresh()
+    _lib.check(L.icn_bn_stats(a.data_ptr(), M, C, 1e-5, 0.1, one_a[0].data_ptr(), one_a[1].data_ptr(), one_a[2].data_ptr(),
+                              ws.data_ptr(), st), 'icn_bn_stats')
+    _lib.check(L.icn_bn_stats(b.data_ptr(), M, C, 1e-3, 0.2, one_b[0].data_ptr(), one_b[1].data_ptr(), one_b[2].data_ptr(),
+                              ws.data_ptr(), st), 'icn_bn_stats')
+    _lib.check(L.icn_bn_stats2(a.data_ptr(), b.data_ptr(), M, C, 1e-5, 0.1, two_a[0].data_ptr(), two_a[1].data_ptr(),
+                               two_a[2].data_ptr(), 1e-3, 0.2, two_b[0].data_ptr(), two_b[1].data_ptr(), two_b[2].data_ptr(),
+                               ws.data_ptr(), st), 'icn_bn_stats2')
+    for x, y in zip(one_a + one_b, two_a + two_b):
+        assert torch.equal(x, y)
+    ref = torch.nn.functional.batch_norm(b.double().cpu(), None, None, training=True, eps=1e-3)
+    got = (b.double().cpu() - two_b[2][:C].double().cpu()) * two_b[2][C:].double().cpu()
+    assert float((got - ref).abs().max()) < 1e-3          # mean -50, std 0.1: the shifted sums keep the variance
+
+
 def test_fused_head_matches_conv1x1_tanh():
     from geniconet_amd import fused
     torch.manual_seed(4)
