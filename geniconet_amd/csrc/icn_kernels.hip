@@ -1095,6 +1095,9 @@ static void launch_conv_dma_auto(const GatherGemmArgs& a, hipStream_t s) {
         const bool sk = c.bm == 64 && conv_sk_eligible(a) && conv_sk_splits(tiles, (int)slots, a.K / BK / conv_sk_ku(a));
         const double rounds = sk ? (double)tiles / slots : (double)((tiles + slots - 1) / slots);
         double cost = rounds * occ * c.bm * c.bn / (c.eff * occ / c.occ);
+        // stride-2 data gradients (tap masks: tiles of 1-2 taps, unequal lengths) balance better on the finer tile: the
+        // 128 -> 2x256 block's 258 against 281 us (tools/bench_layers.py --model under ICN_TILE = 3 / 2)
+        if (a.mask32 && c.bn == 128) cost *= 1.1;
         if (force && atoi(force) == i) cost = -1;
         if (best < 0 || cost < best_cost) { best = i; best_cost = cost; best_occ = occ; }
     }
