@@ -62,6 +62,7 @@ SIGNATURES = {
     'icn_reparam_fwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_size_t] + [_c_float_p] + [ctypes.c_void_p]),
     'icn_reparam_bwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_size_t] + [_c_float_p] * 2 + [ctypes.c_void_p]),
     'icn_adam_step': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_double] * 4 + [ctypes.c_void_p]),
+    'icn_table_stream_k': (ctypes.c_long, [ctypes.c_int] * 4 + [_i32p, ctypes.c_size_t]),
     'icn_set_debug_flags': (ctypes.c_int, [ctypes.c_int]),
     'icn_point_to_mesh': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [ctypes.c_void_p]),
     'icn_table_conv_fwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t]),
@@ -202,6 +203,17 @@ def table_upconv_bwd(r_in, corner_mode):
     idx, coef = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.float32)
     L.icn_table_upconv_bwd(r_in, m, idx.ctypes.data_as(_i32p), coef.ctypes.data_as(_f32p), n, ctypes.byref(w))
     return idx.reshape(-1, w.value), coef.reshape(-1, w.value)
+
+
+def table_stream_k(ntiles, grid, nk, ku=1):
+    """Stream-K schedule (icn_table_stream_k): int32 array (n, 4) of rows (workgroup, tile, k0, k1) in walk order."""
+    L = lib()
+    n = L.icn_table_stream_k(ntiles, grid, nk, ku, None, 0)
+    if n < 0:
+        check(-1, 'icn_table_stream_k')
+    out = np.empty(n, dtype=np.int32)
+    L.icn_table_stream_k(ntiles, grid, nk, ku, out.ctypes.data_as(_i32p), n)
+    return out.reshape(-1, 4)
 
 
 def profile_start(max_launches=4096, only=None):

@@ -13,6 +13,7 @@
 #include "../../include/icn.h"
 #include "icn_geometry.h"
 #include "icn_launch.h"
+#include "icn_streamk.h"
 
 namespace {
 
@@ -1156,6 +1157,27 @@ int icn_adam_step(int count, float* const* params, const float* const* grads, fl
         return 0;
     } catch (const std::exception& e) {
         return fail(e.what());
+    }
+}
+
+long icn_table_stream_k(int ntiles, int grid, int nk, int ku, int32_t* out, size_t cap) {
+    try {
+        if (ntiles < 1 || grid < 8 || grid % 8 != 0 || nk < 1 || ku < 1 || nk % ku != 0)
+            throw std::invalid_argument("icn_table_stream_k: grid must be a positive multiple of 8, nk a positive multiple of ku");
+        size_t n = 0;
+        for (int b = 0; b < grid; ++b) {
+            icn::SkWalk w{};
+            w.init(b, grid, ntiles, nk, ku);
+            int tile, k0, k1;
+            while (w.next(tile, k0, k1)) {
+                if (out && n + 4 <= cap) { out[n] = b; out[n + 1] = tile; out[n + 2] = k0; out[n + 3] = k1; }
+                n += 4;
+            }
+        }
+        return (long)n;
+    } catch (const std::exception& e) {
+        fail(e.what());
+        return -1;
     }
 }
 

@@ -22,6 +22,7 @@
 #include <utility>
 
 #include "icn_launch.h"
+#include "icn_streamk.h"
 
 namespace icn {
 
@@ -354,24 +355,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned SIDE_FLAG = 0x80000000u;
 constexpr unsigned NOTHING_OFFSET = 0xC0000000u;
 
-// Stream-K plan of one XCD's share of a launch (q_x tiles for GL persistent blocks, nk k-chunks of 7 K-steps per tile).
-// Whole tiles are dealt round-robin as before (local tile indices < dp_l); the last 1 + frac rounds (nsk tiles) are cut into
-// GL equal ranges of k-chunks, so a block's tail is never a mostly idle round.  Host and device use the same function.
-struct SkPlan { int dp_l, nsk; };
-__host__ __device__ inline SkPlan sk_plan(int q_x, int GL, int nk) {
-    const int R = q_x / GL, frac = q_x - R * GL;
-    SkPlan p{q_x, 0};
-    if (frac == 0) return p;                              // whole rounds: nothing to balance
-    if (R >= 1) {                                         // ranges of 1 .. 2 tiles: a tile is shared by at most 3 blocks
-        p.dp_l = (R - 1) * GL;
-        p.nsk = GL + frac;
-    } else if ((long)frac * nk >= 2L * GL && 4 * frac >= GL) {
-        p.dp_l = 0;                                       // fewer tiles than blocks: >= 2 k-chunks per block, <= 5 blocks per tile
-        p.nsk = frac;
-    }
-    return p;
-}
-
 // (body of the two kernels below: k_conv_dma<BM, BN, SEG> and its stream-K form k_conv_dma_sk<BM, BN>)
 template <int BM, int BN, bool SEG, bool SK>   // SEG: class-major rows + virtual taps of a composite table (icn_upconv_*)
 __device__ __forceinline__ void conv_dma_body(
@@ -606,34 +589,9 @@ __device__ __forceinline__ void conv_dma_body(
     // waits for lower block ids of its own launch -- dispatched before it, whatever else shares the GPU -- and those never
     // wait for anything before parking their piece.  (A ticket drawn from an atomic counter instead of blockIdx would not
     // even need in-order dispatch; its round trip at the top of every launch cost half of what stream-K gains.)
-    int sk_round = 0, sk_u0 = 0, sk_pos = 0, sk_dp_l = 0; // DP round; start of the range / walk position (k-chunk units); first split tile
-    long sk_U = 0;                                        // k-chunk units of this XCD's split tiles
-    const int sk_bl = blockIdx.x / 8;                     // rank within the XCD residue class
-    const int sk_x = blockIdx.x % 8, sk_GL = gridDim.x / 8;
-    if constexpr (SK) {
-        const SkPlan pl = sk_plan(ntiles / 8 + (sk_x < ntiles % 8 ? 1 : 0), sk_GL, nk / sk_ku);
-        sk_dp_l = pl.dp_l;
-        sk_U = (long)pl.nsk * (nk / sk_ku);
-        sk_u0 = (int)(sk_U * sk_bl / sk_GL);
-        sk_pos = (int)(sk_U * (sk_bl + 1) / sk_GL);
-    }
-    auto seg_fetch = [&](int& tile_, int& k0_, int& k1_) __attribute__((always_inline)) {
-        const int li = sk_bl + sk_round * sk_GL;
-        if (li < sk_dp_l) {
-            ++sk_round;
-            tile_ = li * 8 + sk_x; k0_ = 0; k1_ = nk;
-            return 1;
-        }
-        if (sk_pos > sk_u0) {
-            const int nku = nk / sk_ku, lt = (sk_pos - 1) / nku;
-            const int u1 = sk_pos - lt * nku, u0 = u1 - min(u1, sk_pos - sk_u0);
-            sk_pos -= u1 - u0;
-            k0_ = u0 * sk_ku; k1_ = u1 * sk_ku;
-            tile_ = (sk_dp_l + lt) * 8 + sk_x;
-            return 1;
-        }
-        return 0;
-    };
+    SkWalk skw{};                                         // (icn_streamk.h; plain ints: stays in scalar registers)
+    if constexpr (SK) skw.init(blockIdx.x, gridDim.x, ntiles, nk, sk_ku);
+    auto seg_fetch = [&](int& tile_, int& k0_, int& k1_) __attribute__((always_inline)) { return skw.next(tile_, k0_, k1_); };
     int tile = blockIdx.x, m0, n0;
     int c_k0 = 0, c_k1 = nk, n_k0 = 0, n_k1 = nk;         // k-chunk range of the compute / next segment (SK; else whole tiles)
     if constexpr (SK) {
@@ -811,7 +769,7 @@ _Pragma("unroll") \
             // the XCD, once per block: measured, that made every launch 10 - 50 % slower.
             constexpr int SYS = 17;                       // cache policy bits of the buffer builtins: sc0 | sc1
             const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc(sk_part, 0, (int)(gridDim.x * (unsigned)(BM * BN * 4)), 0x00020000);
-            const int me = sk_bl * 8 + sk_x;               // this block's slot / flag
+            const int me = blockIdx.x;                     // this block's slot / flag
             if (c_k1 < nk) {                               // a piece that does not reach the tile's end: park it
                 const unsigned base = (unsigned)me * (unsigned)(BM * BN * 4) + tid * 16u;
 #pragma unroll
@@ -829,11 +787,11 @@ _Pragma("unroll") \
                 if (tid == 0) __hip_atomic_store(sk_flag + me, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 sk_store = false;
             } else if (c_k0 > 0) {                         // the tile's last k-chunks: add the earlier blocks' pieces, nearest first
-                const int nku = nk / sk_ku, lt = tile / 8 - sk_dp_l;
-                int pos = lt * nku + c_k0 / sk_ku, nb = sk_bl - 1;   // units [lt * nku, pos) are parked in the slots of blocks nb, nb - 1, ...
+                const int nku = skw.nku, lt = tile / 8 - skw.dp_l;
+                int pos = lt * nku + c_k0 / sk_ku, nb = skw.bl - 1;  // units [lt * nku, pos) are parked in the slots of blocks nb, nb - 1, ...
                 bool sk_lost = false;
                 while (pos > lt * nku) {
-                    const int blk = nb * 8 + sk_x;
+                    const int blk = nb * 8 + skw.x;
                     int spins = 0;
                     while (__hip_atomic_load(sk_flag + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
                         __builtin_amdgcn_s_sleep(8);
@@ -856,7 +814,7 @@ _Pragma("unroll") \
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += v[e];
                             }
-                    pos = max(lt * nku, (int)(sk_U * nb / sk_GL));  // block nb's range starts there
+                    pos = max(lt * nku, skw.range_start(nb));       // block nb's range starts there
                     --nb;
                 }
                 if (sk_lost) {                             // make the failure loud: the tile becomes NaN, and so does the loss

@@ -217,6 +217,10 @@ long icn_table_conv_bwd(int r_in, int stride, int corner_mode, int32_t* out, siz
 long icn_table_upsample(int r_in, int corner_mode, int transpose, int32_t* idx, float* coef, size_t cap, int* width);
 long icn_table_upsample_pairs(int r_in, int32_t* out, size_t cap);                            /* [2][P_fine]   */
 long icn_table_faces(int r, int32_t* out, size_t cap);                                         /* [20*4^r][3]   */
+/* The stream-K schedule of the persistent conv GEMM for a launch of `ntiles` tiles of `nk` k-chunks on `grid`
+ * workgroups, split in units of `ku` k-chunks: rows {workgroup, tile, k0, k1} in each workgroup's walk order.  A row with
+ * k1 < nk is a piece the workgroup parks for the workgroup that holds the tile's last k-chunks (k0 > 0, k1 == nk). */
+long icn_table_stream_k(int ntiles, int grid, int nk, int ku, int32_t* out, size_t cap);
 /* Composite table of conv_stride1(upsample(x)) over the COARSE tensor (icn_upconv_*; csrc/icn_geometry.h UpconvTable):
  * meta[7] = {P_fine, P_coarse, n_slots, E, nseg, NV (virtual taps), number of floats};
  * ints = seg[nseg][3] (rows per sample, first list position, virtual-tap mask) | pix[P_fine] (class-major list of fine
