@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from geniconet_amd import _lib, data, models  # noqa: E402
-from geniconet_amd.train import Trainer  # noqa: E402
+from geniconet_amd.train import Trainer, force_ddp_requested  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
 # algorithmic work per mesh per TRAINING step (SURVEY.md 8d / BASELINE.md): 3 x forward conv FLOPs
@@ -51,6 +51,18 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def cpu_model():
+    """'model name' of /proc/cpuinfo (the CPU baseline states core count and CPU model)."""
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def cpu_baseline(cfg, budget_s=12.0):
@@ -90,7 +102,7 @@ def cpu_baseline(cfg, budget_s=12.0):
                 tr.step(x, t)
             return batch * steps / (time.perf_counter() - t0)
     off, on = timed(False), timed(True)
-    return {'value': round(off, 3), 'unit': 'meshes/s', 'cores': cores, 'kind': 'port',
+    return {'value': round(off, 3), 'unit': 'meshes/s', 'cores': cores, 'cpu_model': cpu_model(), 'kind': 'port',
             'with_anomaly': round(on, 3),
             'sample': '%d timed training steps of batch %d at I%d after 1 warm-up (batch sized for ~%ds of CPU work per mode), '
                       'torch CPU restatement (oracle/), %d threads; value: detect_anomaly off, with_anomaly: on (run.py:237)'
@@ -126,6 +138,15 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ.get('ICN_BENCH_WATCHDOG', 300)), exit=True)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    # ICN_FORCE_DDP=1 at N = 1 (never set by the driver): the production communication path on a one-GPU box -- an RCCL process
+    # group of one rank, DistributedDataParallel around the model exactly as for N > 1, device barriers.  Everything N ranks
+    # would run except the wire.
+    forced = world == 1 and force_ddp_requested() and not rehearsal
+    if forced:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group('nccl', device_id=device, rank=0, world_size=1)
+    group = world > 1 or forced
     if world > 1:
         if rehearsal:
             dist.init_process_group('gloo')
@@ -139,7 +160,7 @@ def main():
     x = x.contiguous(memory_format=torch.channels_last)
 
     def barrier():
-        if world > 1:
+        if group:
             if rehearsal:
                 dist.barrier()
             else:
@@ -171,10 +192,11 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_stop() if dominant else []
     el = torch.tensor([elapsed], device='cpu' if rehearsal else device, dtype=torch.float64)   # gloo: host tensors only
-    if world > 1:
+    if group:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el)
     final_loss = float(loss)
+    _lib.raise_on_device_status(device)      # a kernel-side failure (lost stream-K partner) must not yield a bench line
 
     if rank == 0:
         meshes = cfg['batch'] * world * args.steps
@@ -230,13 +252,14 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'per_gpu_batch': cfg['batch'], 'global_batch': cfg['batch'] * world,
-                       'subdivisions': cfg['R'], 'parallelism': 'dp%d' % world, 'final_loss': final_loss},
+                       'subdivisions': cfg['R'], 'parallelism': 'dp%d' % world + (' (DDP over RCCL forced at world size 1)' if forced else ''),
+                       'final_loss': final_loss},
             'roofline': roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if group:
         dist.destroy_process_group()
 
 

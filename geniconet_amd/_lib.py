@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libicn.so')
+# ICN_LIB_PATH: developer override (tools/asan_host.sh runs the host-side tests against a sanitizer build of the library)
+LIB_PATH = os.environ.get('ICN_LIB_PATH') or os.path.join(_HERE, 'libicn.so')
 
 OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT = 0, 1, 2
 CORNER_MODES = {'zeros': 0, 'average': 1}
@@ -64,6 +65,8 @@ SIGNATURES = {
     'icn_adam_step': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_double] * 4 + [ctypes.c_void_p]),
     'icn_table_stream_k': (ctypes.c_long, [ctypes.c_int] * 4 + [_i32p, ctypes.c_size_t]),
     'icn_set_debug_flags': (ctypes.c_int, [ctypes.c_int]),
+    'icn_device_status': (ctypes.c_int, [ctypes.c_int]),
+    'icn_host_selfcheck': (ctypes.c_long, [ctypes.c_int] * 2),
     'icn_point_to_mesh': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [ctypes.c_void_p]),
     'icn_table_conv_fwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t]),
     'icn_table_conv_bwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t, _intp]),
@@ -111,6 +114,30 @@ def lib():
 def check(rc, what):
     if rc != 0:
         raise RuntimeError('%s failed: %s' % (what, lib().icn_last_error().decode()))
+
+
+STATUS_BITS = {1: "a stream-K workgroup of k_conv_dma_sk never received a partner's partial tile (the tile was set to NaN)"}
+
+
+def device_status(device=None, clear=True, synchronize=True):
+    """Bits of the device's asynchronous failure word (icn_device_status): 0 = no kernel reported a failure."""
+    import torch
+    with torch.cuda.device(device):
+        if synchronize:
+            torch.cuda.synchronize()
+        v = lib().icn_device_status(1 if clear else 0)
+    if v < 0:
+        check(-1, 'icn_device_status')
+    return v
+
+
+def raise_on_device_status(device=None):
+    """Synchronise `device` and raise if a kernel reported a failure since the last check."""
+    v = device_status(device)
+    if v:
+        raise RuntimeError('libicn: asynchronous kernel failure on %s: %s' % (
+            device if device is not None else 'the current device',
+            '; '.join(msg for bit, msg in STATUS_BITS.items() if v & bit) or 'status 0x%x' % v))
 
 
 def corner_code(corner_mode):

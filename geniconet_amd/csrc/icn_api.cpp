@@ -30,10 +30,18 @@ int fail(const std::string& msg) {
         if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// icn_host_selfcheck: build every table on the host and skip the device copy (sanitizer runs of the host code need no GPU)
+thread_local bool g_dry_run = false;
+thread_local size_t g_dry_elems = 0;
+
 template <typename T>
 T* upload(const std::vector<T>& v) {
     T* d = nullptr;
     if (v.empty()) return d;
+    if (g_dry_run) {
+        g_dry_elems += v.size();
+        return d;
+    }
     ICN_HIP(hipMalloc(reinterpret_cast<void**>(&d), v.size() * sizeof(T)));
     ICN_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return d;
@@ -139,13 +147,7 @@ std::map<std::tuple<int, int, int>, UpconvBwdDev> g_upconv_bwd;
 std::map<std::tuple<int, int, int, int>, ConvTables> g_conv;   // (device, r, stride, mode)
 std::map<std::tuple<int, int, int>, UpTables> g_up;            // (device, r, mode)
 
-const ConvTables& conv_tables(int r_in, int stride, int mode) {
-    int dev = 0;
-    ICN_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto key = std::make_tuple(dev, r_in, stride, mode);
-    auto it = g_conv.find(key);
-    if (it != g_conv.end()) return it->second;
+ConvTables make_conv_tables(int r_in, int stride, int mode) {
     ConvTables t;
     t.n_in = 1 << r_in;
     t.n_out = t.n_in / stride;
@@ -186,7 +188,16 @@ const ConvTables& conv_tables(int r_in, int stride, int mode) {
         t.bwd_perm = upload(bwd_p);
         t.d_bwdp = upload_dma(bwd_p, t.E, t.Pin);
     }
-    return g_conv.emplace(key, t).first->second;
+    return t;
+}
+const ConvTables& conv_tables(int r_in, int stride, int mode) {
+    int dev = 0;
+    ICN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(dev, r_in, stride, mode);
+    auto it = g_conv.find(key);
+    if (it != g_conv.end()) return it->second;
+    return g_conv.emplace(key, make_conv_tables(r_in, stride, mode)).first->second;
 }
 
 std::map<std::pair<int, int>, int32_t*> g_vf;                  // (device, r) -> incident-face table of the loss
@@ -203,13 +214,7 @@ const int32_t* vertex_faces(int r) {
     return g_vf.emplace(key, upload(vf)).first->second;
 }
 
-const UpTables& up_tables(int r_in, int mode) {
-    int dev = 0;
-    ICN_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto key = std::make_tuple(dev, r_in, mode);
-    auto it = g_up.find(key);
-    if (it != g_up.end()) return it->second;
+UpTables make_up_tables(int r_in, int mode) {
     icn::Ell f, b;
     icn::build_upsample(r_in, mode, f, b);
     UpTables t;
@@ -221,16 +226,19 @@ const UpTables& up_tables(int r_in, int mode) {
     t.coef_f = upload(f.coef);
     t.idx_b = upload(b.idx);
     t.coef_b = upload(b.coef);
-    return g_up.emplace(key, t).first->second;
+    return t;
 }
-
-const UpconvDev& upconv_tables(int r_in, int mode) {
+const UpTables& up_tables(int r_in, int mode) {
     int dev = 0;
     ICN_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
     auto key = std::make_tuple(dev, r_in, mode);
-    auto it = g_upconv.find(key);
-    if (it != g_upconv.end()) return it->second;
+    auto it = g_up.find(key);
+    if (it != g_up.end()) return it->second;
+    return g_up.emplace(key, make_up_tables(r_in, mode)).first->second;
+}
+
+UpconvDev make_upconv_tables(int r_in, int mode) {
     icn::UpconvTable h;
     icn::build_upconv_fwd(r_in, mode, h);
     UpconvDev d;
@@ -241,16 +249,19 @@ const UpconvDev& upconv_tables(int r_in, int mode) {
     d.slot_idx = upload(h.slot_idx);
     d.alpha = upload(h.alpha);
     d.slot_coef = upload(h.slot_coef);
-    return g_upconv.emplace(key, d).first->second;
+    return d;
 }
-
-const UpconvBwdDev& upconv_bwd_tables(int r_in, int mode) {
+const UpconvDev& upconv_tables(int r_in, int mode) {
     int dev = 0;
     ICN_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
     auto key = std::make_tuple(dev, r_in, mode);
-    auto it = g_upconv_bwd.find(key);
-    if (it != g_upconv_bwd.end()) return it->second;
+    auto it = g_upconv.find(key);
+    if (it != g_upconv.end()) return it->second;
+    return g_upconv.emplace(key, make_upconv_tables(r_in, mode)).first->second;
+}
+
+UpconvBwdDev make_upconv_bwd_tables(int r_in, int mode) {
     icn::Ell e, f;
     icn::build_upconv_bwd(r_in, mode, e);
     icn::build_upconv_scatter(r_in, mode, f);
@@ -331,7 +342,16 @@ const UpconvBwdDev& upconv_bwd_tables(int r_in, int mode) {
     std::vector<int32_t> iota(d.Pc);
     for (int i = 0; i < d.Pc; ++i) iota[i] = i;
     d.iota = upload(iota);
-    return g_upconv_bwd.emplace(key, d).first->second;
+    return d;
+}
+const UpconvBwdDev& upconv_bwd_tables(int r_in, int mode) {
+    int dev = 0;
+    ICN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(dev, r_in, mode);
+    auto it = g_upconv_bwd.find(key);
+    if (it != g_upconv_bwd.end()) return it->second;
+    return g_upconv_bwd.emplace(key, make_upconv_bwd_tables(r_in, mode)).first->second;
 }
 
 // slots of the composite table per level (host only, cached; the larger of the two corner modes)
@@ -1182,6 +1202,56 @@ long icn_table_stream_k(int ntiles, int grid, int nk, int ku, int32_t* out, size
 }
 
 int icn_set_debug_flags(int flags) { return icn::set_debug_flags(flags); }
+
+long icn_host_selfcheck(int r, int corner_mode) {
+    // Every host-side table builder and planner the device paths use at level r, with the device copies skipped: lets the
+    // whole host side of the library run under ASan / UBSan on a machine without a GPU (tools/asan_host.sh).  Returns the
+    // number of table elements that would have been uploaded.
+    try {
+        if (r < 0 || r > 7 || (corner_mode != 0 && corner_mode != 1)) throw std::invalid_argument("icn_host_selfcheck: r in [0, 7], corner_mode 0 / 1");
+        g_dry_run = true;
+        g_dry_elems = 0;
+        struct Reset { ~Reset() { g_dry_run = false; } } reset;
+        (void)make_conv_tables(r, 1, corner_mode);
+        if (r >= 1) (void)make_conv_tables(r, 2, corner_mode);
+        (void)make_up_tables(r, corner_mode);
+        (void)make_upconv_tables(r, corner_mode);
+        (void)make_upconv_bwd_tables(r, corner_mode);
+        std::vector<int32_t> vf;
+        icn::build_vertex_faces(r, vf);
+        (void)upload(vf);
+        (void)table_counts(r, 1);
+        if (r >= 1) (void)table_counts(r, 2);
+        (void)upconv_slots(r);
+        // launch planning of the GEMMs at this level for the model's channel counts and a few batch sizes
+        const int chans[] = {64, 128, 256, 512};
+        size_t plan = 0;
+        for (int B : {1, 3, 36})
+            for (int ci : chans)
+                for (int co : chans) {
+                    for (int stride = 1; stride <= (r >= 1 ? 2 : 1); ++stride) {
+                        for (int op = 0; op < 3; ++op) plan += conv_ws_bytes(op, B, ci, co, 0, r, stride) != 0;
+                        if (pair_supported(B, ci, co, co, r, stride))
+                            for (int op = 0; op < 3; ++op) plan += conv_ws_bytes(op, B, ci, co, co, r, stride) != 0;
+                        const int n_out = (1 << r) / stride, M = B * 10 * n_out * n_out;
+                        plan += (size_t)icn::wgrad_splits(M, ci, co, 0);
+                    }
+                    plan += icn_upconv_workspace_bytes(B, ci, co, co, r) != 0;
+                    plan += icn_upconv_bwd_workspace_bytes(B, ci, co, co, r) != 0;
+                }
+        return (long)(g_dry_elems + plan);
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+int icn_device_status(int clear) {
+    try {
+        return icn::device_status(clear);
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
 
 // ---- fused BatchNorm + ReLU ---------------------------------------------------------------------------------
 size_t icn_bn_workspace_floats(int M, int C) { return (M < 1 || C < 1) ? 0 : (size_t)icn::bn_chunks(M) * 4 * C; }

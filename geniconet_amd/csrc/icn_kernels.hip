@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <type_traits>
 #include <utility>
@@ -302,6 +304,32 @@ int set_debug_flags(int flags) {
     return old;
 }
 static int dbg_flags() { return debug_flags(); }
+
+// Asynchronous failure word of a device: one int in pinned host memory mapped into the device's address space.  A kernel
+// that detects a failure it cannot return (a stream-K finisher whose partner never parked its piece) ORs a bit into it with a
+// system-scope atomic; the host reads it without touching the device (icn_device_status).  Allocated once per device.
+static std::mutex g_status_mu;
+static int* g_status_host[64] = {};
+int* device_status_word() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    if (g_status_host[dev] == nullptr) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+            throw std::runtime_error("icn: cannot allocate the device status word");
+        std::memset(p, 0, 64);
+        g_status_host[dev] = static_cast<int*>(p);
+    }
+    return g_status_host[dev];      // unified addressing: the host pointer of mapped pinned memory is valid on the device
+}
+int device_status(int clear) {
+    int* w = device_status_word();
+    const int v = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+    if (clear && v) __atomic_fetch_and(w, ~v, __ATOMIC_ACQ_REL);
+    return v;
+}
 static int current_device_bit() {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -373,7 +401,9 @@ __device__ __forceinline__ void conv_dma_body(
     const RowSegs segs,
     int sk_ku,                          // SK: k-chunks per unit of the split (1 with 7 taps per k-chunk; 4 for a one-tap launch: >= 4 K-steps)
     float* __restrict__ sk_part,        // SK: one BM x BN partial-accumulator slot per block (raw register layout)
-    int* __restrict__ sk_flag) {        // SK: CONV_SK_FLAGS words zeroed by the prologue: [b] = 1: block b's piece is parked; error word; tickets
+    int* __restrict__ sk_flag,          // SK: CONV_SK_FLAGS words zeroed by the prologue: [b] = 1: block b's piece is parked
+    int* __restrict__ sk_status,        // SK: the device's asynchronous failure word (pinned host memory, icn_device_status)
+    int sk_spin_limit) {                // SK: polls before a partner counts as lost; < 0: fault injection (tests): lost at once
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
     // T taps in wt / dcode (7 hex taps, or the virtual taps of a composite table); a tile runs at most 7 of them (its tap
     // mask), and the LDS offset table is indexed by a tap's RANK inside that mask.
@@ -758,10 +788,10 @@ _Pragma("unroll") \
         }
         bool sk_store = true;
         if constexpr (SK) {
-            // A tile cut in K: the block holding its FIRST k-chunks finishes it (that segment is the last thing the block does,
-            // the other pieces are the first thing later blocks do, so they are long done).  The others park their raw
-            // accumulators in their slot and raise their flag; the finisher adds the slots in block order -- a fixed order,
-            // so the result does not depend on timing.
+            // A tile cut in K: the block holding its LAST k-chunks finishes it (that segment is the last thing the block does,
+            // the other pieces are the first thing LOWER-numbered blocks do after their whole tiles, so they are long done).
+            // The others park their raw accumulators in their slot and raise their flag; the finisher adds the slots in block
+            // order -- a fixed order, so the result does not depend on timing.
             // Slots and flags cross XCDs (one L2 each, not coherent with one another for ordinary accesses): every access to
             // them is a system-scope one (sc0 sc1: written through / fetched past the caches), ordered by hand -- the data
             // stores have completed (vmcnt) on every wave before the flag is raised, the data loads are issued after the
@@ -790,16 +820,25 @@ _Pragma("unroll") \
                 const int nku = skw.nku, lt = tile / 8 - skw.dp_l;
                 int pos = lt * nku + c_k0 / sk_ku, nb = skw.bl - 1;  // units [lt * nku, pos) are parked in the slots of blocks nb, nb - 1, ...
                 bool sk_lost = false;
+                int* const lost_s = reinterpret_cast<int*>(bias_s + (bias ? 3 * BN : 0));   // one LDS word behind the tables
                 while (pos > lt * nku) {
                     const int blk = nb * 8 + skw.x;
-                    int spins = 0;
-                    while (__hip_atomic_load(sk_flag + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++spins > (1 << 22)) {        // seconds: a partner that never arrives is a bug, not a reason to hang the GPU
-                            if (tid == 0) atomicOr(sk_flag + CONV_SK_ERROR, 1);
-                            sk_lost = true;
-                            break;
+                    // Block-uniform wait: ONE lane polls the partner's flag (system scope) and the verdict goes through LDS, so
+                    // every wave takes the same branch (with one counter per thread, waves could disagree on a timeout and leave
+                    // a tile half NaN) and 255 threads' worth of polling traffic is gone.
+                    if (tid == 0) {
+                        int lost = sk_spin_limit < 0, spins = 0;
+                        while (!lost && __hip_atomic_load(sk_flag + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > sk_spin_limit) lost = 1;   // seconds: a partner that never arrives is a bug, not a reason to hang the GPU
                         }
+                        if (lost) __hip_atomic_fetch_or(sk_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        *lost_s = lost;
+                    }
+                    __syncthreads();
+                    if (*lost_s) {
+                        sk_lost = true;
+                        break;
                     }
                     asm volatile("" ::: "memory");
                     const unsigned base = (unsigned)blk * (unsigned)(BM * BN * 4) + tid * 16u;
@@ -816,6 +855,7 @@ _Pragma("unroll") \
                             }
                     pos = max(lt * nku, skw.range_start(nb));       // block nb's range starts there
                     --nb;
+                    __syncthreads();                               // everyone has read lost_s before lane 0 writes it again
                 }
                 if (sk_lost) {                             // make the failure loud: the tile becomes NaN, and so does the loss
 #pragma unroll
@@ -888,7 +928,7 @@ __global__ __launch_bounds__(256) void k_conv_dma(const float* __restrict__ src,
                                                    int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles, int T_arg,
                                                    const RowSegs segs) {
     conv_dma_body<BM, BN, SEG, false>(src, src2, wt, bias, dst, dst2, dcode, side, side2, perm, mask32, M, Ps, Pd, K, N, N0, n_slots,
-                                      src_bytes, side_bytes, ntiles, T_arg, segs, 1, nullptr, nullptr);
+                                      src_bytes, side_bytes, ntiles, T_arg, segs, 1, nullptr, nullptr, nullptr, 0);
 }
 
 // Stream-K form: same tiles, same K-step pipeline; the last 1 + frac rounds of tiles are cut into equal k-chunk ranges (sk_plan),
@@ -903,14 +943,16 @@ __global__ __launch_bounds__(256) void k_conv_dma_sk(const float* __restrict__ s
                                                       const float* __restrict__ side2, const int32_t* __restrict__ perm, int M, int Ps,
                                                       int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes,
                                                       unsigned side_bytes, int ntiles, int T_arg, const RowSegs segs, int sk_ku,
-                                                      float* __restrict__ sk_part, int* __restrict__ sk_flag) {
+                                                      float* __restrict__ sk_part, int* __restrict__ sk_flag,
+                                                      int* __restrict__ sk_status, int sk_spin_limit) {
     conv_dma_body<BM, BN, SEG, true>(src, src2, wt, bias, dst, dst2, dcode, side, side2, SEG ? perm : nullptr, nullptr, M, Ps, Pd, K, N, N0, n_slots,
-                                     src_bytes, side_bytes, ntiles, T_arg, segs, sk_ku, sk_part, sk_flag);
+                                     src_bytes, side_bytes, ntiles, T_arg, segs, sk_ku, sk_part, sk_flag, sk_status, sk_spin_limit);
 }
 
 // dynamic LDS of k_conv_dma: A/B rings, offset table, destination-row table (row permutation only), bias (bias only)
 static size_t conv_dma_lds(int bm, int bn, bool perm, bool bias) {
-    return (size_t)3 * (bm + bn) * BK * 4 + (size_t)2 * 7 * bm * 4 + (perm ? (size_t)3 * bm * 4 : 0) + (bias ? (size_t)3 * bn * 4 : 0);
+    return (size_t)3 * (bm + bn) * BK * 4 + (size_t)2 * 7 * bm * 4 + (perm ? (size_t)3 * bm * 4 : 0) + (bias ? (size_t)3 * bn * 4 : 0) +
+           16;   // + the stream-K form's block-uniform "partner lost" word
 }
 
 template <int BM, int BN, bool SEG>
@@ -974,7 +1016,7 @@ static void launch_conv_dma_sk_t(const GatherGemmArgs& a, int occ, hipStream_t s
     hipLaunchKernelGGL((k_conv_dma_sk<BM, BN, SEG>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,
                        a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.M, a.Ps, a.Pd, a.K,
                        a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs, conv_sk_ku(a),
-                       a.sk_part, a.sk_flag);
+                       a.sk_part, a.sk_flag, device_status_word(), (dbg_flags() & 256) ? -1 : (1 << 22));
     prof_mark_end(s);
 }
 

@@ -44,8 +44,12 @@ struct GatherGemmArgs {
     float* sk_part;         // stream-K scratch: conv_sk_part_bytes() bytes, or null (no stream-K)
     int* sk_flag;           // CONV_SK_FLAGS ints zeroed before the launch (PrologueArgs::zero), with sk_part
 };
-constexpr int CONV_SK_ERROR = 1024;                        // flag words: [0, 1024) one per block, then the error word
+constexpr int CONV_SK_ERROR = 1024;                        // flag words: [0, 1024) one per block (the grid's upper bound)
 constexpr int CONV_SK_FLAGS = 1032;
+// The device's asynchronous failure word (pinned host memory mapped to the device; bit 0: a stream-K partner never arrived)
+// and its host-side read (clear != 0: reset the bits returned).  icn_device_status in include/icn.h.
+int* device_status_word();
+int device_status(int clear);
 size_t conv_sk_part_bytes();                               // partial-tile slots of the largest stream-K grid
 
 
@@ -170,7 +174,8 @@ void launch_reparam_bwd(const float* dz, const float* logvar, const float* eps, 
 void launch_point_to_mesh(const float* pts, const float* vts, const int32_t* faces, int B, int P, int V, int F, float* dist,
                           int32_t* face, int32_t* kind, hipStream_t s);
 
-// developer routing flags (ICN_DEBUG / icn_set_debug_flags): 16 = convs on k_gather_gemm, 32 = wgrads on k_wgrad
+// developer routing flags (ICN_DEBUG / icn_set_debug_flags): 16 = convs on k_gather_gemm, 32 = wgrads on k_wgrad,
+// 128 = no stream-K, 256 = fault injection: every stream-K finisher reports its partners lost (tests of the failure path)
 int debug_flags();
 int set_debug_flags(int flags);
 

@@ -68,12 +68,23 @@ def _torch_point_to_mesh(points, vertices, faces, chunk=256):
     return best, face, kind
 
 
+_MAX_GRID_Y = 65535
+
+
 def point_to_mesh_distance(pointclouds, vertices, faces):
     """See the module docstring.  `faces` may be int32 / int64, (F, 3), shared by the batch (as in kaolin 0.9.1)."""
     if pointclouds.dim() != 3 or vertices.dim() != 3 or pointclouds.shape[-1] != 3 or vertices.shape[-1] != 3:
         raise ValueError('point_to_mesh_distance: expected (B, P, 3) points and (B, V, 3) vertices')
     if pointclouds.shape[0] != vertices.shape[0] or faces.dim() != 2 or faces.shape[1] != 3:
         raise ValueError('point_to_mesh_distance: batch sizes differ or faces is not (F, 3)')
+    if faces.shape[0] > 0:
+        # the kernel indexes vertices[b, faces[f]] unchecked: a 1-based or mismatched face list (an OFF file read with the
+        # wrong vertex set) must fail here like kaolin's / torch's IndexError, not as a device memory fault.  One host sync;
+        # this is a test-time metric (ico_utils.py:26-44).
+        lo, hi = int(faces.min()), int(faces.max())
+        if lo < 0 or hi >= vertices.shape[1]:
+            raise IndexError('point_to_mesh_distance: face indices span [%d, %d] but there are %d vertices'
+                             % (lo, hi, vertices.shape[1]))
     if pointclouds.is_cuda and pointclouds.dtype == torch.float32 and vertices.dtype == torch.float32 and faces.shape[0] > 0:
         L = _lib.lib()
         B, P, _ = pointclouds.shape
@@ -83,9 +94,12 @@ def point_to_mesh_distance(pointclouds, vertices, faces):
         face = torch.empty(B, P, dtype=torch.int32, device=pts.device)
         kind = torch.empty(B, P, dtype=torch.int32, device=pts.device)
         with torch.cuda.device(pts.device):
-            rc = L.icn_point_to_mesh(pts.data_ptr(), vts.data_ptr(), f32.data_ptr(), B, P, vertices.shape[1], faces.shape[0],
-                                     dist.data_ptr(), face.data_ptr(), kind.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, 'icn_point_to_mesh')
+            for b0 in range(0, B, _MAX_GRID_Y):                  # the batch index is gridDim.y (<= 65535 per launch)
+                nb = min(_MAX_GRID_Y, B - b0)
+                rc = L.icn_point_to_mesh(pts[b0:].data_ptr(), vts[b0:].data_ptr(), f32.data_ptr(), nb, P, vertices.shape[1],
+                                         faces.shape[0], dist[b0:].data_ptr(), face[b0:].data_ptr(), kind[b0:].data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
+                _lib.check(rc, 'icn_point_to_mesh')
         return dist, face.long(), kind
     return _torch_point_to_mesh(pointclouds, vertices, faces.to(pointclouds.device))
 

@@ -40,13 +40,17 @@ class Adam(torch.optim.Adam):
 
     @torch.no_grad()
     def step(self, closure=None):
-        groups = self._hip_groups()
-        if groups is None:
-            return super().step(closure)
+        # the closure first, as torch.optim.Adam.step does: eligibility and the list of parameters with gradients must come
+        # from the gradients the closure leaves behind (zero_grad(set_to_none=True) + backward inside it), not from the ones
+        # that existed before it ran
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        groups = self._hip_groups()
+        if groups is None:
+            super().step()                    # the closure has run: not passed on
+            return loss
         L = _lib.lib()
         for group, ps in groups:
             if not ps:

@@ -12,6 +12,9 @@ the names and from how the results are used; each docstring cites the call site.
 or  python tools/run_reference.py /path/to/GenIcoNet --model ico2ico --process train --quickLearn 8 ...
 """
 import importlib
+import importlib.abc
+import importlib.util
+import logging
 import os
 import sys
 import types
@@ -45,12 +48,40 @@ class SummaryWriter:
         pass
 
 
+SHIM_MODULES = ('natsort', 'kaolin', 'mesh', 'python_utils', 'torch_utils', 'torchsummary')
+ACTIVE = []          # top-level stand-ins that were actually served (a real package of the same name wins, see _ShimFinder)
+
+
+class _ShimFinder(importlib.abc.MetaPathFinder):
+    """Serves a stand-in from this directory ONLY when the ordinary import machinery has failed to find the module: it sits
+    at the END of sys.meta_path, behind the path-based finder, so a real installed `natsort` / `kaolin`, or a real
+    PythonFunctions checkout that the reference appended to sys.path (run.py:22-23), is imported instead of being shadowed
+    by a stand-in with different metrics or conventions.  Every stand-in that is used is recorded in ACTIVE and logged."""
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname not in SHIM_MODULES:
+            return None                                   # submodules of a served package are found through its __path__
+        pkg = os.path.join(_HERE, fullname, '__init__.py')
+        if os.path.exists(pkg):
+            spec = importlib.util.spec_from_file_location(fullname, pkg, submodule_search_locations=[os.path.dirname(pkg)])
+        else:
+            spec = importlib.util.spec_from_file_location(fullname, os.path.join(_HERE, fullname + '.py'))
+        if spec is not None and fullname not in ACTIVE:
+            ACTIVE.append(fullname)
+            logging.getLogger('geniconet_amd.shims').warning(
+                'using the stand-in for %r from %s (no real module of that name is importable)', fullname, _HERE)
+        return spec
+
+
 def install(tensorboard_stub=None):
-    """Put the shim modules and the repo root (the `icocnn` drop-in) in front of sys.path; register the tensorboard stand-in
-    when `torch.utils.tensorboard` cannot be imported (tensorboard_stub=True forces it, False forbids it).  Idempotent."""
-    for p in (_HERE, _ROOT):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+    """Put the repo root (the `icocnn` drop-in) in front of sys.path and register the stand-ins as a LAST-RESORT finder (a
+    real package of the same name is preferred, geniconet_amd.shims.ACTIVE lists the stand-ins in use); register the
+    tensorboard stand-in when `torch.utils.tensorboard` cannot be imported (tensorboard_stub=True forces it, False forbids
+    it).  Idempotent."""
+    if _ROOT not in sys.path:
+        sys.path.insert(0, _ROOT)
+    if not any(isinstance(f, _ShimFinder) for f in sys.meta_path):
+        sys.meta_path.append(_ShimFinder())
     import numpy as np
     if 'Inf' not in np.__dict__:                       # run.py:342,433,459 use np.Inf, which NumPy 2.0 removed
         np.Inf = np.inf

@@ -23,6 +23,15 @@ from . import losses, models, optim
 GRAD_BUCKET_MB = 5   # ~4 buckets for the 18.5 MB (AE) / 24 MB (VAE) of fp32 gradients, decoder first
 
 
+def force_ddp_requested():
+    """ICN_FORCE_DDP=1: wrap the model in DistributedDataParallel whenever a process group exists, also at world size 1.
+    With backend 'nccl' (= RCCL) that runs everything N ranks would run except the wire -- communicator creation, DDP's
+    reducer over the custom autograd Functions with gradient_as_bucket_view, the bucket all-reduce kernels queued on RCCL's
+    stream beside the persistent conv kernels -- which is how the production communication path is exercised on a one-GPU
+    box (bench.py, tests/test_gpu_ddp_nccl.py)."""
+    return os.environ.get('ICN_FORCE_DDP', '') == '1'
+
+
 def _host_staged_allreduce_hook(world):
     """DDP communication hook for the one-GPU REHEARSAL only (several ranks share a device and talk over gloo, which has
     no RCCL): a bucket is copied to pinned host memory, averaged by gloo's CPU all-reduce and copied back.  gloo's own
@@ -70,8 +79,11 @@ def build_criterion(params, device):
 
 
 class Trainer:
-    def __init__(self, params, device, model=None, criterion=None, seed=0, anomaly=False, channels_last=True):
+    def __init__(self, params, device, model=None, criterion=None, seed=0, anomaly=False, channels_last=True, force_ddp=None,
+                 check_device_status=None):
         self.params, self.device, self.anomaly = params, torch.device(device), anomaly
+        # debug mode: after every step, synchronise and raise if a kernel reported a failure (icn_device_status)
+        self.check_device_status = (os.environ.get('ICN_CHECK', '') == '1') if check_device_status is None else check_device_status
         cfg = params[params['model_name']]
         torch.manual_seed(seed)
         self.model = model if model is not None else build_model(params, self.device)
@@ -82,7 +94,9 @@ class Trainer:
         self.criterion = criterion if criterion is not None else build_criterion(params, self.device)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.net = self.model
-        if self.world > 1:
+        if force_ddp is None:
+            force_ddp = force_ddp_requested()
+        if self.world > 1 or (force_ddp and dist.is_available() and dist.is_initialized()):
             ids = [self.device.index] if self.device.type == 'cuda' else None
             # rehearsal on one GPU: ranks share a device over gloo -> stage every exchange through the host
             staged = self.device.type == 'cuda' and dist.get_backend() == 'gloo'
@@ -123,6 +137,9 @@ class Trainer:
             self.optimizer.step()
             if self.scheduler is not None:
                 self.scheduler.step()
+        if self.check_device_status and self.device.type == 'cuda':
+            from . import _lib
+            _lib.raise_on_device_status(self.device)
         return loss.detach()
 
     @torch.no_grad()

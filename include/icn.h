@@ -250,8 +250,25 @@ int icn_profile_select(const char* kernel);
 
 /* Developer routing flags (same bits as the ICN_DEBUG environment variable, which only sets the initial value):
  * 16 = convolutions on the register-staged fallback kernel, 32 = weight gradients on it, 128 = no stream-K (every tile of
- * the persistent GEMM computed whole by one workgroup).  Returns the previous flags. */
+ * the persistent GEMM computed whole by one workgroup), 256 = fault injection for the tests of the failure path below (every
+ * stream-K finisher reports its partners lost).  Returns the previous flags. */
 int icn_set_debug_flags(int flags);
+
+/* Asynchronous failures of the CURRENT device.  Kernels cannot return an error code; the one failure they can detect --
+ * a workgroup of the stream-K GEMM whose partner never parked its partial tile within about a second -- turns the tile into
+ * NaNs and sets bit 0 (ICN_STATUS_STREAMK_LOST) of a per-device word in pinned host memory.  This call returns the bits set
+ * since they were last cleared (>= 0) and clears them when `clear` is non-zero; -1 on error (icn_last_error).  It does not
+ * synchronise: call it after the stream (or device) has been synchronised.  The reference has no counterpart (it checks
+ * nothing but NaNs through torch.autograd.detect_anomaly, run.py:237); geniconet_amd.train.Trainer calls it once per step in
+ * debug mode (ICN_CHECK=1) and bench.py once after the timed region. */
+/* Host-only self check: runs every host-side table builder and launch planner of level r (conv stride 1 / 2, upsample,
+ * composite upsample + conv tables, loss tables, workspace layouts for the model's channel counts) WITHOUT copying anything
+ * to a device, so the host side of the library can be exercised under ASan / UBSan on a machine without a GPU
+ * (tools/asan_host.sh).  Returns a positive element count, -1 on error. */
+long icn_host_selfcheck(int r, int corner_mode);
+
+#define ICN_STATUS_STREAMK_LOST 1
+int icn_device_status(int clear);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,93 @@
+"""The PRODUCTION communication path on the one GPU a test box has: an RCCL (backend 'nccl') process group of world size 1,
+DistributedDataParallel around the product model exactly as geniconet_amd/train.py builds it for N > 1 (no comm hook,
+init_sync, gradient_as_bucket_view, 5 MB buckets), device barriers, destroy_process_group.  World size 1 over RCCL runs
+everything N ranks would run except the wire: communicator creation, DDP's reducer over the pair / upconv / BN / head /
+loss autograd Functions with bucket-view gradients feeding icn_adam_step, and the bucket all-reduce kernels queued on
+RCCL's stream while the persistent, spin-waiting stream-K conv kernels own every CU.
+
+Checked: gradients and the weights / BatchNorm statistics after 3 optimiser + scheduler steps are BIT-IDENTICAL to the
+trainer without DDP (a one-rank sum followed by a division by 1 must change nothing), at a small size and at the
+BASELINE configs[1] size (I5, 36 meshes).  The worker is a freshly started interpreter (spawn): the process group is
+created before anything else touches the GPU.  2 processes use the GPU (pytest + 1 worker)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, port, out_path):
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(420, exit=True)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    device = torch.device('cuda', 0)
+    dist.init_process_group('nccl', device_id=device, rank=0, world_size=1)     # RCCL communicator, as bench.py creates it
+    from geniconet_amd import _lib, data, models
+    from geniconet_amd.train import Trainer
+    report = {'backend': dist.get_backend(), 'cases': []}
+    for name, R, B in (('ico2ico', 3, 3), ('ico2ico_vae', 3, 2), ('ico2ico', 5, 36)):
+        p = models.default_params(name, subdivisions=R)
+        p[name].update(lr=1e-4, lr_base=1e-4, lr_max=1e-3)
+        plain = Trainer(p, device, seed=11, force_ddp=False)
+        ddp = Trainer(p, device, seed=12, force_ddp=True)        # other initial weights: DDP is built first, then aligned
+        assert isinstance(ddp.net, torch.nn.parallel.DistributedDataParallel) and plain.net is plain.model
+        ddp.model.load_state_dict(plain.model.state_dict())
+        x, t = data.synthetic_batch(B, R, seed=77, device=device)
+        x = x.contiguous(memory_format=torch.channels_last)
+        case = {'name': name, 'R': R, 'B': B, 'grad_mismatch': [], 'weight_mismatch': [], 'bucket_views': 0}
+        # one backward: the gradient every parameter ends up with
+        for tr in (plain, ddp):
+            torch.manual_seed(5)                                # the VAE draws its noise from the default generator
+            tr.optimizer.zero_grad()
+            tr.criterion(tr.net(x), t).backward()
+        gp = dict(plain.model.named_parameters())
+        for k, q in ddp.model.named_parameters():
+            if q.grad is None or gp[k].grad is None or not torch.equal(q.grad, gp[k].grad):
+                case['grad_mismatch'].append(k)
+        # after the first backward DDP has re-pointed .grad at views of its buckets (gradient_as_bucket_view)
+        case['params'] = len(gp)
+        # three full steps (the weights moved above by nothing: no optimiser step yet; BN statistics moved equally on both)
+        for step in range(3):
+            for tr in (plain, ddp):
+                torch.manual_seed(100 + step)
+                loss = tr.step(x, t)
+            dist.barrier(device_ids=[0])
+        sp, sd = plain.model.state_dict(), ddp.model.state_dict()
+        for k in sp:
+            if not torch.equal(sp[k], sd[k]):
+                case['weight_mismatch'].append(k)
+        case['finite'] = bool(torch.isfinite(loss))
+        case['status'] = _lib.device_status(device)
+        report['cases'].append(case)
+        del plain, ddp
+    dist.barrier(device_ids=[0])
+    dist.destroy_process_group()
+    torch.save(report, out_path)
+
+
+@pytest.mark.timeout(900)
+def test_ddp_over_rccl_at_world_size_one_is_bit_identical_to_the_plain_trainer(tmp_path):
+    out = str(tmp_path / 'report.pt')
+    mp.spawn(_worker, args=(_free_port(), out), nprocs=1, join=True)
+    rep = torch.load(out)
+    assert rep['backend'] == 'nccl'
+    assert [c['name'] for c in rep['cases']] == ['ico2ico', 'ico2ico_vae', 'ico2ico']
+    for c in rep['cases']:
+        assert c['grad_mismatch'] == [], (c['name'], c['R'], c['grad_mismatch'][:5])
+        assert c['weight_mismatch'] == [], (c['name'], c['R'], c['weight_mismatch'][:5])
+        assert c['finite'] and c['status'] == 0, c

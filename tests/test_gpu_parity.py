@@ -270,6 +270,35 @@ def test_stream_k_in_the_decoder_heads_dense_gemms(r, cin, cout, B):
     assert any(k.startswith('k_conv_dma_sk') and k.endswith('true>') for k in seen), seen
 
 
+def test_a_lost_stream_k_partner_is_loud():
+    """The failure path of the stream-K GEMM, by fault injection (debug flag 256: every finisher reports its partners lost):
+    the tile becomes NaN AND the device's asynchronous status word is set, which icn_device_status returns (and clears) and
+    geniconet_amd._lib.raise_on_device_status / Trainer(check_device_status=True) / bench.py turn into an exception.  Before
+    this the only trace of such a failure was NaNs in the output."""
+    from geniconet_amd import _lib
+    from geniconet_amd.ico_conv import ico_conv
+    r, cin, cout, B = SK_CASES[0][:4]
+    n = 2 ** r
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, cin, 5 * n, 2 * n, generator=g).cuda()
+    w = (torch.randn(cout, cin, 7, generator=g) / (7 * cin) ** 0.5).cuda()
+    assert _lib.device_status() == 0
+    y_ok = ico_conv(x, w, None, r, 1, 'average')
+    assert _lib.device_status() == 0 and bool(torch.isfinite(y_ok).all())
+    old = _lib.lib().icn_set_debug_flags(256)
+    try:
+        y_bad = ico_conv(x, w, None, r, 1, 'average')
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().icn_set_debug_flags(old)
+    assert bool(torch.isnan(y_bad).any())
+    with pytest.raises(RuntimeError, match='stream-K'):
+        _lib.raise_on_device_status()
+    assert _lib.device_status() == 0                          # reading cleared it
+    y_again = ico_conv(x, w, None, r, 1, 'average')           # and the next launch is healthy
+    assert torch.equal(y_again, y_ok) and _lib.device_status() == 0
+
+
 def test_conv_without_bias_and_noncontiguous_input():
     from geniconet_amd.ico_conv import ico_conv
     for k, (got, want) in conv_both(2, 1, 64, 64, 2, 'average', seed=5, bias=False).items():

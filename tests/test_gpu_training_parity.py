@@ -31,64 +31,179 @@ def _zero_true_gradient(key):
 
 
 # ---- (a) training trajectory: reference run.py:244-254 over several batches -------------------------------------------------
+def _fixed_noise(monkeypatch, R, B, steps):
+    """The same reparameterisation noise on both sides: the product draws it with torch.randn_like as the reference does
+    (models.py:91); every (device, step) pair gets the step's tensor."""
+    n = 2 ** (R - 3)
+    noise = [torch.randn(B, 512, 5 * n, 2 * n, generator=torch.Generator().manual_seed(70 + k)) for k in range(steps)]
+    draws = {'cuda': 0, 'cpu': 0}
+
+    def fixed_randn_like(t, **kw):
+        k = draws[t.device.type]
+        draws[t.device.type] += 1
+        return noise[k % steps].to(t.device)
+    monkeypatch.setattr(torch, 'randn_like', fixed_randn_like)
+
+
+def _ulp(t):
+    """Spacing of fp32 numbers at |t| (elementwise)."""
+    return torch.from_numpy(np.spacing(np.abs(t.numpy()).astype(np.float32)))
+
+
 @pytest.mark.parametrize('name', ['ico2ico', 'ico2ico_vae'])
-def test_training_trajectory_matches_the_oracle_trainer(name, monkeypatch):
-    """Product Trainer on the GPU vs the same Trainer class driving the oracle network on the CPU, from one state_dict:
-    forward -> loss -> zero_grad -> backward -> Adam -> CyclicLR for 3 batches (a different batch each step).
-    Bounds: loss 1e-4 relative at the first step (identical weights), 1e-3 after; the weight UPDATE w - w_init of every tensor with a non-zero true gradient 0.15
-    rel-L2 -- Adam divides by sqrt(v), so an element whose gradient is at rounding-noise level (whole-network gradients agree
-    to ~1e-3) moves by a full +-lr on either side: 0.1 % of such elements already give 0.06, and the two trajectories then
-    drift apart at that level -- hence also 5e-3 rel-L2 on the BatchNorm running statistics after three steps (the statistics
-    of a single step from identical weights are held to 1e-4 in test_gpu_parity.py)."""
+def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypatch):
+    """Product Trainer on the GPU against the same Trainer class driving the oracle network on the CPU, TEACHER-FORCED: before
+    every step the GPU side receives the CPU trainer's weights, BatchNorm statistics and Adam state, so each step is compared
+    from identical state and nothing is amplified from step to step (Adam's first steps are ~ lr * sign(g): free-running
+    trajectories drift apart at rounding-noise-level gradient elements, which is why the earlier free-running form of this
+    test needed a 15 % bound and a list of exempt tensors).  Per step k = 0..3, a different batch each:
+      1. forward + loss + backward on both sides: loss to 1e-4 relative, every parameter gradient to 2e-3 rel-L2 (denominators
+         floored at 1e-3 of the largest gradient norm: conv biases in front of a train-mode BatchNorm have a zero true
+         gradient), BatchNorm running statistics to 1e-4;
+      2. the CPU gradients are copied into the GPU parameters' .grad, and Adam + CyclicLR step on both sides from IDENTICAL
+         gradients, moments, step counts and learning rate.  The HIP Adam (icn_adam_step) must then reproduce torch's update on
+         EVERY tensor, no exemptions: exp_avg and exp_avg_sq to 1e-6 rel-L2, every weight element within 2 ulp of the CPU
+         result (fp32 weights quantise an update of size lr at ulp(w) / lr ~ 1e-5, so ulps of w -- not a relative bound on the
+         update -- are the sharp statement), and, against a float64 evaluation of Adam's formula, the applied update to 1e-4
+         rel-L2 of the update itself (a wrong bias correction, a stale moment or a skipped tensor is off by >= 1e-1 there)."""
     from geniconet_amd import data, models
     from geniconet_amd.train import Trainer, build_criterion
-    R, B, STEPS = 3, 3, 3
+    R, B, STEPS = 3, 3, 4
     p = models.default_params(name, subdivisions=R)
-    p[name].update(lr=1e-4, lr_base=1e-4, lr_max=1e-3)          # the reference's 1e-9 .. 1e-3 cycle moves nothing in 3 steps
+    p[name].update(lr=1e-4, lr_base=1e-4, lr_max=1e-3)          # the reference's 1e-9 .. 1e-3 cycle moves nothing in 4 steps
     torch.manual_seed(5)
     ref = getattr(models_ref, name)(R=R).train()
-    init = copy.deepcopy(ref.state_dict())
     gpu = Trainer(p, 'cuda', model=_product(ref, name, R))
     cpu = Trainer(p, 'cpu', model=ref, criterion=build_criterion(p, 'cpu'), channels_last=False)
+    assert type(gpu.optimizer).__module__ == 'geniconet_amd.optim'
     if name == 'ico2ico_vae':
-        # the same noise on both sides: the product draws it with torch.randn_like (as the reference does, models.py:91)
-        n = 2 ** (R - 3)
-        noise = [torch.randn(B, 512, 5 * n, 2 * n, generator=torch.Generator().manual_seed(70 + k)) for k in range(STEPS)]
-        draws = {'cuda': 0, 'cpu': 0}
-
-        def fixed_randn_like(t, **kw):
-            k = draws[t.device.type]
-            draws[t.device.type] += 1
-            return noise[k].to(t.device)
-        monkeypatch.setattr(torch, 'randn_like', fixed_randn_like)
+        _fixed_noise(monkeypatch, R, B, STEPS)
+    names = [k for k, _ in cpu.model.named_parameters()]
+    pg, pc = dict(gpu.model.named_parameters()), dict(cpu.model.named_parameters())
     for k in range(STEPS):
+        # -- teacher forcing: CPU state -> GPU (weights + BN buffers, Adam moments and step counts, scheduler position)
+        gpu.model.load_state_dict(cpu.model.state_dict())
+        if k > 0:
+            for key in names:
+                sc, sg = cpu.optimizer.state[pc[key]], gpu.optimizer.state[pg[key]]
+                sg['exp_avg'].copy_(sc['exp_avg'])
+                sg['exp_avg_sq'].copy_(sc['exp_avg_sq'])
+                sg['step'].copy_(sc['step'])
+        assert abs(gpu.optimizer.param_groups[0]['lr'] - cpu.optimizer.param_groups[0]['lr']) < 1e-15
+        x, t = data.synthetic_batch(B, R, seed=40 + k)
+        # -- 1. forward, loss, backward (run.py:244-250)
+        outs = {}
+        for tr, xx, tt in ((gpu, x.cuda().contiguous(memory_format=torch.channels_last), t.cuda()), (cpu, x, t)):
+            tr.optimizer.zero_grad()
+            loss = tr.criterion(tr.net(xx), tt)
+            loss.backward()
+            outs[tr.device.type] = float(loss)
+        assert abs(outs['cuda'] - outs['cpu']) <= 1e-4 * abs(outs['cpu']), (k, outs)
+        floor = 1e-3 * max(float(q.grad.norm()) for q in pc.values())
+        for key in names:
+            err = float((pg[key].grad.cpu() - pc[key].grad).norm()) / max(float(pc[key].grad.norm()), floor)
+            assert err < 2e-3, (k, key, err)
+        sg, sc = gpu.model.state_dict(), cpu.model.state_dict()
+        for key in sc:
+            if 'num_batches_tracked' in key:
+                assert int(sg[key]) == int(sc[key]) == k + 1, key
+            elif 'running' in key:
+                assert rel_l2(sg[key].cpu().numpy(), sc[key].numpy()) < 1e-4, (k, key)
+        # -- 2. identical gradients in, Adam + CyclicLR on both sides (run.py:251-254)
+        lr = cpu.optimizer.param_groups[0]['lr']
+        before = {key: pc[key].detach().clone() for key in names}
+        with torch.no_grad():
+            for key in names:
+                pg[key].grad.copy_(pc[key].grad)
+        for tr in (gpu, cpu):
+            tr.optimizer.step()
+            tr.scheduler.step()
+        assert abs(gpu.scheduler.get_last_lr()[0] - cpu.scheduler.get_last_lr()[0]) < 1e-15
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        for key in names:
+            sgk, sck = gpu.optimizer.state[pg[key]], cpu.optimizer.state[pc[key]]
+            assert float(sgk['step']) == float(sck['step']) == k + 1, key
+            assert rel_l2(sgk['exp_avg'].cpu().numpy(), sck['exp_avg'].numpy()) < 1e-6, (k, key)
+            assert rel_l2(sgk['exp_avg_sq'].cpu().numpy(), sck['exp_avg_sq'].numpy()) < 1e-6, (k, key)
+            wg, wc = pg[key].detach().cpu(), pc[key].detach()
+            worst = float(((wg - wc).abs() / _ulp(wc)).max())
+            assert worst <= 2.0, (k, key, worst)
+            # float64 Adam from the CPU side's (identical) inputs
+            m = sck['exp_avg'].double()
+            v = sck['exp_avg_sq'].double()
+            want = -(lr / (1 - b1 ** (k + 1))) * m / ((v / (1 - b2 ** (k + 1))).sqrt() + eps)
+            got = wg.double() - before[key].double()
+            quant = float(_ulp(before[key]).double().norm())                  # what fp32 storage of w can resolve
+            assert float((got - want).norm()) <= 1e-4 * float(want.norm()) + quant, (k, key)
+
+
+def test_free_running_trajectory_smoke():
+    """Three free-running steps of both trainers from one state_dict (no teacher forcing): a smoke check only -- the losses stay
+    together to 1e-3 and the BatchNorm statistics to 1e-2; the sharp per-step statements are in the teacher-forced test."""
+    from geniconet_amd import data, models
+    from geniconet_amd.train import Trainer, build_criterion
+    name, R, B = 'ico2ico', 3, 3
+    p = models.default_params(name, subdivisions=R)
+    p[name].update(lr=1e-4, lr_base=1e-4, lr_max=1e-3)
+    torch.manual_seed(5)
+    ref = getattr(models_ref, name)(R=R).train()
+    gpu = Trainer(p, 'cuda', model=_product(ref, name, R))
+    cpu = Trainer(p, 'cpu', model=ref, criterion=build_criterion(p, 'cpu'), channels_last=False)
+    for k in range(3):
         x, t = data.synthetic_batch(B, R, seed=40 + k)
         lg = float(gpu.step(x.cuda().contiguous(memory_format=torch.channels_last), t.cuda()))
         lc = float(cpu.step(x, t))
-        assert abs(lg - lc) <= (1e-4 if k == 0 else 1e-3) * abs(lc), (k, lg, lc)      # from step 1 on the weights differ
+        assert abs(lg - lc) <= 1e-3 * abs(lc), (k, lg, lc)
     sg, sc = gpu.model.state_dict(), cpu.model.state_dict()
-    assert list(sg) == list(sc)
-    compared, noisy = [], []
     for key, vc in sc.items():
-        vg = sg[key].cpu()
-        if 'num_batches_tracked' in key:
-            assert int(vg) == int(vc) == STEPS, key
-        elif 'running' in key:
-            assert rel_l2(vg.numpy(), vc.numpy()) < 5e-3, key
-        elif not _zero_true_gradient(key):
-            du_g, du_c = (vg - init[key]).numpy(), (vc - init[key]).numpy()
-            assert np.linalg.norm(du_c) > 0, key
-            # Adam moves every element by about lr per step when its gradient keeps its sign.  A tensor that moved much less
-            # (e.g. the BatchNorm bias of the VAE's mu head: sum(mu) = 0 makes the KL term's gradient vanish there) has a
-            # noise-level gradient; its update is then as arbitrary on the CPU as on the GPU and is not compared.
-            if np.linalg.norm(du_c) < 0.3 * STEPS * 1e-4 * np.sqrt(du_c.size):
-                noisy.append(key)
-                continue
-            compared.append(key)
-            assert rel_l2(du_g, du_c) < 0.15, (key, rel_l2(du_g, du_c))
-    assert abs(gpu.scheduler.get_last_lr()[0] - cpu.scheduler.get_last_lr()[0]) < 1e-12
-    conv_weights = [k for k in sc if k.endswith('.weight') and sc[k].dim() == 3]
-    assert set(conv_weights) <= set(compared) and len(noisy) <= 4, (noisy, set(conv_weights) - set(compared))
+        if 'running' in key:
+            assert rel_l2(sg[key].cpu().numpy(), vc.numpy()) < 1e-2, key
+
+
+# ---- (a2) checkpoints with the product model and the HIP Adam: reference run.py:330-372 --------------------------------------
+@pytest.mark.parametrize('name', ['ico2ico', 'ico2ico_vae'])
+def test_checkpoint_save_load_next_step_identical_on_the_device(name, tmp_path, monkeypatch):
+    """save_checkpoint (run.py:330-340) after two steps of the product trainer on the GPU, load_checkpoint (run.py:342-372:
+    tensors through the CPU, key filter + strict load, optimizer state restored) into a differently initialised product trainer,
+    then the next step on both: the loss, every weight, every BatchNorm buffer and the HIP Adam's state must be BIT-identical
+    to the trainer that never stopped.  The reference does not save the CyclicLR position (run.py:369-370 restores the
+    optimizer only), so the test carries the scheduler's state_dict across by hand."""
+    from geniconet_amd import data, models
+    from geniconet_amd.train import Trainer, load_checkpoint, save_checkpoint
+    R, B = 3, 3
+    p = models.default_params(name, subdivisions=R)
+    p[name].update(lr=1e-4, lr_base=1e-4, lr_max=1e-3)
+    if name == 'ico2ico_vae':
+        _fixed_noise(monkeypatch, R, B, 3)
+    batches = [data.synthetic_batch(B, R, seed=60 + k) for k in range(3)]
+    batches = [(x.cuda().contiguous(memory_format=torch.channels_last), t.cuda()) for x, t in batches]
+    a = Trainer(p, 'cuda', seed=3)
+    for x, t in batches[:2]:
+        a.step(x, t)
+    path = save_checkpoint(a, str(tmp_path), 2, val_loss=0.5)
+    assert path is not None and path.endswith('%s_E2.pt' % name)
+    sched = a.scheduler.state_dict()
+    b = Trainer(p, 'cuda', seed=4)                                # other weights, fresh optimizer
+    assert not torch.equal(next(iter(a.model.parameters())), next(iter(b.model.parameters())))
+    ckpt = load_checkpoint(b.model, str(tmp_path), name, epoch=2, optimizer=b.optimizer)
+    assert ckpt['epoch'] == 2 and ckpt['loss'] == 0.5
+    b.scheduler.load_state_dict(sched)
+    b.optimizer.param_groups[0]['lr'] = a.optimizer.param_groups[0]['lr']
+    for key, v in a.model.state_dict().items():
+        assert torch.equal(v, b.model.state_dict()[key]), key
+    if name == 'ico2ico_vae':
+        _fixed_noise(monkeypatch, R, B, 1)                        # both next steps draw the same noise
+    la, lb = a.step(*batches[2]), b.step(*batches[2])
+    assert torch.equal(la, lb)
+    sa, sb = a.model.state_dict(), b.model.state_dict()
+    for key in sa:
+        assert torch.equal(sa[key], sb[key]), key
+    pa, pb = list(a.model.parameters()), list(b.model.parameters())
+    for qa, qb in zip(pa, pb):
+        ea, eb = a.optimizer.state[qa], b.optimizer.state[qb]
+        assert float(ea['step']) == float(eb['step']) == 3
+        assert torch.equal(ea['exp_avg'], eb['exp_avg']) and torch.equal(ea['exp_avg_sq'], eb['exp_avg_sq'])
+    assert a.scheduler.get_last_lr() == b.scheduler.get_last_lr()
 
 
 # ---- (b) whole-VAE gradients with a fixed eps ----------------------------------------------------------------------------------

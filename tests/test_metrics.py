@@ -67,3 +67,17 @@ def test_full_size_metric_of_a_mesh_against_itself_and_a_shifted_copy():
     shifted[..., 0] += eps
     d2, _, _ = metrics.point_to_mesh_distance(shifted, v, f)
     assert float(d2.max()) <= eps * eps * (1 + 1e-4) and 0 < float(d2.mean()) < eps * eps
+
+
+def test_face_indices_outside_the_vertex_list_raise_an_index_error():
+    """A 1-based or mismatched face list: IndexError on the host, as kaolin / the torch formulation would raise,
+    instead of an unchecked device read."""
+    import torch
+    from geniconet_amd.metrics import point_to_mesh_distance
+    pts, vts = torch.rand(1, 5, 3), torch.rand(1, 4, 3)
+    with pytest.raises(IndexError):
+        point_to_mesh_distance(pts, vts, torch.tensor([[1, 2, 4]]))      # 1-based
+    with pytest.raises(IndexError):
+        point_to_mesh_distance(pts, vts, torch.tensor([[-1, 2, 3]]))
+    d, f, k = point_to_mesh_distance(pts, vts, torch.tensor([[0, 1, 2], [1, 2, 3]]))
+    assert d.shape == (1, 5)

@@ -100,3 +100,26 @@ def test_hip_adam_unsupported_options_fall_back_to_torch(monkeypatch):
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert 'max_exp_avg_sq' in oa.state[a[0]]
+
+
+def test_closure_runs_before_eligibility_is_decided():
+    """torch.optim.Adam.step(closure) evaluates the closure FIRST; with zero_grad(set_to_none=True) + backward inside it the
+    gradients only exist afterwards, so the first step must already move the parameters (and the closure must run once)."""
+    a, b = _params('cpu'), _params('cpu')
+    oa, ob = optim.Adam(a, lr=1e-2), torch.optim.Adam(b, lr=1e-2)
+    calls = {'a': 0, 'b': 0}
+
+    def make(ps, opt, tag):
+        def closure():
+            calls[tag] += 1
+            opt.zero_grad(set_to_none=True)
+            loss = sum((p * p).sum() for p in ps)
+            loss.backward()
+            return loss
+        return closure
+    for _ in range(2):
+        la, lb = oa.step(make(a, oa, 'a')), ob.step(make(b, ob, 'b'))
+        assert float(la) == float(lb)
+    assert calls == {'a': 2, 'b': 2}
+    for x, y, x0 in zip(a, b, _params('cpu')):
+        assert torch.equal(x, y) and not torch.equal(x, x0)
