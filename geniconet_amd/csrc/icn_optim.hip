@@ -33,8 +33,13 @@ struct AdamTable {
 };
 static_assert(sizeof(AdamTable) <= 4000, "kernel arguments are limited to 4 KB");
 
+// No FMA contraction here: the vector path (16-byte aligned tensors) and the scalar path (e.g. gradients that are views into a
+// DistributedDataParallel bucket, which start at any 4-byte offset) must round identically, or the same training run differs in
+// the last bit with and without DDP (seen: weights 1 ulp apart after the second step).  With contraction left to the compiler
+// the two inlined copies were fused differently.
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1c, float b2, float b2c, float eps, float wd,
                                          float step_size, float bc2_sqrt) {
+#pragma clang fp contract(off)
     if (wd != 0.f) g = g + wd * p;
     m = m + (g - m) * b1c;
     v = v * b2 + b2c * g * g;

@@ -62,9 +62,9 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
          gradient), BatchNorm running statistics to 1e-4;
       2. the CPU gradients are copied into the GPU parameters' .grad, and Adam + CyclicLR step on both sides from IDENTICAL
          gradients, moments, step counts and learning rate.  The HIP Adam (icn_adam_step) must then reproduce torch's update on
-         EVERY tensor, no exemptions: exp_avg and exp_avg_sq to 1e-6 rel-L2, every weight element within 2 ulp of the CPU
-         result (fp32 weights quantise an update of size lr at ulp(w) / lr ~ 1e-5, so ulps of w -- not a relative bound on the
-         update -- are the sharp statement), and, against a float64 evaluation of Adam's formula, the applied update to 1e-4
+         EVERY tensor, no exemptions: exp_avg and exp_avg_sq to 1e-6 rel-L2, every weight element within 2 ulp (of the
+         larger of |w_old|, |w_new|) + 1e-6 of its update of the CPU result (fp32 weights quantise an update of size lr at
+         ulp(w) / lr ~ 1e-5, so ulps of w -- not a relative bound on the update -- are the sharp statement), and, against a float64 evaluation of Adam's formula, the applied update to 1e-4
          rel-L2 of the update itself (a wrong bias correction, a stale moment or a skipped tensor is off by >= 1e-1 there)."""
     from geniconet_amd import data, models
     from geniconet_amd.train import Trainer, build_criterion
@@ -126,8 +126,11 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
             assert rel_l2(sgk['exp_avg'].cpu().numpy(), sck['exp_avg'].numpy()) < 1e-6, (k, key)
             assert rel_l2(sgk['exp_avg_sq'].cpu().numpy(), sck['exp_avg_sq'].numpy()) < 1e-6, (k, key)
             wg, wc = pg[key].detach().cpu(), pc[key].detach()
-            worst = float(((wg - wc).abs() / _ulp(wc)).max())
-            assert worst <= 2.0, (k, key, worst)
+            # 2 ulp at the larger of |w_old|, |w_new| (an element may cancel to ~0: its own ulp says nothing there) + 1e-6 of
+            # the element's update
+            tol = 2.0 * _ulp(torch.maximum(before[key].abs(), wc.abs())) + 1e-6 * (wc - before[key]).abs()
+            worst = float(((wg - wc).abs() / tol).max())
+            assert worst <= 1.0, (k, key, worst)
             # float64 Adam from the CPU side's (identical) inputs
             m = sck['exp_avg'].double()
             v = sck['exp_avg_sq'].double()
