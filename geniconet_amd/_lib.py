@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('ICN_LIB_PATH') or os.path.join(_HERE, 'libicn.so')
 
 OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT = 0, 1, 2
 CORNER_MODES = {'zeros': 0, 'average': 1}
-ABI_VERSION = 3
+ABI_VERSION = 4
 LAP_MODES = {'mean-v': 0, 'v-mean': 1, 'sum-kv': 2, 'kv-sum': 3}   # ICN_LAP_* of include/icn.h
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses
@@ -67,6 +67,7 @@ SIGNATURES = {
     'icn_set_debug_flags': (ctypes.c_int, [ctypes.c_int]),
     'icn_device_status': (ctypes.c_int, [ctypes.c_int]),
     'icn_host_selfcheck': (ctypes.c_long, [ctypes.c_int] * 2),
+    'icn_debug_trace': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     'icn_point_to_mesh': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [ctypes.c_void_p]),
     'icn_table_conv_fwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t]),
     'icn_table_conv_bwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t, _intp]),
@@ -233,7 +234,8 @@ def table_upconv_bwd(r_in, corner_mode):
 
 
 def table_stream_k(ntiles, grid, nk, ku=1):
-    """Stream-K schedule (icn_table_stream_k): int32 array (n, 4) of rows (workgroup, tile, k0, k1) in walk order."""
+    """Stream-K schedule (icn_table_stream_k) of ntiles tiles of nk K-steps, pieces >= ku steps: int32 array (n, 4) of rows
+    (workgroup, tile, k0, k1) in walk order."""
     L = lib()
     n = L.icn_table_stream_k(ntiles, grid, nk, ku, None, 0)
     if n < 0:

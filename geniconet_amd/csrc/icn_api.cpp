@@ -1182,12 +1182,15 @@ int icn_adam_step(int count, float* const* params, const float* const* grads, fl
 
 long icn_table_stream_k(int ntiles, int grid, int nk, int ku, int32_t* out, size_t cap) {
     try {
-        if (ntiles < 1 || grid < 8 || grid % 8 != 0 || nk < 1 || ku < 1 || nk % ku != 0)
-            throw std::invalid_argument("icn_table_stream_k: grid must be a positive multiple of 8, nk a positive multiple of ku");
+        if (ntiles < 1 || grid < 8 || grid % 8 != 0 || nk < 1 || ku < 1)
+            throw std::invalid_argument("icn_table_stream_k: grid must be a positive multiple of 8, nk and ku positive");
         size_t n = 0;
+        std::vector<int> tables(2 * (grid / 8 + 1));
+        const int occ = grid / 256;                       // the launcher's grids are 256 CUs x blocks per CU
+        icn::sk_tables(ntiles, grid, nk, ku, occ, grid % 256 == 0 ? icn::sk_speed_factors(occ) : nullptr, tables.data());
         for (int b = 0; b < grid; ++b) {
             icn::SkWalk w{};
-            w.init(b, grid, ntiles, nk, ku);
+            w.init(b, grid, ntiles, nk, ku, tables.data());
             int tile, k0, k1;
             while (w.next(tile, k0, k1)) {
                 if (out && n + 4 <= cap) { out[n] = b; out[n + 1] = tile; out[n + 2] = k0; out[n + 3] = k1; }
@@ -1202,6 +1205,11 @@ long icn_table_stream_k(int ntiles, int grid, int nk, int ku, int32_t* out, size
 }
 
 int icn_set_debug_flags(int flags) { return icn::set_debug_flags(flags); }
+
+int icn_debug_trace(void* device_buffer, size_t n_u64) {
+    icn::set_trace_buffer(device_buffer, n_u64);
+    return 0;
+}
 
 long icn_host_selfcheck(int r, int corner_mode) {
     // Every host-side table builder and planner the device paths use at level r, with the device copies skipped: lets the

@@ -16,9 +16,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <tuple>
+#include <vector>
 #include <stdexcept>
 #include <type_traits>
 #include <utility>
@@ -330,6 +334,10 @@ int device_status(int clear) {
     if (clear && v) __atomic_fetch_and(w, ~v, __ATOMIC_ACQ_REL);
     return v;
 }
+// developer: per-block timestamps of the next stream-K launches (icn_debug_trace; the buffer is the caller's device memory)
+static unsigned long long* g_trace = nullptr;
+static size_t g_trace_cap = 0;
+void set_trace_buffer(void* p, size_t n_u64) { g_trace = static_cast<unsigned long long*>(p); g_trace_cap = p ? n_u64 : 0; }
 static int current_device_bit() {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -399,11 +407,13 @@ __device__ __forceinline__ void conv_dma_body(
     const uint32_t* __restrict__ mask32,// [Pd/32] taps in use per 32 rows, or null (all 7)
     int M, int Ps, int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles, int T_arg,
     const RowSegs segs,
-    int sk_ku,                          // SK: k-chunks per unit of the split (1 with 7 taps per k-chunk; 4 for a one-tap launch: >= 4 K-steps)
+    int sk_mp,                          // SK: fewest K-steps a piece of a split tile may run (4: the ring's fill and the metadata look-ahead)
     float* __restrict__ sk_part,        // SK: one BM x BN partial-accumulator slot per block (raw register layout)
     int* __restrict__ sk_flag,          // SK: CONV_SK_FLAGS words zeroed by the prologue: [b] = 1: block b's piece is parked
     int* __restrict__ sk_status,        // SK: the device's asynchronous failure word (pinned host memory, icn_device_status)
-    int sk_spin_limit) {                // SK: polls before a partner counts as lost; < 0: fault injection (tests): lost at once
+    int sk_spin_limit,                  // SK: polls before a partner counts as lost; < 0: fault injection (tests): lost at once
+    unsigned long long* __restrict__ trace,     // developer: 8 timestamps (100 MHz) per block, or null (icn_debug_trace)
+    const int* __restrict__ sk_bnd) {   // SK: range boundaries of the launch's two residue-class sizes, [2][G / 8 + 1] (sk_tables)
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
     // T taps in wt / dcode (7 hex taps, or the virtual taps of a composite table); a tile runs at most 7 of them (its tap
     // mask), and the LDS offset table is indexed by a tap's RANK inside that mask.
@@ -609,35 +619,52 @@ __device__ __forceinline__ void conv_dma_body(
     // those with `s_waitcnt vmcnt(0)`, which drains the ring.
     // All loop state is kept in plain ints and passed through readfirstlane: hipcc must see the DMA's LDS base
     // and scalar offset as wave-uniform or it wraps every DMA in a waterfall loop.
-    // SK: a block's work is a list of SEGMENTS (tile, k-chunk range [k0, k1) of its nk): whole tiles b, b + G, ... first, then
-    // its range of the split tiles (sk_plan above), walked BACK TO FRONT.  seg_fetch hands out the next one; everything below
-    // that says "tile" means the segment's tile, and the K-step loop, the DMA pointer and the epilogue respect the
-    // segment's k-chunk range.
+    // SK: a block's work is a list of SEGMENTS (tile, K-step range [s0, s1) of the tile's S = taps * nk steps, in the order
+    // k-chunk major, tap minor): whole tiles b, b + G, ... first, then its range of the split tiles (icn_streamk.h), walked BACK
+    // TO FRONT.  seg_fetch hands out the next one; everything below that says "tile" means the segment's tile, and the K-step
+    // loop, the DMA pointer and the epilogue respect the segment's step range.  (Without SK a segment is a whole tile.)
     // Who waits for whom: of a tile cut in K, the block holding its LAST k-chunks finishes it; that piece lies at the front
     // of the block's range, i.e. it is the last thing the block does, while the other pieces lie at the back of LOWER-numbered
     // blocks' ranges, i.e. they are the first thing those blocks do after their whole tiles.  A block therefore only ever
     // waits for lower block ids of its own launch -- dispatched before it, whatever else shares the GPU -- and those never
     // wait for anything before parking their piece.  (A ticket drawn from an atomic counter instead of blockIdx would not
     // even need in-order dispatch; its round trip at the top of every launch cost half of what stream-K gains.)
+    unsigned long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_split = 0, tr_wait = 0;
+    if (trace) tr_t0 = __builtin_amdgcn_s_memrealtime();
     SkWalk skw{};                                         // (icn_streamk.h; plain ints: stays in scalar registers)
-    if constexpr (SK) skw.init(blockIdx.x, gridDim.x, ntiles, nk, sk_ku);
-    auto seg_fetch = [&](int& tile_, int& k0_, int& k1_) __attribute__((always_inline)) { return skw.next(tile_, k0_, k1_); };
+    const int sk_S = (SEG ? __popc(segs.mask[0]) : 7) * nk;   // SK: K-steps of a tile (every tile of an SK launch runs the same taps)
+    if constexpr (SK) skw.init(blockIdx.x, gridDim.x, ntiles, sk_S, sk_mp, sk_bnd);
+    auto seg_fetch = [&](int& tile_, int& s0_, int& s1_) __attribute__((always_inline)) { return skw.next(tile_, s0_, s1_); };
     int tile = blockIdx.x, m0, n0;
-    int c_k0 = 0, c_k1 = nk, n_k0 = 0, n_k1 = nk;         // k-chunk range of the compute / next segment (SK; else whole tiles)
+    int c_s0 = 0, c_s1 = 0, n_s0 = 0, n_s1 = 0;           // K-step range of the compute / next segment
     if constexpr (SK) {
-        if (!seg_fetch(tile, c_k0, c_k1)) return;         // more blocks than work (block-uniform, before any barrier)
+        if (!seg_fetch(tile, c_s0, c_s1)) return;         // more blocks than work (block-uniform, before any barrier)
     }
     tile_origin(tile, m0, n0);
     build_first(m0, n0, tile_taps(m0));
     __syncthreads();
+    if (trace) tr_t1 = __builtin_amdgcn_s_memrealtime();
     int slot = 0, eslot = 0;                              // offset-table slot / epilogue-table slot of the compute tile
     int next_tile = tile + gridDim.x;
     int has_next = next_tile < ntiles;
-    if constexpr (SK) has_next = seg_fetch(next_tile, n_k0, n_k1);
+    if constexpr (SK) has_next = seg_fetch(next_tile, n_s0, n_s1);
     int nm0 = m0, nn0 = n0;
     if (has_next) tile_origin(next_tile, nm0, nn0);
     unsigned mask_c = tile_taps(m0), mask_n = has_next ? tile_taps(nm0) : 0x7fu;   // taps of the compute / next tile
-    int i_t = __ffs(mask_c) - 1, i_kc = SK ? c_k0 : 0, i_ring = 0, i_own = 1, i_live = 1;   // DMA pointer; i_own: inside compute tile
+    if constexpr (!SK) {                                  // whole tiles: every step of the tile's taps
+        c_s1 = __popc(mask_c) * nk;
+        n_s1 = __popc(mask_n) * nk;
+    }
+    // first step of a segment -> (k-chunk, tap) of the DMA pointer
+    auto seg_start = [&](unsigned mk_, int s0_, int& kc_, int& t_) __attribute__((always_inline)) {
+        const int nt_ = __popc(mk_);
+        kc_ = s0_ / nt_;
+        t_ = nth_tap(mk_, s0_ - kc_ * nt_);
+    };
+    int i_t, i_kc, n_t0 = 0, n_kc0 = 0;                   // DMA pointer (tap, k-chunk); where it enters the next segment
+    seg_start(mask_c, c_s0, i_kc, i_t);
+    if (has_next) seg_start(mask_n, n_s0, n_kc0, n_t0);
+    int i_left = c_s1 - c_s0, i_ring = 0, i_own = 1, i_live = 1;   // steps left in the pointer's segment; i_own: inside compute tile
     unsigned pbase[RA];                                   // row offsets of the next stage to be issued (prefetched)
 #pragma unroll
     for (int i = 0; i < RA; ++i) pbase[i] = otab[(SEG ? 0 : i_t) * BM + 8 * (wave + 4 * i) + rsub];   // SEG: rank 0
@@ -683,17 +710,16 @@ _Pragma("unroll") \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)lds_dst, 16, bconst[i], b_soff, 0, 0); \
             } \
             i_ring = i_ring == 2 ? 0 : i_ring + 1; \
-            { \
-                unsigned mk_ = i_own ? mask_c : mask_n; \
+            if (--i_left == 0) {                         /* the pointer leaves its segment */ \
+                if (i_own && has_next) { i_own = 0; i_left = n_s1 - n_s0; i_kc = n_kc0; i_t = n_t0; } \
+                else i_live = 0; \
+            } else { \
+                const unsigned mk_ = i_own ? mask_c : mask_n; \
                 const unsigned higher_ = mk_ & ~((2u << i_t) - 1u); \
                 if (higher_) { \
                     i_t = __ffs(higher_) - 1; \
                 } else { \
-                    if (++i_kc == (SK ? (i_own ? c_k1 : n_k1) : nk)) { \
-                        i_kc = SK ? n_k0 : 0; \
-                        if (i_own && has_next) { i_own = 0; mk_ = mask_n; } \
-                        else i_live = 0; \
-                    } \
+                    ++i_kc; \
                     i_t = __ffs(mk_) - 1; \
                 } \
             } \
@@ -774,9 +800,11 @@ _Pragma("unroll") \
     ICN_ISSUE_STAGE();
     ICN_RETIRE_AND_PUBLISH(false);
     zero_acc();
+    if (trace) tr_t2 = __builtin_amdgcn_s_memrealtime();
     int c_ring = 0;
     for (;;) {
-        const int S = __popc(mask_c) * (SK ? c_k1 - c_k0 : nk);      // K-steps of this tile (SK: of this segment)
+        const int S = c_s1 - c_s0;                        // K-steps of this segment (without SK: of the whole tile)
+        if (SK && trace && tr_split == 0 && (c_s0 > 0 || c_s1 < sk_S)) tr_split = __builtin_amdgcn_s_memrealtime();
         for (int step = 0; step < S; ++step) {
             const bool meta = step == 0 && has_next;      // wave-uniform
             frag0(c_ring);
@@ -800,7 +828,7 @@ _Pragma("unroll") \
             constexpr int SYS = 17;                       // cache policy bits of the buffer builtins: sc0 | sc1
             const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc(sk_part, 0, (int)(gridDim.x * (unsigned)(BM * BN * 4)), 0x00020000);
             const int me = blockIdx.x;                     // this block's slot / flag
-            if (c_k1 < nk) {                               // a piece that does not reach the tile's end: park it
+            if (c_s1 < sk_S) {                             // a piece that does not reach the tile's end: park it
                 const unsigned base = (unsigned)me * (unsigned)(BM * BN * 4) + tid * 16u;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -816,23 +844,30 @@ _Pragma("unroll") \
                 __syncthreads();
                 if (tid == 0) __hip_atomic_store(sk_flag + me, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 sk_store = false;
-            } else if (c_k0 > 0) {                         // the tile's last k-chunks: add the earlier blocks' pieces, nearest first
-                const int nku = skw.nku, lt = tile / 8 - skw.dp_l;
-                int pos = lt * nku + c_k0 / sk_ku, nb = skw.bl - 1;  // units [lt * nku, pos) are parked in the slots of blocks nb, nb - 1, ...
+            } else if (c_s0 > 0) {                         // the tile's last steps: add the earlier blocks' pieces, nearest first
+                const int nku = sk_S, lt = tile / 8 - skw.dp_l;
+                int pos = lt * nku + c_s0, nb = skw.bl - 1;         // steps [lt * S, pos) are parked in the slots of blocks nb, nb - 1, ...
                 bool sk_lost = false;
                 int* const lost_s = reinterpret_cast<int*>(bias_s + (bias ? 3 * BN : 0));   // one LDS word behind the tables
-                while (pos > lt * nku) {
+                while (pos > lt * nku && nb >= 0) {
+                    const int rs = skw.range_start(nb);             // block nb's range is [rs, range_start(nb + 1))
+                    if (rs >= pos) {                                // an empty range: that block parks nothing (degenerate shapes)
+                        --nb;
+                        continue;
+                    }
                     const int blk = nb * 8 + skw.x;
                     // Block-uniform wait: ONE lane polls the partner's flag (system scope) and the verdict goes through LDS, so
                     // every wave takes the same branch (with one counter per thread, waves could disagree on a timeout and leave
                     // a tile half NaN) and 255 threads' worth of polling traffic is gone.
                     if (tid == 0) {
+                        const unsigned long long w0_ = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
                         int lost = sk_spin_limit < 0, spins = 0;
                         while (!lost && __hip_atomic_load(sk_flag + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
                             __builtin_amdgcn_s_sleep(8);
                             if (++spins > sk_spin_limit) lost = 1;   // seconds: a partner that never arrives is a bug, not a reason to hang the GPU
                         }
                         if (lost) __hip_atomic_fetch_or(sk_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (trace) tr_wait += __builtin_amdgcn_s_memrealtime() - w0_;
                         *lost_s = lost;
                     }
                     __syncthreads();
@@ -853,7 +888,7 @@ _Pragma("unroll") \
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += v[e];
                             }
-                    pos = max(lt * nku, skw.range_start(nb));       // block nb's range starts there
+                    pos = max(lt * nku, rs);                        // block nb's range starts there
                     --nb;
                     __syncthreads();                               // everyone has read lost_s before lane 0 writes it again
                 }
@@ -901,15 +936,21 @@ _Pragma("unroll") \
         i_own = 1;                                        // the DMA pointer is already inside this tile
         next_tile = tile + gridDim.x;
         has_next = next_tile < ntiles;
-        if constexpr (SK) {
-            c_k0 = n_k0;
-            c_k1 = n_k1;
-            has_next = seg_fetch(next_tile, n_k0, n_k1);
-        }
+        c_s0 = n_s0;
+        c_s1 = n_s1;
+        if constexpr (SK) has_next = seg_fetch(next_tile, n_s0, n_s1);
         if (has_next) {
             tile_origin(next_tile, nm0, nn0);
             mask_n = tile_taps(nm0);
+            if constexpr (!SK) n_s1 = __popc(mask_n) * nk;
+            seg_start(mask_n, n_s0, n_kc0, n_t0);
         }
+    }
+    if (trace && tid == 0) {
+        unsigned long long* o = trace + (size_t)blockIdx.x * 8;
+        o[0] = tr_t0; o[1] = tr_t1; o[2] = tr_t2; o[3] = tr_split; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = tr_wait;
+        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // XCC_ID (HW_REG 20, bits 3:0)
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);    // HW_ID
     }
 #undef ICN_ISSUE_STAGE
 #undef ICN_META_ISSUE
@@ -928,7 +969,7 @@ __global__ __launch_bounds__(256) void k_conv_dma(const float* __restrict__ src,
                                                    int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles, int T_arg,
                                                    const RowSegs segs) {
     conv_dma_body<BM, BN, SEG, false>(src, src2, wt, bias, dst, dst2, dcode, side, side2, perm, mask32, M, Ps, Pd, K, N, N0, n_slots,
-                                      src_bytes, side_bytes, ntiles, T_arg, segs, 1, nullptr, nullptr, nullptr, 0);
+                                      src_bytes, side_bytes, ntiles, T_arg, segs, 4, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
 // Stream-K form: same tiles, same K-step pipeline; the last 1 + frac rounds of tiles are cut into equal k-chunk ranges (sk_plan),
@@ -942,11 +983,12 @@ __global__ __launch_bounds__(256) void k_conv_dma_sk(const float* __restrict__ s
                                                       const int32_t* __restrict__ dcode, const float* __restrict__ side,
                                                       const float* __restrict__ side2, const int32_t* __restrict__ perm, int M, int Ps,
                                                       int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes,
-                                                      unsigned side_bytes, int ntiles, int T_arg, const RowSegs segs, int sk_ku,
+                                                      unsigned side_bytes, int ntiles, int T_arg, const RowSegs segs, int sk_mp,
                                                       float* __restrict__ sk_part, int* __restrict__ sk_flag,
-                                                      int* __restrict__ sk_status, int sk_spin_limit) {
+                                                      int* __restrict__ sk_status, int sk_spin_limit,
+                                                      unsigned long long* __restrict__ trace, const int* __restrict__ sk_bnd) {
     conv_dma_body<BM, BN, SEG, true>(src, src2, wt, bias, dst, dst2, dcode, side, side2, SEG ? perm : nullptr, nullptr, M, Ps, Pd, K, N, N0, n_slots,
-                                     src_bytes, side_bytes, ntiles, T_arg, segs, sk_ku, sk_part, sk_flag, sk_status, sk_spin_limit);
+                                     src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd);
 }
 
 // dynamic LDS of k_conv_dma: A/B rings, offset table, destination-row table (row permutation only), bias (bias only)
@@ -988,12 +1030,50 @@ static bool conv_sk_splits(long ntiles, int slots, int nk) {
     if (slots % 8 != 0 || ntiles < 8) return false;
     return sk_plan((int)((ntiles + 7) / 8), slots / 8, nk).nsk > 0;
 }
-// k-chunks per unit of the split: a piece must run >= 4 K-steps (the ring's fill and the metadata look-ahead)
-static int conv_sk_ku(const GatherGemmArgs& a) { return a.segs.nseg > 0 ? 4 : 1; }
+// a piece of a split tile must run >= 4 K-steps (the ring's fill and the metadata look-ahead)
+constexpr int CONV_SK_MIN_PIECE = 4;
+// K-steps of a tile of a stream-K-eligible launch (every tile runs the same taps): taps * k-chunks
+static int conv_sk_steps(const GatherGemmArgs& a) { return (a.segs.nseg > 0 ? __builtin_popcount(a.segs.mask[0]) : 7) * (a.K / BK); }
 static bool conv_sk_eligible(const GatherGemmArgs& a) {
     if (a.sk_part == nullptr || a.sk_flag == nullptr || a.mask32 != nullptr || (dbg_flags() & 128)) return false;
     if (a.segs.nseg == 0) return a.perm == nullptr && (a.T == 0 || a.T == 7);           // plain 7-tap convolution
-    return a.segs.nseg == 1 && a.T == 1 && a.segs.mask[0] == 1u && (a.K / BK) % 4 == 0;  // one-tap dense GEMM
+    return a.segs.nseg == 1 && a.T == 1 && a.segs.mask[0] == 1u;                          // one-tap dense GEMM
+}
+
+const int* sk_speed_factors(int occ) {
+    // measured on MI355X with equal shares (tools/trace_conv_blocks.py): see sk_boundaries
+    static int fac2[2] = {1060, 940}, fac3[3] = {1150, 1020, 830};
+    static const int parsed = [] {
+        const char* e = getenv("ICN_SK_FAC");
+        if (!e) return 1;
+        int v[3] = {0, 0, 0};
+        const int n = sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+        if (n == 2) { fac2[0] = v[0]; fac2[1] = v[1]; }
+        if (n == 3) { fac3[0] = v[0]; fac3[1] = v[1]; fac3[2] = v[2]; }
+        return n >= 2 ? 1 : 0;                            // "0" (or anything else): off
+    }();
+    if (!parsed) return nullptr;
+    return occ == 2 ? fac2 : (occ == 3 ? fac3 : nullptr);
+}
+
+// Device copy of a launch shape's stream-K boundary tables (sk_tables), built on first use and kept: immutable per
+// (device, tiles, grid, steps per tile), like the gather tables.
+static const int* sk_boundary_tables(int ntiles, int grid, int S, int occ) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int>, int*> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_tuple(dev, ntiles, grid, S);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    std::vector<int> h(2 * (grid / 8 + 1));
+    sk_tables(ntiles, grid, S, CONV_SK_MIN_PIECE, occ, sk_speed_factors(occ), h.data());
+    int* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), h.size() * sizeof(int)) != hipSuccess ||
+        hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        throw std::runtime_error("icn: cannot upload the stream-K boundary tables");
+    return cache.emplace(key, d).first->second;
 }
 
 template <int BM, int BN, bool SEG>
@@ -1015,8 +1095,9 @@ static void launch_conv_dma_sk_t(const GatherGemmArgs& a, int occ, hipStream_t s
     prof_mark_begin((SEG ? PROF_DMAKS_64x128 : PROF_DMAK_64x128) + (BN == 128 ? 0 : 1), a.algo_flops, s);
     hipLaunchKernelGGL((k_conv_dma_sk<BM, BN, SEG>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,
                        a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.M, a.Ps, a.Pd, a.K,
-                       a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs, conv_sk_ku(a),
-                       a.sk_part, a.sk_flag, device_status_word(), (dbg_flags() & 256) ? -1 : (1 << 22));
+                       a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs, CONV_SK_MIN_PIECE,
+                       a.sk_part, a.sk_flag, device_status_word(), (dbg_flags() & 256) ? -1 : (1 << 22),
+                       g_trace_cap >= (size_t)grid * 8 ? g_trace : nullptr, sk_boundary_tables(ntiles, grid, conv_sk_steps(a), occ));
     prof_mark_end(s);
 }
 
@@ -1092,7 +1173,7 @@ static void launch_conv_dma_auto(const GatherGemmArgs& a, hipStream_t s) {
         const long tiles = ((rows + c.bm - 1) / c.bm) * (a.N / c.bn);
         const long slots = 256L * occ;
         // rounds of tiles a block runs: whole rounds, unless the stream-K form evens out the last one (64-row tiles only)
-        const bool sk = c.bm == 64 && conv_sk_eligible(a) && conv_sk_splits(tiles, (int)slots, a.K / BK / conv_sk_ku(a));
+        const bool sk = c.bm == 64 && conv_sk_eligible(a) && conv_sk_splits(tiles, (int)slots, std::max(1, conv_sk_steps(a) / CONV_SK_MIN_PIECE));
         const double rounds = sk ? (double)tiles / slots : (double)((tiles + slots - 1) / slots);
         double cost = rounds * occ * c.bm * c.bn / (c.eff * occ / c.occ);
         // stride-2 data gradients (tap masks: tiles of 1-2 taps, unequal lengths) balance better on the finer tile: the
@@ -1105,7 +1186,7 @@ static void launch_conv_dma_auto(const GatherGemmArgs& a, hipStream_t s) {
         const DmaCfg& c = kDma[best];
         const long rows = a.segs.nseg > 0 ? seg_rows(a.segs, c.bm, nullptr) : a.M;
         const long tiles = ((rows + c.bm - 1) / c.bm) * (a.N / c.bn);
-        if (conv_sk_splits(tiles, 256 * best_occ, a.K / BK / conv_sk_ku(a)))
+        if (conv_sk_splits(tiles, 256 * best_occ, std::max(1, conv_sk_steps(a) / CONV_SK_MIN_PIECE)))
             return best == 2 ? launch_conv_dma_sk<64, 128>(a, best_occ, s) : launch_conv_dma_sk<64, 64>(a, best_occ, s);
     }
     switch (best) {

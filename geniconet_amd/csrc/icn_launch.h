@@ -48,9 +48,14 @@ constexpr int CONV_SK_ERROR = 1024;                        // flag words: [0, 10
 constexpr int CONV_SK_FLAGS = 1032;
 // The device's asynchronous failure word (pinned host memory mapped to the device; bit 0: a stream-K partner never arrived)
 // and its host-side read (clear != 0: reset the bits returned).  icn_device_status in include/icn.h.
+void set_trace_buffer(void* p, size_t n_u64);   // developer: icn_debug_trace
 int* device_status_word();
 int device_status(int clear);
 size_t conv_sk_part_bytes();                               // partial-tile slots of the largest stream-K grid
+// per-mille speed factors the stream-K plan assumes for the k-th blocks to arrive on a CU (icn_streamk.h: sk_boundaries), for
+// `occ` blocks per CU (1..3); returns the table or null (equal shares).  ICN_SK_FAC="a,b[,c]" overrides the defaults of the
+// matching occupancy, ICN_SK_FAC=0 switches the weighting off (developer A/B).
+const int* sk_speed_factors(int occ);
 
 
 struct WgradArgs {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ICN_ABI_VERSION 3
+#define ICN_ABI_VERSION 4
 
 #define ICN_CORNER_ZEROS 0
 #define ICN_CORNER_AVERAGE 1
@@ -217,9 +217,10 @@ long icn_table_conv_bwd(int r_in, int stride, int corner_mode, int32_t* out, siz
 long icn_table_upsample(int r_in, int corner_mode, int transpose, int32_t* idx, float* coef, size_t cap, int* width);
 long icn_table_upsample_pairs(int r_in, int32_t* out, size_t cap);                            /* [2][P_fine]   */
 long icn_table_faces(int r, int32_t* out, size_t cap);                                         /* [20*4^r][3]   */
-/* The stream-K schedule of the persistent conv GEMM for a launch of `ntiles` tiles of `nk` k-chunks on `grid`
- * workgroups, split in units of `ku` k-chunks: rows {workgroup, tile, k0, k1} in each workgroup's walk order.  A row with
- * k1 < nk is a piece the workgroup parks for the workgroup that holds the tile's last k-chunks (k0 > 0, k1 == nk). */
+/* The stream-K schedule of the persistent conv GEMM for a launch of `ntiles` tiles of `nk` K-STEPS each on `grid`
+ * workgroups, no piece shorter than `ku` steps: rows {workgroup, tile, k0, k1} (step ranges) in each workgroup's walk order.
+ * A row with k1 < nk is a piece the workgroup parks for the workgroup that holds the tile's last steps (k0 > 0, k1 == nk).
+ * (ABI 4: ranges are K-steps; up to ABI 3 they were whole k-chunks, multiples of ku.) */
 long icn_table_stream_k(int ntiles, int grid, int nk, int ku, int32_t* out, size_t cap);
 /* Composite table of conv_stride1(upsample(x)) over the COARSE tensor (icn_upconv_*; csrc/icn_geometry.h UpconvTable):
  * meta[7] = {P_fine, P_coarse, n_slots, E, nseg, NV (virtual taps), number of floats};
@@ -261,6 +262,12 @@ int icn_set_debug_flags(int flags);
  * synchronise: call it after the stream (or device) has been synchronised.  The reference has no counterpart (it checks
  * nothing but NaNs through torch.autograd.detect_anomaly, run.py:237); geniconet_amd.train.Trainer calls it once per step in
  * debug mode (ICN_CHECK=1) and bench.py once after the timed region. */
+/* Developer instrumentation (tools/trace_conv_blocks.py): while a device buffer of n_u64 >= 8 * grid 64-bit words is
+ * registered, every workgroup b of a stream-K GEMM launch (k_conv_dma_sk) writes 8 words at [8 b]: constant-clock (100 MHz)
+ * timestamps of entry, first-tile tables built, ring filled, first split-phase segment, exit; the time spent waiting for
+ * partners; XCC id; HW_ID.  NULL / 0 switches it off (the default; the kernel then only tests one scalar).  Not thread safe. */
+int icn_debug_trace(void* device_buffer, size_t n_u64);
+
 /* Host-only self check: runs every host-side table builder and launch planner of level r (conv stride 1 / 2, upsample,
  * composite upsample + conv tables, loss tables, workspace layouts for the model's channel counts) WITHOUT copying anything
  * to a device, so the host side of the library can be exercised under ASan / UBSan on a machine without a GPU
