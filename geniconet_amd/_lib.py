@@ -64,6 +64,7 @@ SIGNATURES = {
     'icn_reparam_bwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_size_t] + [_c_float_p] * 2 + [ctypes.c_void_p]),
     'icn_adam_step': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_double] * 4 + [ctypes.c_void_p]),
     'icn_table_stream_k': (ctypes.c_long, [ctypes.c_int] * 4 + [_i32p, ctypes.c_size_t]),
+    'icn_table_tile_lists': (ctypes.c_long, [ctypes.c_int] * 7 + [_i32p, ctypes.c_size_t]),
     'icn_set_debug_flags': (ctypes.c_int, [ctypes.c_int]),
     'icn_device_status': (ctypes.c_int, [ctypes.c_int]),
     'icn_host_selfcheck': (ctypes.c_long, [ctypes.c_int] * 2),
@@ -243,6 +244,17 @@ def table_stream_k(ntiles, grid, nk, ku=1):
     out = np.empty(n, dtype=np.int32)
     L.icn_table_stream_k(ntiles, grid, nk, ku, out.ctypes.data_as(_i32p), n)
     return out.reshape(-1, 4)
+
+
+def table_tile_lists(r_in, B, bm, ntn, grid, corner_mode='average'):
+    """Tile lists of a stride-2 data-gradient launch (icn_table_tile_lists): (offsets [grid + 1], ids)."""
+    L, m = lib(), corner_code(corner_mode)
+    n = L.icn_table_tile_lists(r_in, 2, m, B, bm, ntn, grid, None, 0)
+    if n < 0:
+        check(-1, 'icn_table_tile_lists')
+    out = np.empty(n, dtype=np.int32)
+    L.icn_table_tile_lists(r_in, 2, m, B, bm, ntn, grid, out.ctypes.data_as(_i32p), n)
+    return out[:grid + 1], out[grid + 1:]
 
 
 def profile_start(max_launches=4096, only=None):

@@ -76,6 +76,8 @@ struct ConvTables {
     int32_t* perm = nullptr;   // [Pin] (stride 2 only)
     int32_t* bwd_perm = nullptr;  // [7][E][Pin] transposed table in permuted row order (stride 2 only)
     uint32_t* mask32 = nullptr; // [Pin/32] (stride 2 only)
+    std::vector<uint32_t> mask32_h;   // host copy: the launcher balances the tiles of a masked launch by their step counts
+    int key = 0;                  // (r, stride, mode) packed: names this table set in the launcher's tile-list cache
     DevDma d_fwd, d_bwd, d_bwd1, d_virt, d_bwdp;   // DmaTable forms of fwd, bwd, bwd1, vidx, bwd_perm
 };
 struct UpTables {
@@ -180,7 +182,9 @@ ConvTables make_conv_tables(int r_in, int stride, int mode) {
     if (stride == 2) {
         icn::build_bwd_row_order(r_in, stride, bwd, t.E, perm, mask);
         t.perm = upload(perm);
-        t.mask32 = upload(std::vector<uint32_t>(mask.begin(), mask.end()));
+        t.mask32_h.assign(mask.begin(), mask.end());
+        t.mask32 = upload(t.mask32_h);
+        t.key = 1 + ((r_in << 8) | (stride << 4) | mode);
         // the same table in permuted row order (row k of a sample = pixel perm[k]): one load level in the kernels
         std::vector<int32_t> bwd_p(bwd.size());
         for (int te = 0; te < icn::NTAPS * t.E; ++te)
@@ -535,6 +539,7 @@ void conv_bwd_data_impl(const float* dy0, const float* dy1, const float* w0, con
     a.src = dy0; a.src2 = dy1; a.wt = wb; a.dst = dx; a.N0 = Cin;
     a.idx = split ? t.bwd1 : (stride == 2 ? t.bwd_perm : t.bwd); a.dcode = dm.code; a.side = side; a.side2 = side2;
     a.n_slots = dm.n_slots; a.perm = t.perm; a.mask32 = t.mask32;
+    a.mask32_host = t.mask32_h.empty() ? nullptr : t.mask32_h.data(); a.mask_key = t.key;
     a.M = B * t.Pin; a.Ps = t.Pout; a.Pd = t.Pin; a.K = C; a.N = Cin; a.E = split ? 1 : t.E; a.ns = t.n_out;
     a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pout;
     a.sk_part = sk_part; a.sk_flag = sk_flag;             // (only the main launch: the flags are cleared once per call)
@@ -1198,6 +1203,27 @@ long icn_table_stream_k(int ntiles, int grid, int nk, int ku, int32_t* out, size
             }
         }
         return (long)n;
+    } catch (const std::exception& e) {
+        fail(e.what());
+        return -1;
+    }
+}
+
+long icn_table_tile_lists(int r_in, int stride, int corner_mode, int B, int bm, int ntn, int grid, int32_t* out, size_t cap) {
+    try {
+        if (r_in < 1 || r_in > 8 || stride != 2 || B < 1 || (bm != 64 && bm != 128) || ntn < 1 || grid < 8 || grid % 256 != 0)
+            throw std::invalid_argument("icn_table_tile_lists: stride-2 tables, bm 64 / 128, grid a multiple of 256");
+        std::vector<int32_t> bwd, perm;
+        std::vector<uint8_t> mask;
+        const int E = icn::build_conv_bwd(r_in, stride, corner_mode, bwd);
+        icn::build_bwd_row_order(r_in, stride, bwd, E, perm, mask);
+        const std::vector<uint32_t> m32(mask.begin(), mask.end());
+        const int Pd = icn::pixels(r_in), M = B * Pd, ntiles = ((M + bm - 1) / bm) * ntn;
+        std::vector<int> h;
+        icn::build_tile_lists(m32.data(), M, Pd, bm, ntn, ntiles, grid, grid / 256, h);
+        if (out)
+            for (size_t i = 0; i < h.size() && i < cap; ++i) out[i] = h[i];
+        return (long)h.size();
     } catch (const std::exception& e) {
         fail(e.what());
         return -1;

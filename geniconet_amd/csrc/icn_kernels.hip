@@ -413,7 +413,8 @@ __device__ __forceinline__ void conv_dma_body(
     int* __restrict__ sk_status,        // SK: the device's asynchronous failure word (pinned host memory, icn_device_status)
     int sk_spin_limit,                  // SK: polls before a partner counts as lost; < 0: fault injection (tests): lost at once
     unsigned long long* __restrict__ trace,     // developer: 8 timestamps (100 MHz) per block, or null (icn_debug_trace)
-    const int* __restrict__ sk_bnd) {   // SK: range boundaries of the launch's two residue-class sizes, [2][G / 8 + 1] (sk_tables)
+    const int* __restrict__ sk_bnd,     // SK: range boundaries of the launch's two residue-class sizes, [2][G / 8 + 1] (sk_tables)
+    const int* __restrict__ tlist) {    // !SK: per-workgroup tile lists, [G + 1] offsets then the tile ids (tile_lists), or null: b, b + G, ...
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
     // T taps in wt / dcode (7 hex taps, or the virtual taps of a composite table); a tile runs at most 7 of them (its tap
     // mask), and the LDS offset table is indexed by a tap's RANK inside that mask.
@@ -640,12 +641,29 @@ __device__ __forceinline__ void conv_dma_body(
     if constexpr (SK) {
         if (!seg_fetch(tile, c_s0, c_s1)) return;         // more blocks than work (block-uniform, before any barrier)
     }
+    // Tile lists (launches whose tiles run different numbers of K-steps: tap masks): the host dealt the tiles of each residue
+    // class to its workgroups so that their step totals are even (launch_conv_dma_t).  The ids come through the scalar cache,
+    // two tiles ahead of the compute tile.
+    const int* const tl_ids = tlist ? tlist + gridDim.x + 1 : nullptr;
+    int tl_i = 0, tl_hi = 0, tl_pend = ntiles;
+    if constexpr (!SK) {
+        if (tlist) {
+            tl_i = tlist[blockIdx.x];
+            tl_hi = tlist[blockIdx.x + 1];
+            if (tl_i >= tl_hi) return;                    // no tile for this workgroup (block-uniform, before any barrier)
+            tile = tl_ids[tl_i];
+        }
+    }
     tile_origin(tile, m0, n0);
     build_first(m0, n0, tile_taps(m0));
     __syncthreads();
     if (trace) tr_t1 = __builtin_amdgcn_s_memrealtime();
     int slot = 0, eslot = 0;                              // offset-table slot / epilogue-table slot of the compute tile
     int next_tile = tile + gridDim.x;
+    if (!SK && tlist) {
+        next_tile = tl_i + 1 < tl_hi ? tl_ids[tl_i + 1] : ntiles;
+        tl_pend = tl_i + 2 < tl_hi ? tl_ids[tl_i + 2] : ntiles;
+    }
     int has_next = next_tile < ntiles;
     if constexpr (SK) has_next = seg_fetch(next_tile, n_s0, n_s1);
     int nm0 = m0, nn0 = n0;
@@ -935,6 +953,11 @@ _Pragma("unroll") \
         eslot = eslot == 2 ? 0 : eslot + 1;
         i_own = 1;                                        // the DMA pointer is already inside this tile
         next_tile = tile + gridDim.x;
+        if (!SK && tlist) {
+            next_tile = tl_pend;
+            ++tl_i;
+            tl_pend = tl_i + 2 < tl_hi ? tl_ids[tl_i + 2] : ntiles;
+        }
         has_next = next_tile < ntiles;
         c_s0 = n_s0;
         c_s1 = n_s1;
@@ -967,9 +990,10 @@ __global__ __launch_bounds__(256) void k_conv_dma(const float* __restrict__ src,
                                                    const float* __restrict__ side2, const int32_t* __restrict__ perm,
                                                    const uint32_t* __restrict__ mask32, int M, int Ps, int Pd, int K, int N, int N0,
                                                    int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles, int T_arg,
-                                                   const RowSegs segs) {
+                                                   const RowSegs segs, unsigned long long* __restrict__ trace,
+                                                   const int* __restrict__ tlist) {
     conv_dma_body<BM, BN, SEG, false>(src, src2, wt, bias, dst, dst2, dcode, side, side2, perm, mask32, M, Ps, Pd, K, N, N0, n_slots,
-                                      src_bytes, side_bytes, ntiles, T_arg, segs, 4, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
+                                      src_bytes, side_bytes, ntiles, T_arg, segs, 4, nullptr, nullptr, nullptr, 0, trace, nullptr, tlist);
 }
 
 // Stream-K form: same tiles, same K-step pipeline; the last 1 + frac rounds of tiles are cut into equal k-chunk ranges (sk_plan),
@@ -988,13 +1012,78 @@ __global__ __launch_bounds__(256) void k_conv_dma_sk(const float* __restrict__ s
                                                       int* __restrict__ sk_status, int sk_spin_limit,
                                                       unsigned long long* __restrict__ trace, const int* __restrict__ sk_bnd) {
     conv_dma_body<BM, BN, SEG, true>(src, src2, wt, bias, dst, dst2, dcode, side, side2, SEG ? perm : nullptr, nullptr, M, Ps, Pd, K, N, N0, n_slots,
-                                     src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd);
+                                     src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
 }
 
 // dynamic LDS of k_conv_dma: A/B rings, offset table, destination-row table (row permutation only), bias (bias only)
 static size_t conv_dma_lds(int bm, int bn, bool perm, bool bias) {
     return (size_t)3 * (bm + bn) * BK * 4 + (size_t)2 * 7 * bm * 4 + (perm ? (size_t)3 * bm * 4 : 0) + (bias ? (size_t)3 * bn * 4 : 0) +
            16;   // + the stream-K form's block-uniform "partner lost" word
+}
+
+// Tile lists of a masked launch (stride-2 data gradients: a tile runs the taps of its rows' lattice class, 1 or 2 of the 7, so
+// tiles differ 2 : 1 in K-steps).  Dealt round-robin (b, b + G, ...) the workgroups' step totals differ by up to 30 %
+// (icn_debug_trace on the 128 -> 2x256 block's data gradient: exits from 156 to 278 us, 75 % of the block slots used).  Here
+// each residue class's tiles (one XCD, one L2: the same set as before) are dealt longest-first to the workgroup that would
+// finish it earliest given the speed factor of its arrival slot (sk_speed_factors), then sorted by id within a workgroup.
+// Layout: [G + 1] offsets, then the ids.  Built once per (device, table set, launch shape) and kept.
+const int* sk_speed_factors(int occ);
+void build_tile_lists(const uint32_t* mask32_host, int M, int Pd, int bm, int ntn, int ntiles, int grid, int occ, std::vector<int>& h) {
+    const int GL = grid / 8;
+    const int* fac = sk_speed_factors(occ);
+    h.assign((size_t)grid + 1 + ntiles, 0);
+    std::vector<std::vector<int>> lists(grid);
+    const int q = ntiles / 8, rem = ntiles % 8;
+    for (int x = 0; x < 8; ++x) {
+        // tiles of class x and their step counts (relative: taps in use; the k-chunk count scales all alike)
+        std::vector<std::pair<int, int>> tl;              // (taps, tile id)
+        for (int tile = x; tile < ntiles; tile += 8) {
+            const int sw = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + tile / 8;   // as tile_origin
+            const int m0 = (sw / ntn) * bm;
+            unsigned mk = 0;
+            for (int g2 = 0; g2 < bm / 32; ++g2)
+                if (m0 + 32 * g2 < M) mk |= mask32_host[((m0 + 32 * g2) % Pd) >> 5];
+            tl.emplace_back(std::max(1, __builtin_popcount(mk)), tile);
+        }
+        std::stable_sort(tl.begin(), tl.end(), [](const std::pair<int, int>& u, const std::pair<int, int>& v) { return u.first > v.first; });
+        std::vector<double> load(GL, 0.0);
+        for (const auto& e : tl) {
+            int best = 0;
+            double best_t = 0;
+            for (int bl = 0; bl < GL; ++bl) {
+                const double f = fac ? fac[(int)((long)bl * occ / GL)] / 1000.0 : 1.0;
+                const double tdone = (load[bl] + e.first) / f;
+                if (bl == 0 || tdone < best_t) { best = bl; best_t = tdone; }
+            }
+            load[best] += e.first;
+            lists[best * 8 + x].push_back(e.second);
+        }
+    }
+    int off = 0;
+    for (int b = 0; b < grid; ++b) {
+        std::sort(lists[b].begin(), lists[b].end());
+        h[b] = off;
+        for (int id : lists[b]) h[(size_t)grid + 1 + off++] = id;
+    }
+    h[grid] = off;
+}
+static const int* tile_lists(const GatherGemmArgs& a, int bm, int bn, int ntiles, int grid, int occ) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int, int, int>, int*> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int ntn = a.N / bn;
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_tuple(dev, a.mask_key, a.M, bm, ntn, grid, a.Pd);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    std::vector<int> h;
+    build_tile_lists(a.mask32_host, a.M, a.Pd, bm, ntn, ntiles, grid, occ, h);
+    int* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), h.size() * sizeof(int)) != hipSuccess ||
+        hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        throw std::runtime_error("icn: cannot upload the tile lists");
+    return cache.emplace(key, d).first->second;
 }
 
 template <int BM, int BN, bool SEG>
@@ -1013,12 +1102,16 @@ static void launch_conv_dma_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
     const size_t nb = a.segs.nseg > 0 ? (size_t)a.segs.B : (size_t)(a.M / a.Pd);          // samples
     const unsigned src_bytes = (unsigned)(nb * a.Ps * Ks * 4);
     const unsigned side_bytes = (unsigned)(nb * a.n_slots * Ks * 4);
+    const int* tlist = nullptr;
+    if (!SEG && a.mask32 && a.mask32_host && a.mask_key && grid % 8 == 0 && !(dbg_flags() & 512))
+        tlist = tile_lists(a, BM, BN, ntiles, grid, occ);
     prof_mark_begin((BM == 64 ? (BN == 128 ? PROF_DMA_64x128 : PROF_DMA_64x64) : (BN == 128 ? PROF_DMA_128x128 : PROF_DMA_128x64)) +
                         (SEG ? PROF_DMAS_128x128 - PROF_DMA_128x128 : 0),
                     a.algo_flops, s);
     hipLaunchKernelGGL((k_conv_dma<BM, BN, SEG>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2,
                        a.dcode, a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.mask32, a.M,
-                       a.Ps, a.Pd, a.K, a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs);
+                       a.Ps, a.Pd, a.K, a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs,
+                       g_trace_cap >= (size_t)grid * 8 ? g_trace : nullptr, tlist);
     prof_mark_end(s);
 }
 
@@ -1374,8 +1467,10 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
     float* __restrict__ partial,        // [S][7][Cin][Cout]
     float* __restrict__ bias_partial,   // [S][Cout] or null
     int M, int Ps, int Pd, int Cin, int Cout, int Cout0, int n_slots, int rows_per_split, int n_splits, unsigned x_bytes,
-    unsigned side_bytes, int y_taps) {
+    unsigned side_bytes, int y_taps, unsigned long long* __restrict__ trace) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long tr_t0 = 0;
+    if (trace) tr_t0 = __builtin_amdgcn_s_memrealtime();
     // y_taps = 7: dy is the tap-major aggregate g (M, 7, Cout) of icn_upconv_bwd -- tap t reads channels [t * Cout, (t+1) * Cout)
     // of a row of 7 * Cout floats -- and dcode is ONE table [Pd] shared by the taps (the rows of x are not shifted).
     constexpr int TI = BI / 64, TJ = BJ / 64;
@@ -1402,7 +1497,7 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
     const int ci0 = (tile / ntj) * BI, co0 = (tile % ntj) * BJ;
     const int m_begin = split * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
-    const int nsteps = (m_end - m_begin + WG_RS - 1) / WG_RS;
+    const int nsteps = m_end > m_begin ? (m_end - m_begin + WG_RS - 1) / WG_RS : 0;   // (0: a split past the last row writes zeros)
     const bool do_bias = bias_partial != nullptr && t == 0 && ci0 == 0;   // block-uniform
 
     // the block's output-channel tile lies in one of the two dy tensors (block-uniform)
@@ -1577,6 +1672,12 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
                 out[(size_t)ci * Cout + co] = acc[i][j][r];
             }
     if (do_bias && tid < BJ) bias_partial[(size_t)split * Cout + co0 + tid] = bsum;
+    if (trace && tid == 0) {
+        unsigned long long* o = trace + (size_t)blockIdx.x * 8;
+        o[0] = tr_t0; o[1] = tr_t0; o[2] = tr_t0; o[3] = 0; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = 0;
+        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);
+    }
 #endif
 }
 
@@ -1802,22 +1903,23 @@ bool wgrad_pair_supported(int M, int Ps, int Pd, int Cin, int Cout0, int Cout1) 
 }
 
 // number of row splits (= partial slabs) each wgrad flavour uses; shared by the workspace query and the launch
+static int wgrad_base_splits(int M, int Cin, int Cout, int Cout0) {     // MFMA kernels
+    // One block per (ci tile, co tile, tap, row split).  Measured on I5 / batch 36 (tools/bench_layers.py with
+    // ICN_WG_MULT = 0.75 ... 6): about three rounds of blocks over the chip's co-resident block slots is best -- one
+    // exactly filled round of long blocks is 15 % slower (blocks drift apart and the tail idles), many more rounds
+    // only add partial-slab traffic.
+    const int bi = (Cin % 128 == 0) ? 128 : 64, bj = wgrad_bj(Cout, Cout0);
+    const long tiles = 7L * (Cin / bi) * (Cout / bj);
+    static const double mult = getenv("ICN_WG_MULT") ? atof(getenv("ICN_WG_MULT")) : 3.0;   // developer override
+    long s = (long)(mult * 256L * wgrad_occ(bi, bj) / tiles);
+    const long max_s = (M + 255) / 256;                    // >= 16 stages of 16 rows per block
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    return (int)s;
+}
 int wgrad_splits(int M, int Cin, int Cout, int Cout0) {
     if (Cout0 <= 0 || Cout0 > Cout) Cout0 = Cout;
-    if (wgrad_supported(Cin, Cout)) {
-        // One block per (ci tile, co tile, tap, row split).  Measured on I5 / batch 36 (tools/bench_layers.py with
-        // ICN_WG_MULT = 0.75 ... 6): about three rounds of blocks over the chip's co-resident block slots is best -- one
-        // exactly filled round of long blocks is 15 % slower (blocks drift apart and the tail idles), many more rounds
-        // only add partial-slab traffic.
-        const int bi = (Cin % 128 == 0) ? 128 : 64, bj = wgrad_bj(Cout, Cout0);
-        const long tiles = 7L * (Cin / bi) * (Cout / bj);
-        static const double mult = getenv("ICN_WG_MULT") ? atof(getenv("ICN_WG_MULT")) : 3.0;   // developer override
-        long s = (long)(mult * 256L * wgrad_occ(bi, bj) / tiles);
-        const long max_s = (M + 255) / 256;                    // >= 16 stages of 16 rows per block
-        if (s > max_s) s = max_s;
-        if (s < 1) s = 1;
-        return (int)s;
-    }
+    if (wgrad_supported(Cin, Cout)) return wgrad_base_splits(M, Cin, Cout, Cout0);
     if (stem_supported(Cin, Cout)) return std::min(2048, (M + 255) / 256);
     return std::min(512, (M + 127) / 128);
 }
@@ -1845,7 +1947,8 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         if (dma)                                                                                                           \
             hipLaunchKernelGGL((k_wgrad_dma<I, J>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.dy2, a.dcode,                  \
                                a.n_slots > 0 ? a.side : nullptr, a.partial, a.bias_partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout,   \
-                               a.y_taps ? a.Cout : Cout0, a.n_slots, rows, S, (unsigned)x_bytes, (unsigned)side_bytes, a.y_taps); \
+                               a.y_taps ? a.Cout : Cout0, a.n_slots, rows, S, (unsigned)x_bytes, (unsigned)side_bytes, a.y_taps, \
+                               g_trace_cap >= (size_t)grid.x * 8 ? g_trace : nullptr); \
         else                                                                                                               \
             hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M,   \
                                a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows, S);                                                  \

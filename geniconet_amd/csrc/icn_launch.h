@@ -37,6 +37,8 @@ struct GatherGemmArgs {
     int n_slots;
     const int32_t* perm;    // [Pd] or null
     const uint32_t* mask32; // [Pd/32] tap mask per 32 rows (one word each: scalar loads), or null
+    const uint32_t* mask32_host;   // host copy of mask32 (stable pointer) or null; with mask_key != 0 the launcher deals the tiles
+    int mask_key;                  // of the launch to the workgroups by their step counts (tile lists, cached under this key)
     int M, Ps, Pd, K, N, E, ns;
     double algo_flops;      // algorithmic FLOPs of this launch (profiling only)
     int T;                  // taps of wt / dcode: 0 = the 7 hex taps; > 7: virtual taps of a composite table (LDS-DMA kernel only)
@@ -56,6 +58,11 @@ size_t conv_sk_part_bytes();                               // partial-tile slots
 // `occ` blocks per CU (1..3); returns the table or null (equal shares).  ICN_SK_FAC="a,b[,c]" overrides the defaults of the
 // matching occupancy, ICN_SK_FAC=0 switches the weighting off (developer A/B).
 const int* sk_speed_factors(int occ);
+}  // namespace icn
+#include <vector>
+namespace icn {
+// Tile lists of a masked launch (host side; icn_table_tile_lists): h = [grid + 1] offsets, then the tile ids of each workgroup
+void build_tile_lists(const uint32_t* mask32_host, int M, int Pd, int bm, int ntn, int ntiles, int grid, int occ, std::vector<int>& h);
 
 
 struct WgradArgs {
@@ -180,7 +187,8 @@ void launch_point_to_mesh(const float* pts, const float* vts, const int32_t* fac
                           int32_t* face, int32_t* kind, hipStream_t s);
 
 // developer routing flags (ICN_DEBUG / icn_set_debug_flags): 16 = convs on k_gather_gemm, 32 = wgrads on k_wgrad,
-// 128 = no stream-K, 256 = fault injection: every stream-K finisher reports its partners lost (tests of the failure path)
+// 128 = no stream-K, 256 = fault injection: every stream-K finisher reports its partners lost (tests of the failure path),
+// 512 = masked launches walk tiles b, b + G, ... instead of the balanced tile lists
 int debug_flags();
 int set_debug_flags(int flags);
 

@@ -222,6 +222,11 @@ long icn_table_faces(int r, int32_t* out, size_t cap);                          
  * A row with k1 < nk is a piece the workgroup parks for the workgroup that holds the tile's last steps (k0 > 0, k1 == nk).
  * (ABI 4: ranges are K-steps; up to ABI 3 they were whole k-chunks, multiples of ku.) */
 long icn_table_stream_k(int ntiles, int grid, int nk, int ku, int32_t* out, size_t cap);
+/* The tile lists of a stride-2 data-gradient launch (batch B at input level r_in, tiles of bm rows x ntn column tiles, `grid`
+ * workgroups = 256 x blocks per CU): [grid + 1] offsets, then each workgroup's tile ids.  Tiles of such a launch run 1 or 2
+ * of the 7 taps; the lists deal every residue class's tiles (tile % 8 = workgroup % 8) so that the workgroups' K-step totals
+ * are even. */
+long icn_table_tile_lists(int r_in, int stride, int corner_mode, int B, int bm, int ntn, int grid, int32_t* out, size_t cap);
 /* Composite table of conv_stride1(upsample(x)) over the COARSE tensor (icn_upconv_*; csrc/icn_geometry.h UpconvTable):
  * meta[7] = {P_fine, P_coarse, n_slots, E, nseg, NV (virtual taps), number of floats};
  * ints = seg[nseg][3] (rows per sample, first list position, virtual-tap mask) | pix[P_fine] (class-major list of fine
@@ -251,7 +256,8 @@ int icn_profile_select(const char* kernel);
 
 /* Developer routing flags (same bits as the ICN_DEBUG environment variable, which only sets the initial value):
  * 16 = convolutions on the register-staged fallback kernel, 32 = weight gradients on it, 128 = no stream-K (every tile of
- * the persistent GEMM computed whole by one workgroup), 256 = fault injection for the tests of the failure path below (every
+ * the persistent GEMM computed whole by one workgroup), 512 = masked launches walk tiles b, b + G, ... instead of the balanced
+ * tile lists, 256 = fault injection for the tests of the failure path below (every
  * stream-K finisher reports its partners lost).  Returns the previous flags. */
 int icn_set_debug_flags(int flags);
 

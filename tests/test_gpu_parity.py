@@ -270,6 +270,38 @@ def test_stream_k_in_the_decoder_heads_dense_gemms(r, cin, cout, B):
     assert any(k.startswith('k_conv_dma_sk') and k.endswith('true>') for k in seen), seen
 
 
+@pytest.mark.parametrize('r,cin,cout,B,pair', [(4, 128, 256, 36, True), (5, 64, 128, 12, True), (3, 256, 256, 36, False), (3, 256, 512, 5, True)])
+def test_balanced_tile_lists_equal_the_round_robin_walk(r, cin, cout, B, pair):
+    """Stride-2 data gradients: the tiles of such a launch run 1 or 2 of the 7 taps, and the launcher deals them to the
+    workgroups by their step counts (tile lists, debug flag 512 = the round-robin walk b, b + G, ... of rounds 1-2).  A tile is
+    computed whole by one workgroup either way, so the results must be BIT-identical."""
+    from geniconet_amd import _lib
+    from geniconet_amd.ico_conv import ico_conv, ico_conv_pair
+    g = torch.Generator().manual_seed(r * 10 + cin)
+    n = 2 ** r
+    ws = [(torch.randn(cout, cin, 7, generator=g) / (7 * cin) ** 0.5).cuda() for _ in range(2)]
+
+    def run(flags, x, gy):
+        old = _lib.lib().icn_set_debug_flags(flags)
+        try:
+            xs = x.clone().requires_grad_()
+            if pair:
+                ys = ico_conv_pair(xs, ws[0], None, ws[1], None, r, 2, 'average')
+            else:
+                ys = (ico_conv(xs, ws[0], None, r, 2, 'average'),)
+            torch.autograd.backward(ys, gy[:len(ys)])
+            torch.cuda.synchronize()
+            return xs.grad
+        finally:
+            _lib.lib().icn_set_debug_flags(old)
+    for trial in range(2):
+        x = torch.randn(B, cin, 5 * n, 2 * n, generator=g).cuda()
+        gy = [torch.randn(B, cout, 5 * n // 2, n, generator=g).cuda() for _ in range(2)]
+        a, b = run(0, x, gy), run(512, x, gy)
+        assert torch.equal(a, b), trial
+        assert bool(torch.isfinite(a).all())
+
+
 def test_a_lost_stream_k_partner_is_loud():
     """The failure path of the stream-K GEMM, by fault injection (debug flag 256: every finisher reports its partners lost):
     the tile becomes NaN AND the device's asynchronous status word is set, which icn_device_status returns (and clears) and

@@ -33,16 +33,15 @@ def _zero_true_gradient(key):
 # ---- (a) training trajectory: reference run.py:244-254 over several batches -------------------------------------------------
 def _fixed_noise(monkeypatch, R, B, steps):
     """The same reparameterisation noise on both sides: the product draws it with torch.randn_like as the reference does
-    (models.py:91); every (device, step) pair gets the step's tensor."""
+    (models.py:91); every draw of step state['k'] (set by the test) gets that step's tensor, on any device, in any dtype."""
     n = 2 ** (R - 3)
     noise = [torch.randn(B, 512, 5 * n, 2 * n, generator=torch.Generator().manual_seed(70 + k)) for k in range(steps)]
-    draws = {'cuda': 0, 'cpu': 0}
+    state = {'k': 0}
 
     def fixed_randn_like(t, **kw):
-        k = draws[t.device.type]
-        draws[t.device.type] += 1
-        return noise[k % steps].to(t.device)
+        return noise[state['k'] % steps].to(device=t.device, dtype=t.dtype)
     monkeypatch.setattr(torch, 'randn_like', fixed_randn_like)
+    return state
 
 
 def _ulp(t):
@@ -77,8 +76,7 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
     gpu = Trainer(p, 'cuda', model=_product(ref, name, R))
     cpu = Trainer(p, 'cpu', model=ref, criterion=build_criterion(p, 'cpu'), channels_last=False)
     assert type(gpu.optimizer).__module__ == 'geniconet_amd.optim'
-    if name == 'ico2ico_vae':
-        _fixed_noise(monkeypatch, R, B, STEPS)
+    noise_step = _fixed_noise(monkeypatch, R, B, STEPS) if name == 'ico2ico_vae' else {'k': 0}
     names = [k for k, _ in cpu.model.named_parameters()]
     pg, pc = dict(gpu.model.named_parameters()), dict(cpu.model.named_parameters())
     for k in range(STEPS):
@@ -92,6 +90,8 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
                 sg['step'].copy_(sc['step'])
         assert abs(gpu.optimizer.param_groups[0]['lr'] - cpu.optimizer.param_groups[0]['lr']) < 1e-15
         x, t = data.synthetic_batch(B, R, seed=40 + k)
+        noise_step['k'] = k
+        before_fwd = copy.deepcopy(cpu.model.state_dict())         # for the float64 arbiter below
         # -- 1. forward, loss, backward (run.py:244-250)
         outs = {}
         for tr, xx, tt in ((gpu, x.cuda().contiguous(memory_format=torch.channels_last), t.cuda()), (cpu, x, t)):
@@ -101,9 +101,23 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
             outs[tr.device.type] = float(loss)
         assert abs(outs['cuda'] - outs['cpu']) <= 1e-4 * abs(outs['cpu']), (k, outs)
         floor = 1e-3 * max(float(q.grad.norm()) for q in pc.values())
+        g64 = None
         for key in names:
             err = float((pg[key].grad.cpu() - pc[key].grad).norm()) / max(float(pc[key].grad.norm()), floor)
-            assert err < 2e-3, (k, key, err)
+            if err >= 2e-3:
+                # Two fp32 evaluations of an ill-conditioned gradient (the stem's, behind 19 BatchNorms over as few as 30 values
+                # at this test size) can differ by more than the usual bound although both are as accurate as fp32 allows.  A
+                # float64 evaluation of the oracle arbitrates: the GPU gradient may be at most 1.5 x as far from it as the CPU's.
+                if g64 is None:
+                    ref64 = getattr(models_ref, name)(R=R).train()
+                    ref64.load_state_dict(before_fwd)
+                    ref64 = ref64.double()
+                    build_criterion(p, 'cpu').double()(ref64(x.double()), t.double()).backward()
+                    g64 = {kk: q.grad for kk, q in ref64.named_parameters()}
+                den = max(float(g64[key].norm()), floor)
+                e_gpu = float((pg[key].grad.cpu().double() - g64[key]).norm()) / den
+                e_cpu = float((pc[key].grad.double() - g64[key]).norm()) / den
+                assert e_gpu <= 1.5 * e_cpu + 5e-4, (k, key, err, e_gpu, e_cpu)
         sg, sc = gpu.model.state_dict(), cpu.model.state_dict()
         for key in sc:
             if 'num_batches_tracked' in key:
@@ -178,12 +192,12 @@ def test_checkpoint_save_load_next_step_identical_on_the_device(name, tmp_path, 
     R, B = 3, 3
     p = models.default_params(name, subdivisions=R)
     p[name].update(lr=1e-4, lr_base=1e-4, lr_max=1e-3)
-    if name == 'ico2ico_vae':
-        _fixed_noise(monkeypatch, R, B, 3)
+    noise_step = _fixed_noise(monkeypatch, R, B, 3) if name == 'ico2ico_vae' else {'k': 0}
     batches = [data.synthetic_batch(B, R, seed=60 + k) for k in range(3)]
     batches = [(x.cuda().contiguous(memory_format=torch.channels_last), t.cuda()) for x, t in batches]
     a = Trainer(p, 'cuda', seed=3)
-    for x, t in batches[:2]:
+    for k, (x, t) in enumerate(batches[:2]):
+        noise_step['k'] = k
         a.step(x, t)
     path = save_checkpoint(a, str(tmp_path), 2, val_loss=0.5)
     assert path is not None and path.endswith('%s_E2.pt' % name)
@@ -196,8 +210,7 @@ def test_checkpoint_save_load_next_step_identical_on_the_device(name, tmp_path, 
     b.optimizer.param_groups[0]['lr'] = a.optimizer.param_groups[0]['lr']
     for key, v in a.model.state_dict().items():
         assert torch.equal(v, b.model.state_dict()[key]), key
-    if name == 'ico2ico_vae':
-        _fixed_noise(monkeypatch, R, B, 1)                        # both next steps draw the same noise
+    noise_step['k'] = 2                                           # both next steps draw the same noise
     la, lb = a.step(*batches[2]), b.step(*batches[2])
     assert torch.equal(la, lb)
     sa, sb = a.model.state_dict(), b.model.state_dict()

@@ -104,3 +104,27 @@ def test_whole_rounds_and_tiny_launches_are_left_alone():
     assert (t[:, 2] == 0).all() and (t[:, 3] == 1).all() and len(t) == 40
     assert _lib.lib().icn_table_stream_k(100, 100, 4, 1, None, 0) < 0      # grid must be a multiple of 8
     assert _lib.lib().icn_table_stream_k(100, 512, 0, 4, None, 0) < 0      # nk, ku positive
+
+
+# ---- tile lists of masked launches (stride-2 data gradients) ------------------------------------------------------------------
+@pytest.mark.parametrize('r,B,bm,ntn,grid', [(4, 36, 64, 2, 768), (5, 36, 64, 1, 768), (3, 36, 64, 4, 768), (4, 36, 64, 1, 512),
+                                             (2, 3, 64, 4, 768), (5, 8, 64, 2, 768), (4, 36, 128, 2, 512)])
+def test_tile_lists_cover_every_tile_once_and_even_out_the_step_totals(r, B, bm, ntn, grid):
+    """icn_table_tile_lists: every tile in exactly one workgroup's list, lists ascending, residue class kept (tile % 8 =
+    workgroup % 8: the XCD / L2 association of the round-robin walk), and -- the point -- the workgroups' K-step totals, which
+    differ by up to 2 : 1 per tile, are even within each arrival slot's share (the k-th arrivals on a CU get the plan's speed
+    factor, icn_streamk.h), where the round-robin deal b, b + G, ... is off by tens of per cent."""
+    off, ids = _lib.table_tile_lists(r, B, bm, ntn, grid)
+    nt = len(ids)
+    assert off[0] == 0 and off[-1] == nt and (np.diff(off) >= 0).all()
+    assert sorted(ids.tolist()) == list(range(nt))
+    cnt = np.diff(off)
+    for b in range(grid):
+        mine = ids[off[b]:off[b + 1]]
+        assert (mine % 8 == b % 8).all() and (np.diff(mine) > 0).all()
+    if nt >= 4 * grid:
+        occ, per_slot = grid // 256, 256
+        for k in range(occ):
+            c = cnt[k * per_slot:(k + 1) * per_slot]
+            assert c.max() - c.min() <= max(2, c.mean() * 0.6), (k, c.min(), c.max())   # tile counts differ (1- and 2-tap tiles) ...
+        assert cnt[:256].mean() >= cnt[-256:].mean()                                    # ... and earlier arrivals never get less

@@ -30,16 +30,40 @@ def main():
     ap.add_argument('--cout', type=int, default=128)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--dump', default='')
+    ap.add_argument('--mode', default='fwd', choices=['fwd', 'dgrad', 'wgrad'])
+    ap.add_argument('--stride', type=int, default=1)
+    ap.add_argument('--pair', action='store_true')
     a = ap.parse_args()
     L = _lib.lib()
     n = 2 ** a.r
     x = torch.randn(a.batch, a.cin, 5 * n, 2 * n, device='cuda').contiguous(memory_format=torch.channels_last)
     w = torch.randn(a.cout, a.cin, 7, device='cuda') / (7 * a.cin) ** 0.5
     b = torch.randn(a.cout, device='cuda')
-    buf = torch.zeros(1024 * 8, dtype=torch.int64, device='cuda')
-    with torch.no_grad():
+    buf = torch.zeros(16384 * 8, dtype=torch.int64, device='cuda')
+    from geniconet_amd.ico_conv import ico_conv_pair
+    w2 = torch.randn(a.cout, a.cin, 7, device='cuda') / (7 * a.cin) ** 0.5
+    xs = x.clone().requires_grad_(a.mode == 'dgrad')
+    ws = [w.clone().requires_grad_(a.mode == 'wgrad'), w2.clone().requires_grad_(a.mode == 'wgrad')]
+    bs = [b.clone().requires_grad_(a.mode == 'wgrad'), b.clone().requires_grad_(a.mode == 'wgrad')]
+    if a.mode != 'fwd':
+        if a.pair:
+            ys = ico_conv_pair(xs, ws[0], bs[0], ws[1], bs[1], a.r, a.stride, 'average')
+        else:
+            ys = (ico_conv(xs, ws[0], bs[0], a.r, a.stride, 'average'),)
+        gys = [torch.randn_like(y) for y in ys]
+
+        def run():
+            torch.autograd.grad(ys, [xs] if a.mode == 'dgrad' else ws[:len(ys)] + bs[:len(ys)], gys, retain_graph=True)
+    else:
+        def run():
+            with torch.no_grad():
+                if a.pair:
+                    ico_conv_pair(x, w, b, w2, b, a.r, a.stride, 'average')
+                else:
+                    ico_conv(x, w, b, a.r, a.stride, 'average')
+    if True:
         for _ in range(3):
-            ico_conv(x, w, b, a.r, 1, 'average')
+            run()
         torch.cuda.synchronize()
         for rep in range(a.reps):
             buf.zero_()
@@ -47,13 +71,35 @@ def main():
             L.icn_debug_trace(buf.data_ptr(), buf.numel())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            ico_conv(x, w, b, a.r, 1, 'average')
+            run()
             e1.record()
             torch.cuda.synchronize()
             L.icn_debug_trace(None, 0)
             t = buf.cpu().numpy().reshape(-1, 8)
             t = t[t[:, 0] != 0]
             G = len(t)
+            if a.mode == 'wgrad':
+                t0 = t[:, 0].min()
+                ent, ext = (t[:, 0] - t0) / 100.0, (t[:, 4] - t0) / 100.0
+                dur = ext - ent
+                print('rep %d: %d wgrad workgroups, call %.1f us by events, first entry -> last exit %.1f us' % (
+                    rep, G, e0.elapsed_time(e1) * 1e3, ext.max()))
+                pct(dur, 'workgroup duration')
+                pct(ent, 'entry at')
+                pct(ext, 'exit at')
+                # resident workgroups over time -> utilisation of the block slots
+                ev = sorted([(v, 1) for v in ent] + [(v, -1) for v in ext])
+                cur, last, area, peak = 0, 0.0, 0.0, 0
+                for tt, d in ev:
+                    area += cur * (tt - last)
+                    last = tt
+                    cur += d
+                    peak = max(peak, cur)
+                print('  peak resident %d; mean resident / peak over the span = %.1f %%' % (peak, 100.0 * area / (peak * ext.max())))
+                for lo in range(0, int(ext.max()) + 1, 20):
+                    n = int(((ent <= lo) & (ext > lo)).sum())
+                    print('    t = %4d us: %4d resident' % (lo, n))
+                continue
             t0 = t[:, 0].min()
             us = lambda col: (t[:, col] - t0) / 100.0
             end = us(4)
