@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -133,8 +135,63 @@ EllSplitDev upload_ell_split(const icn::Ell& e, int W_main) {
 
 // device tables of the aggregated paths of the decoder-block head: dy -> g (icn_upconv_bwd) and z -> y (dense forward of
 // icn_upconv_fwd) as split ELL matrices; iota = identity table [Pc] (the coarse-level GEMMs do not gather)
+// Patch tables of the LDS-staged sparse passes (icn_launch.h: PatchTab): the outputs (a grid of H x W pixels, row-major ids)
+// are tiled by ph x pw patches; prow [npatch][umax] lists the union of the source rows of a patch's outputs, plocal [H * W][width]
+// gives each output's entries as positions in that list.  idx [H * W][width_in] (negative: none); only the first `width`
+// entries of a row are used (the rest stays with the overflow pass).  umax is rounded up to a multiple of 32.
+struct PatchHost { std::vector<int32_t> prow; std::vector<uint16_t> plocal; int npatch = 0, umax = 0, gridW = 0; };
+bool build_patches(const std::vector<int32_t>& idx, int width_in, int width, int H, int W, int ph, int pw, PatchHost& out) {
+    out = PatchHost{};
+    if (H % ph != 0 || W % pw != 0 || (long)H * W * width_in != (long)idx.size()) return false;
+    const int pr_n = H / ph, pc_n = W / pw;
+    out.npatch = pr_n * pc_n;
+    out.gridW = W;
+    out.plocal.assign((size_t)H * W * width, 0xFFFFu);
+    std::vector<std::vector<int32_t>> lists(out.npatch);
+    for (int p = 0; p < out.npatch; ++p) {
+        std::vector<int32_t>& u = lists[p];
+        for (int i = 0; i < ph; ++i)
+            for (int j = 0; j < pw; ++j) {
+                const size_t r = (size_t)((p / pc_n) * ph + i) * W + (p % pc_n) * pw + j;
+                for (int k = 0; k < width; ++k) {
+                    const int32_t v = idx[r * width_in + k];
+                    if (v >= 0) u.push_back(v);
+                }
+            }
+        std::sort(u.begin(), u.end());
+        u.erase(std::unique(u.begin(), u.end()), u.end());
+        out.umax = std::max(out.umax, (int)u.size());
+    }
+    out.umax = (out.umax + 31) / 32 * 32;
+    if (out.umax == 0 || out.umax >= 0xFFFF) return false;
+    out.prow.assign((size_t)out.npatch * out.umax, -1);
+    for (int p = 0; p < out.npatch; ++p) {
+        const std::vector<int32_t>& u = lists[p];
+        std::copy(u.begin(), u.end(), out.prow.begin() + (size_t)p * out.umax);
+        for (int i = 0; i < ph; ++i)
+            for (int j = 0; j < pw; ++j) {
+                const size_t r = (size_t)((p / pc_n) * ph + i) * W + (p % pc_n) * pw + j;
+                for (int k = 0; k < width; ++k) {
+                    const int32_t v = idx[r * width_in + k];
+                    if (v >= 0) out.plocal[r * width + k] = (uint16_t)(std::lower_bound(u.begin(), u.end(), v) - u.begin());
+                }
+            }
+    }
+    return true;
+}
+struct PatchDev { int32_t* prow = nullptr; uint16_t* plocal = nullptr; int npatch = 0, umax = 0, gridW = 0; };
+PatchDev upload_patches(const PatchHost& h) {
+    PatchDev d;
+    if (getenv("ICN_VERBOSE")) fprintf(stderr, "icn: patch table: %d patches, %d rows per list, grid width %d\n", h.npatch, h.umax, h.gridW);
+    d.prow = upload(h.prow);
+    d.plocal = upload(h.plocal);
+    d.npatch = h.npatch; d.umax = h.umax; d.gridW = h.gridW;
+    return d;
+}
+
 struct UpconvBwdDev {
     int Pc = 0, Pf = 0;
+    PatchDev sc_patch, ga_patch;   // LDS-staged forms of the scatter (fine outputs) and of the per-pixel aggregate (coarse outputs)
     EllSplitDev gather, scatter;   // gather: the rows of the pixels the per-pixel kernel cannot take (main part unused, W = 0)
     int32_t* iota = nullptr;
     int32_t* px_srcs = nullptr;    // [Pc][20] fine rows of a coarse pixel's 7 aggregates (-1 padded; all -1: generic kernel)
@@ -333,6 +390,11 @@ UpconvBwdDev make_upconv_bwd_tables(int r_in, int mode) {
         rest.rows = (int)rest_rows.size();
         d.n_cls = (int)seen.size();
         d.px_srcs = upload(srcs);
+        {   // coarse pixel grid (5n x 2n) in patches of 4 x 8
+            const int n = 1 << r_in;
+            PatchHost ph;
+            if (build_patches(srcs, NS, NS, 5 * n, 2 * n, 4, 8, ph)) d.ga_patch = upload_patches(ph);
+        }
         d.px_cls = upload(cls);
         d.cls_coef = upload(cls_coef);
         d.gather = EllSplitDev{};
@@ -343,6 +405,12 @@ UpconvBwdDev make_upconv_bwd_tables(int r_in, int mode) {
         d.gather.ovf_coef = upload(rest.coef);
     }
     d.scatter = upload_ell_split(f, 16);           // 12-13 entries per fine pixel
+    {   // fine pixel grid (10n x 4n) in patches of 8 x 16; the main part's 16 entries per row
+        const int n = 1 << r_in;
+        PatchHost ph;
+        if (f.width >= 1 && build_patches(f.idx, f.width, std::min(f.width, 16), 10 * n, 4 * n, 8, 16, ph) && std::min(f.width, 16) == 16)
+            d.sc_patch = upload_patches(ph);
+    }
     std::vector<int32_t> iota(d.Pc);
     for (int i = 0; i < d.Pc; ++i) iota[i] = i;
     d.iota = upload(iota);
@@ -911,7 +979,11 @@ int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const fl
             icn::launch_gather_gemm_auto(a, s);
             const EllSplitDev& sc = d.scatter;
             const float* bias = w1 ? bias_cat : bias0;
-            icn::launch_upconv_scatter(z, bias, y0, y1, sc.idx, sc.coef, nullptr, B, 7 * d.Pc, d.Pf, d.Pf, Cout0, Cout1, sc.W, 0, s);
+            const icn::PatchTab pt{d.sc_patch.prow, d.sc_patch.plocal, d.sc_patch.npatch, d.sc_patch.umax, d.sc_patch.gridW};
+            if (sc.W == 16 && icn::upconv_patch_usable(pt, B, (size_t)7 * d.Pc, Cout0, Cout1))
+                icn::launch_upconv_scatter_lds(z, bias, y0, y1, pt, sc.coef, B, 7 * d.Pc, d.Pf, Cout0, Cout1, s);
+            else
+                icn::launch_upconv_scatter(z, bias, y0, y1, sc.idx, sc.coef, nullptr, B, 7 * d.Pc, d.Pf, d.Pf, Cout0, Cout1, sc.W, 0, s);
             icn::launch_upconv_scatter(z, nullptr, y0, y1, sc.ovf_idx, sc.ovf_coef, sc.ovf_rows, B, 7 * d.Pc, sc.n_ovf, d.Pf, Cout0, Cout1,
                                        sc.W_ovf, 1, s);
             ICN_HIP(hipGetLastError());
@@ -1001,7 +1073,11 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
         float* g = reinterpret_cast<float*>(at(ws, wo.g));
         // 1. g[b, s, t, :] = sum_p U[nbr_t(p), s] [dy0 | dy1][b, p, :]
         const EllSplitDev& ga = t.gather;
-        icn::launch_upconv_gather_px(dy0, dy1, g, t.px_srcs, t.px_cls, t.cls_coef, t.n_cls, B, t.Pf, t.Pc, Cout0, Cout1, s);
+        const icn::PatchTab pt{t.ga_patch.prow, t.ga_patch.plocal, t.ga_patch.npatch, t.ga_patch.umax, t.ga_patch.gridW};
+        if (icn::upconv_patch_usable(pt, B, (size_t)t.Pf, Cout0, Cout1))
+            icn::launch_upconv_gather_lds(dy0, dy1, g, pt, t.px_cls, t.cls_coef, t.n_cls, B, t.Pf, t.Pc, Cout0, Cout1, s);
+        else
+            icn::launch_upconv_gather_px(dy0, dy1, g, t.px_srcs, t.px_cls, t.cls_coef, t.n_cls, B, t.Pf, t.Pc, Cout0, Cout1, s);
         icn::launch_upconv_gather(dy0, dy1, g, ga.ovf_idx, ga.ovf_coef, ga.ovf_rows, B, t.Pf, ga.n_ovf, 7 * t.Pc, Cout0, Cout1, ga.W_ovf, 0, s);
         if (dx) {
             // 2. dx[b, s, :] = g[b, s, (t, c)] . Wb[(t, c), :]: a dense GEMM, K = 7 * C (one "tap" whose gather is the identity)

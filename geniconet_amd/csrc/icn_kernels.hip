@@ -2137,6 +2137,218 @@ void launch_upconv_scatter(const float* z, const float* bias, float* y0, float* 
                        idx, coef, rows, B, zrows, nrows, Pout, C0, C1, W, acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// LDS-staged forms of the two sparse passes of the decoder-block head (round 3).  Both are stencils over the pixel grid: an
+// output pixel mixes 12-20 source rows, and neighbouring outputs share most of them.  The row-per-thread kernels above fetch
+// every source row of every output through the vector-memory path (12.5 resp. 20 16-byte loads per output and 4 channels) and
+// are bound by it (TD busy 85 %, 2.7-3.9 TB/s of useful bytes).  Here a workgroup owns a PATCH of the output grid (8 x 16 fine
+// pixels, resp. 4 x 8 coarse ones), brings the union of the patch's source rows -- 2.5 resp. 7.5 per output instead of 12.5 /
+// 20 -- into LDS by LDS-DMA, 32 channels (one 128-byte line per row) at a time, and every thread then mixes its output from
+// LDS.  The patch's row list and each output's positions in it come from a host-built table (icn_api.cpp: build_patches), so
+// chart seams, five-valent vertices and poles need no special code; outputs with more entries than the table's width keep their
+// overflow pass.  Three workgroups per CU cover each other's load phases.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int PATCH_CH = 32;                              // channels per pass: one 128-byte line per source row
+constexpr int PATCH_IT_MAX = 14;                          // row-list capacity: 14 x 32 = 448 rows (56 KB of LDS)
+
+// DMA the patch's rows (sample b, channels [c0, c0 + 32) of `src` with row stride Cs floats) into LDS rows_s[u][32]
+__device__ __forceinline__ void patch_stage(const float* __restrict__ src, unsigned src_bytes, const int32_t* __restrict__ prow_l,
+                                            int n_it, int b, int rows_per_sample, int Cs, int c0, float* rows_s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < PATCH_IT_MAX; ++it) {           // (constant trip count: prow_l stays in registers)
+        if (it < n_it) {
+            const int row = prow_l[it];                   // this lane's source row of instruction `it` (-1: zeros)
+            const unsigned off = row >= 0 ? ((unsigned)(b * rows_per_sample + row) * (unsigned)Cs + (unsigned)c0) * 4u + 16u * (lane & 7)
+                                          : 0xC0000000u;  // out of range: the buffer range check writes zeros
+            float* dst = rows_s + __builtin_amdgcn_readfirstlane((it * 32 + wave * 8) * PATCH_CH);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+        }
+    }
+#endif
+}
+
+constexpr int PS_W = 16;                                  // entries per output pixel of the scatter table
+constexpr int PS_PH = 8, PS_PW = 16;                      // patch of fine pixels
+__global__ __launch_bounds__(256, 3) void k_upconv_scatter_lds(const float* __restrict__ z, const float* __restrict__ bias,
+                                                             float* __restrict__ y0, float* __restrict__ y1,
+                                                             const int32_t* __restrict__ prow, const uint16_t* __restrict__ plocal,
+                                                             const float* __restrict__ coef, int B, int zrows, int Pout, int C0,
+                                                             int C1, int npatch, int umax, int gridW, int bgroup, int cgroup,
+                                                             unsigned z_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* rows_s = reinterpret_cast<float*>(smem);       // [umax][32]
+    const int C = C0 + C1, nchunk = C / PATCH_CH, n_it = umax / 32;
+    const int nbg = (B + bgroup - 1) / bgroup, ncg = (nchunk + cgroup - 1) / cgroup, items = npatch * nbg * ncg;
+    // XCD-contiguous item order: (sample group, channel group) outermost, patches of a chart next to each other inside one
+    // XCD's eighth
+    const int per = (items + 7) / 8, item = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (blockIdx.x / 8 >= per || item >= items) return;
+    const int patch = item % npatch, bg = (item / npatch) % nbg, cg = item / (npatch * nbg);
+    const int ch_end = min(nchunk, (cg + 1) * cgroup);
+    const int ppr = gridW / PS_PW;                        // patches per grid row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = tid >> 1, half = tid & 1;              // output pixel of the patch, 16-channel half of the pass
+    const int orow = ((patch / ppr) * PS_PH + px / PS_PW) * gridW + (patch % ppr) * PS_PW + px % PS_PW;
+    // this thread's entries: positions in the patch's row list + coefficients
+    int li[PS_W];
+    float cf[PS_W];
+    {
+        const uint16_t* lp = plocal + (size_t)orow * PS_W;
+        const float* cp = coef + (size_t)orow * PS_W;
+#pragma unroll
+        for (int e = 0; e < PS_W; ++e) {                  // (absent entries: the zero row behind the list, coefficient 0 -- no branches below)
+            const unsigned v = lp[e];
+            li[e] = (v == 0xFFFFu ? umax : (int)v) * PATCH_CH + half * 16;
+            cf[e] = v == 0xFFFFu ? 0.f : cp[e];
+        }
+    }
+    if (tid < PATCH_CH) rows_s[umax * PATCH_CH + tid] = 0.f;   // the zero row (never written by the DMA)
+    int32_t prow_l[PATCH_IT_MAX];                         // rows this lane stages: row (it * 32 + wave * 8 + lane / 8) of the list
+#pragma unroll
+    for (int it = 0; it < PATCH_IT_MAX; ++it)
+        prow_l[it] = it < n_it ? prow[(size_t)patch * umax + it * 32 + wave * 8 + (lane >> 3)] : -1;
+    const int b_end = min(B, (bg + 1) * bgroup);
+    for (int b = bg * bgroup; b < b_end; ++b)
+        for (int ch = cg * cgroup; ch < ch_end; ++ch) {
+            const int c0 = ch * PATCH_CH;
+            patch_stage(z, z_bytes, prow_l, n_it, b, zrows, C, c0, rows_s);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int c = c0 + half * 16;
+            f32x4 acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = bias ? ld4(bias + c + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < PS_W; ++e) {
+                const float* r = rows_s + li[e];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += cf[e] * ld4(r + 4 * q);
+            }
+            float* o = c < C0 ? y0 + ((size_t)b * Pout + orow) * C0 + c : y1 + ((size_t)b * Pout + orow) * C1 + (c - C0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(o + 4 * q) = acc[q];
+            __syncthreads();                              // every thread is done with rows_s before the next pass overwrites it
+        }
+#endif
+}
+
+// Passes (sample, 32-channel chunk) a workgroup of the patch kernels runs back to back on its patch: enough to amortise its
+// table loads (>= 4), few enough that even the coarsest level makes >= ~4 rounds of workgroups over the chip's slots
+static void patch_groups(int npatch, int B, int nchunk, int& bgroup, int& cgroup) {
+    const long passes = (long)npatch * B * nchunk;
+    long per = passes / (4L * 768);
+    per = per < 4 ? 4 : (per > 16 ? 16 : per);
+    cgroup = (int)std::min<long>(nchunk, per);
+    bgroup = (int)std::max<long>(1, per / cgroup);
+}
+
+void launch_upconv_scatter_lds(const float* z, const float* bias, float* y0, float* y1, const PatchTab& t, const float* coef, int B,
+                               int zrows, int Pout, int C0, int C1, hipStream_t s) {
+    int bgroup, cgroup;
+    patch_groups(t.npatch, B, (C0 + C1) / PATCH_CH, bgroup, cgroup);
+    const int items = t.npatch * ((B + bgroup - 1) / bgroup) * (((C0 + C1) / PATCH_CH + cgroup - 1) / cgroup);
+    const int grid = (items + 7) / 8 * 8;
+    const size_t lds = (size_t)(t.umax + 1) * PATCH_CH * 4;      // + the zero row
+    static std::atomic<uint64_t> attr_devices{0};
+    if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_upconv_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(k_upconv_scatter_lds, dim3(grid), dim3(256), lds, s, z, bias, y0, y1, t.prow, t.plocal, coef, B, zrows, Pout, C0,
+                       C1, t.npatch, t.umax, t.gridW, bgroup, cgroup, (unsigned)((size_t)B * zrows * (C0 + C1) * 4));
+}
+bool upconv_patch_usable(const PatchTab& t, int B, size_t rows_per_sample, int C0, int C1) {
+    if (dbg_flags() & 1024) return false;                 // developer: the row-per-thread kernels
+    if (t.prow == nullptr || t.umax < 32 || t.umax > 32 * PATCH_IT_MAX || t.umax % 32) return false;
+    if (C0 % PATCH_CH || C1 % PATCH_CH) return false;
+    return (size_t)B * rows_per_sample * std::max(C0 + C1, 1) * 4 < ((size_t)3 << 30);   // 32-bit buffer offsets below the zero code
+}
+
+// The aggregate of the composite backward on patches of 4 x 8 coarse pixels: a thread owns one coarse pixel and 4 channels for
+// all 7 taps; its <= 20 fine source rows are positions in the patch's row list (plocal [Pc][20]), the coefficient block comes
+// from the pixel's class (as in k_upconv_gather_px below).
+constexpr int PG_PH = 4, PG_PW = 8;
+__global__ __launch_bounds__(256, 3) void k_upconv_gather_lds(const float* __restrict__ dy0, const float* __restrict__ dy1,
+                                                            float* __restrict__ g, const int32_t* __restrict__ prow,
+                                                            const uint16_t* __restrict__ plocal, const int32_t* __restrict__ cls,
+                                                            const float* __restrict__ cls_coef, int ncls, int B, int Pin, int Pc,
+                                                            int C0, int C1, int npatch, int umax, int gridW, int bgroup, int cgroup) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* ctab = reinterpret_cast<f32x4*>(smem);         // [ncls][20][2]
+    float* rows_s = reinterpret_cast<float*>(ctab + UPCONV_PX_CLASSES * 20 * 2);   // [umax][32]
+    for (int i = threadIdx.x; i < ncls * 20 * 2; i += 256) ctab[i] = ld4(cls_coef + 4 * i);
+    const int C = C0 + C1, nchunk = C / PATCH_CH, n_it = umax / 32;
+    const int nbg = (B + bgroup - 1) / bgroup, ncg = (nchunk + cgroup - 1) / cgroup, items = npatch * nbg * ncg;
+    const int per = (items + 7) / 8, item = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (blockIdx.x / 8 >= per || item >= items) return;
+    const int patch = item % npatch, bg = (item / npatch) % nbg, cg = item / (npatch * nbg);
+    const int ch_end = min(nchunk, (cg + 1) * cgroup);
+    const int ppr = gridW / PG_PW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = tid >> 3, q = tid & 7;                 // coarse pixel of the patch, 16-byte chunk of the pass
+    const int sp = ((patch / ppr) * PG_PH + px / PG_PW) * gridW + (patch % ppr) * PG_PW + px % PG_PW;
+    int li[20];
+    {
+        const uint16_t* lp = plocal + (size_t)sp * 20;
+#pragma unroll
+        for (int k = 0; k < 20; ++k) { const unsigned v = lp[k]; li[k] = (v == 0xFFFFu ? umax : (int)v) * PATCH_CH + 4 * q; }
+    }
+    if (tid < PATCH_CH) rows_s[umax * PATCH_CH + tid] = 0.f;   // the zero row absent sources point at
+    const f32x4* cf = ctab + cls[sp] * 40;
+    int32_t prow_l[PATCH_IT_MAX];
+#pragma unroll
+    for (int it = 0; it < PATCH_IT_MAX; ++it)
+        prow_l[it] = it < n_it ? prow[(size_t)patch * umax + it * 32 + wave * 8 + (lane >> 3)] : -1;
+    const unsigned b0_bytes = (unsigned)((size_t)B * Pin * C0 * 4), b1_bytes = (unsigned)((size_t)B * Pin * C1 * 4);
+    const int b_end = min(B, (bg + 1) * bgroup);
+    __syncthreads();                                      // the class table is in place
+    for (int b = bg * bgroup; b < b_end; ++b)
+        for (int ch = cg * cgroup; ch < ch_end; ++ch) {
+            const int c0 = ch * PATCH_CH;
+            if (c0 < C0) patch_stage(dy0, b0_bytes, prow_l, n_it, b, Pin, C0, c0, rows_s);
+            else patch_stage(dy1, b1_bytes, prow_l, n_it, b, Pin, C1, c0 - C0, rows_s);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            f32x4 acc[7];
+#pragma unroll
+            for (int t = 0; t < 7; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 20; ++k) {
+                const f32x4 x = ld4(rows_s + li[k]);
+                const f32x4 ca = cf[k * 2], cb = cf[k * 2 + 1];
+                acc[0] += ca[0] * x; acc[1] += ca[1] * x; acc[2] += ca[2] * x; acc[3] += ca[3] * x;
+                acc[4] += cb[0] * x; acc[5] += cb[1] * x; acc[6] += cb[2] * x;
+            }
+            float* o = g + ((size_t)b * Pc + sp) * 7 * C + c0 + 4 * q;
+#pragma unroll
+            for (int t = 0; t < 7; ++t) *reinterpret_cast<f32x4*>(o + (size_t)t * C) = acc[t];
+            __syncthreads();
+        }
+#endif
+}
+
+void launch_upconv_gather_lds(const float* dy0, const float* dy1, float* g, const PatchTab& t, const int32_t* cls,
+                              const float* cls_coef, int ncls, int B, int Pin, int Pc, int C0, int C1, hipStream_t s) {
+    if (ncls < 1 || ncls > UPCONV_PX_CLASSES) throw std::invalid_argument("icn: coefficient classes of the per-pixel aggregate out of range");
+    int bgroup, cgroup;
+    patch_groups(t.npatch, B, (C0 + C1) / PATCH_CH, bgroup, cgroup);
+    const int items = t.npatch * ((B + bgroup - 1) / bgroup) * (((C0 + C1) / PATCH_CH + cgroup - 1) / cgroup);
+    const int grid = (items + 7) / 8 * 8;
+    const size_t lds = (size_t)UPCONV_PX_CLASSES * 20 * 2 * 16 + (size_t)(t.umax + 1) * PATCH_CH * 4;   // + the zero row
+    static std::atomic<uint64_t> attr_devices{0};
+    if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_upconv_gather_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(k_upconv_gather_lds, dim3(grid), dim3(256), lds, s, dy0, dy1, g, t.prow, t.plocal, cls, cls_coef, ncls, B, Pin, Pc,
+                       C0, C1, t.npatch, t.umax, t.gridW, bgroup, cgroup);
+}
+
 // Same aggregate, one thread per (sample, coarse pixel, 4 channels) for ALL 7 taps: the 7 rows g_t[s] of a pixel draw on the
 // same <= 20 fine rows (the two-ring of its site), each needed by 2-3 of the taps, so they are loaded once (20 loads instead
 // of 49) and spread over the taps with a dense (20 x 7, mostly zero) coefficient block.  k_upconv_gather above is bound by

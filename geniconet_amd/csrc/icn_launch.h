@@ -103,6 +103,16 @@ void launch_stem_fwd(const float* x, const float* w, const float* bias, float* y
 void launch_upconv_gather(const float* dy0, const float* dy1, float* g, const int32_t* idx, const float* coef, const int32_t* rows,
                           int B, int Pin, int nrows, int rows_total, int C0, int C1, int W, int acc, hipStream_t s);
 
+// LDS-staged forms of the two sparse passes (icn_kernels.hip): a workgroup owns a patch of the output grid; prow [npatch][umax] =
+// the union of the patch's source rows (-1 padded, umax a multiple of 32), plocal [outputs][W] = each output's entries as
+// positions in its patch's list (0xFFFF: none), gridW = width of the output pixel grid (patches tile it exactly)
+struct PatchTab { const int32_t* prow; const uint16_t* plocal; int npatch, umax, gridW; };
+bool upconv_patch_usable(const PatchTab& t, int B, size_t rows_per_sample, int C0, int C1);
+void launch_upconv_scatter_lds(const float* z, const float* bias, float* y0, float* y1, const PatchTab& t, const float* coef, int B,
+                               int zrows, int Pout, int C0, int C1, hipStream_t s);
+void launch_upconv_gather_lds(const float* dy0, const float* dy1, float* g, const PatchTab& t, const int32_t* cls,
+                              const float* cls_coef, int ncls, int B, int Pin, int Pc, int C0, int C1, hipStream_t s);
+
 // the same aggregate per coarse pixel for all 7 taps at once: srcs [Pc][20] fine rows (-1 padded), coefd [Pc][20][8]
 constexpr int UPCONV_PX_CLASSES = 32;   // capacity of k_upconv_gather_px's LDS coefficient-class table
 void launch_upconv_gather_px(const float* dy0, const float* dy1, float* g, const int32_t* srcs, const int32_t* cls,
@@ -188,7 +198,8 @@ void launch_point_to_mesh(const float* pts, const float* vts, const int32_t* fac
 
 // developer routing flags (ICN_DEBUG / icn_set_debug_flags): 16 = convs on k_gather_gemm, 32 = wgrads on k_wgrad,
 // 128 = no stream-K, 256 = fault injection: every stream-K finisher reports its partners lost (tests of the failure path),
-// 512 = masked launches walk tiles b, b + G, ... instead of the balanced tile lists
+// 512 = masked launches walk tiles b, b + G, ... instead of the balanced tile lists, 1024 = the sparse passes of the decoder-block
+// head on the row-per-thread kernels instead of the LDS-staged ones
 int debug_flags();
 int set_debug_flags(int flags);
 

@@ -257,7 +257,7 @@ int icn_profile_select(const char* kernel);
 /* Developer routing flags (same bits as the ICN_DEBUG environment variable, which only sets the initial value):
  * 16 = convolutions on the register-staged fallback kernel, 32 = weight gradients on it, 128 = no stream-K (every tile of
  * the persistent GEMM computed whole by one workgroup), 512 = masked launches walk tiles b, b + G, ... instead of the balanced
- * tile lists, 256 = fault injection for the tests of the failure path below (every
+ * tile lists, 1024 = the sparse passes of the decoder-block heads on the row-per-thread kernels, 256 = fault injection for the tests of the failure path below (every
  * stream-K finisher reports its partners lost).  Returns the previous flags. */
 int icn_set_debug_flags(int flags);
 

@@ -302,6 +302,37 @@ def test_balanced_tile_lists_equal_the_round_robin_walk(r, cin, cout, B, pair):
         assert bool(torch.isfinite(a).all())
 
 
+@pytest.mark.parametrize('r,cin,cout,B', [(2, 256, 256, 5), (3, 256, 128, 9), (4, 128, 64, 6), (2, 128, 64, 3)])
+def test_lds_staged_sparse_passes_equal_the_row_per_thread_kernels(r, cin, cout, B):
+    """The two sparse passes of the decoder-block head (z -> y of icn_upconv_fwd, dy -> g of icn_upconv_bwd) staged through LDS
+    by patches of the pixel grid (k_upconv_scatter_lds / k_upconv_gather_lds, round 3) against the row-per-thread kernels they
+    replace (debug flag 1024): same entries, same order of the sums -> equal to fp32 rounding of the FMA contraction (1e-6), for
+    outputs and every gradient.  (Both are checked against the oracle by the test_upconv_* cases.)"""
+    from geniconet_amd import _lib
+    from geniconet_amd.ico_conv import ico_upconv_pair
+    g = torch.Generator().manual_seed(r * 13 + cin)
+    n = 2 ** r
+    ws = [(torch.randn(cout, cin, 7, generator=g) / (7 * cin) ** 0.5).cuda().requires_grad_() for _ in range(2)]
+    bs = [torch.randn(cout, generator=g).cuda().requires_grad_() for _ in range(2)]
+    x = torch.randn(B, cin, 5 * n, 2 * n, generator=g).cuda()
+    gy = [torch.randn(B, cout, 10 * n, 4 * n, generator=g).cuda() for _ in range(2)]
+
+    def run(flags):
+        old = _lib.lib().icn_set_debug_flags(flags)
+        try:
+            xs = x.clone().requires_grad_()
+            ys = ico_upconv_pair(xs, ws[0], bs[0], ws[1], bs[1], r, 'average')
+            grads = torch.autograd.grad(ys, [xs] + ws + bs, gy)
+            torch.cuda.synchronize()
+            return [y.detach() for y in ys] + list(grads)
+        finally:
+            _lib.lib().icn_set_debug_flags(old)
+    new, ref = run(0), run(1024)
+    for a, b in zip(new, ref):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+        assert bool(torch.isfinite(a).all())
+
+
 def test_a_lost_stream_k_partner_is_loud():
     """The failure path of the stream-K GEMM, by fault injection (debug flag 256: every finisher reports its partners lost):
     the tile becomes NaN AND the device's asynchronous status word is set, which icn_device_status returns (and clears) and
