@@ -1364,7 +1364,8 @@ int icn_device_status(int clear) {
 }
 
 // ---- fused BatchNorm + ReLU ---------------------------------------------------------------------------------
-size_t icn_bn_workspace_floats(int M, int C) { return (M < 1 || C < 1) ? 0 : (size_t)icn::bn_chunks(M) * 4 * C; }
+// (the partial sums are doubles: twice the floats)
+size_t icn_bn_workspace_floats(int M, int C) { return (M < 1 || C < 1) ? 0 : (size_t)icn::bn_chunks(M) * 4 * C * 2; }
 
 int icn_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
                  float* ws, void* stream) {

