@@ -108,7 +108,7 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
                 # The gradient of this network is a DISCONTINUOUS function of the forward pass: a ReLU pre-activation within fp32
                 # rounding of zero (13 layers x 1e5 values at this test size: a few per evaluation are expected) passes or blocks
                 # its whole upstream gradient depending on which side the rounding lands, and one such flip moves the small
-                # cancelling sums of the BatchNorm backward below it by 1e-3 .. 1e-2 (measured: tools/_exp/diag_vae*.py; torch's
+                # cancelling sums of the BatchNorm backward below it by 1e-3 .. 1e-2 (measured: tools/diag_gradient_error.py; torch's
                 # own device kernels show the same).  So beyond the usual bound the question is whether the GPU result lies
                 # within what fp32-level perturbations do to the float64 gradient itself: the float64 oracle is re-evaluated
                 # with every weight and input perturbed by 1e-6 relative (the size of the forward's accumulated rounding),
