@@ -49,7 +49,7 @@ SIGNATURES = {
     'icn_bn_stats2': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int] + ([ctypes.c_float] * 2 + [_c_float_p] * 3) * 2 + [_c_float_p, ctypes.c_void_p]),
     'icn_bn_stats': (ctypes.c_int, [_c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float] + [_c_float_p] * 4 + [ctypes.c_void_p]),
     'icn_bn_relu_fwd': (ctypes.c_int, [_c_float_p] * 9 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
-    'icn_bn_relu_bwd': (ctypes.c_int, [_c_float_p] * 13 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
+    'icn_bn_relu_bwd': (ctypes.c_int, [_c_float_p] * 13 + [ctypes.c_int] * 2 + [_c_float_p] * 4 + [ctypes.c_void_p]),
     'icn_head_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),
     'icn_head_fwd': (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     'icn_head_bwd': (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),

@@ -1413,14 +1413,14 @@ int icn_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const f
 
 int icn_bn_relu_bwd(const float* dy, const float* a, const float* b, const float* stat_a, const float* stat_b, const float* gamma_a,
                     const float* beta_a, const float* gamma_b, const float* beta_b, float* da, float* db, float* sums, float* ws, int M,
-                    int C, void* stream) {
+                    int C, float* dbeta_a, float* dgamma_a, float* dbeta_b, float* dgamma_b, void* stream) {
     try {
         if (!dy || !a || !stat_a || !gamma_a || !beta_a || !da || !sums || !ws || M < 1)
             throw std::invalid_argument("icn_bn_relu_bwd: bad arguments");
         if (b && (!stat_b || !gamma_b || !beta_b || !db)) throw std::invalid_argument("icn_bn_relu_bwd: second input needs its buffers");
         if (!icn::bn_supported(C)) throw std::invalid_argument("icn_bn_relu_bwd: unsupported channel count");
-        icn::launch_bn_relu_bwd(dy, a, b, stat_a, stat_b, gamma_a, beta_a, gamma_b, beta_b, da, db, sums, ws, M, C,
-                                static_cast<hipStream_t>(stream));
+        icn::launch_bn_relu_bwd(dy, a, b, stat_a, stat_b, gamma_a, beta_a, gamma_b, beta_b, da, db, sums, ws, M, C, dbeta_a, dgamma_a,
+                                dbeta_b, dgamma_b, static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());
         return 0;
     } catch (const std::exception& e) {

@@ -216,14 +216,28 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd2(const BnFin fa, const 
     }
 }
 
-// backward finalize: sums[k][C] = sum over chunks (k < NS); blockIdx.y = k
+// backward finalize: sums[k][C] = sum over chunks (k < NS); blockIdx.y = k.  The same values also go to the parameter
+// gradients' own tensors (k = 0: dbeta of bn_a and, for the residual form, of bn_b; 1: dgamma_a; 2: dgamma_b), which may be
+// views into a DistributedDataParallel bucket (geniconet_amd/_gradbuf.py) -- `sums` stays the contiguous copy the apply pass reads.
+struct BnGradOut { float* dbeta_a; float* dbeta_b; float* dgamma_a; float* dgamma_b; };
 __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double* __restrict__ partial, int chunks, int C, int NS,
-                                                          float* __restrict__ sums) {
+                                                          float* __restrict__ sums, const BnGradOut out) {
     __shared__ double red[16][16];
     const int c = blockIdx.x * 16 + threadIdx.x % 16, slice = threadIdx.x / 16, k = blockIdx.y;
     double s;
     chunk_sums<1>(partial, chunks, NS, k, C, c, slice, red, &s);
-    if (slice == 0 && c < C) sums[k * C + c] = (float)s;
+    if (slice == 0 && c < C) {
+        const float v = (float)s;
+        sums[k * C + c] = v;
+        if (k == 0) {
+            if (out.dbeta_a) out.dbeta_a[c] = v;
+            if (out.dbeta_b) out.dbeta_b[c] = v;
+        } else if (k == 1) {
+            if (out.dgamma_a) out.dgamma_a[c] = v;
+        } else if (out.dgamma_b) {
+            out.dgamma_b[c] = v;
+        }
+    }
 }
 
 // y = relu(bn_a(a) [+ bn_b(b)])
@@ -302,13 +316,14 @@ void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, con
 
 void launch_bn_relu_bwd(const float* dy, const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga,
                         const float* ba, const float* gb, const float* bb, float* da, float* db, float* sums, float* ws, int M, int C,
-                        hipStream_t s) {
+                        float* dbeta_a, float* dgamma_a, float* dbeta_b, float* dgamma_b, hipStream_t s) {
     const int chunks = bn_chunks(M), rows = (M + chunks - 1) / chunks;
     const int NS = b ? 3 : 2;
     double* wsd = reinterpret_cast<double*>(ws);
     if (b) hipLaunchKernelGGL(k_bn_partial<2>, dim3(chunks), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, wsd, M, C, rows);
     else hipLaunchKernelGGL(k_bn_partial<1>, dim3(chunks), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, wsd, M, C, rows);
-    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((C + 15) / 16, NS), dim3(256), 0, s, wsd, chunks, C, NS, sums);
+    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((C + 15) / 16, NS), dim3(256), 0, s, wsd, chunks, C, NS, sums,
+                       BnGradOut{dbeta_a, b ? dbeta_b : nullptr, dgamma_a, b ? dgamma_b : nullptr});
     const size_t total4 = (size_t)M * C / 4;
     if (b) hipLaunchKernelGGL(k_bn_relu_bwd<1>, dim3(stream_blocks(total4)), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, sums, da, db, total4, C, 1.f / M);
     else hipLaunchKernelGGL(k_bn_relu_bwd<0>, dim3(stream_blocks(total4)), dim3(256), 0, s, dy, a, b, stat_a, stat_b, ga, ba, gb, bb, sums, da, db, total4, C, 1.f / M);

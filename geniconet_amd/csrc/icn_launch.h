@@ -165,7 +165,7 @@ void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, con
                         const float* gb, const float* bb, float* y, int M, int C, hipStream_t s);
 void launch_bn_relu_bwd(const float* dy, const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga,
                         const float* ba, const float* gb, const float* bb, float* da, float* db, float* sums, float* ws, int M, int C,
-                        hipStream_t s);
+                        float* dbeta_a, float* dgamma_a, float* dbeta_b, float* dgamma_b, hipStream_t s);   // parameter gradients (nullable)
 
 // ---- fused 1x1 head + tanh (icn_bn.hip); ws = head_chunks(M) * 4 * (Cin + 4) floats
 bool head_supported(int Cin, int Cout);

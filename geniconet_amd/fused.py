@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _gradbuf, _lib
 from .ico_conv import (_nhwc, _stream, ico_conv_pair, ico_conv_pair_supported, ico_upconv_pair,
                        ico_upconv_pair_supported)
 
@@ -109,6 +109,7 @@ class _BnReluFn(torch.autograd.Function):
                                          st), 'icn_bn_relu_fwd')
         ctx.save_for_backward(ap, bp, stat_a, stat_b, ga, ba, gb, bb)    # not y: the backward recomputes the ReLU mask
         ctx.dims = (M, C, dual)
+        ctx.params = (ga, ba, gb, bb)                    # where the parameter gradients go (_gradbuf.lease)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -123,16 +124,22 @@ class _BnReluFn(torch.autograd.Function):
         db = torch.empty_like(bp) if dual else None
         sums = torch.empty(3 * C, dtype=torch.float32, device=dev)
         ws = torch.empty(L.icn_bn_workspace_floats(M, C), dtype=torch.float32, device=dev)
+        # the parameter gradients in tensors of their own (the kernel writes them beside `sums`): a view into a DDP bucket when
+        # the trainer remembered one, else new
+        pga, pba, pgb, pbb = ctx.params
+        dga, dba = _gradbuf.lease(pga, (C,), dev), _gradbuf.lease(pba, (C,), dev)
+        dgb = _gradbuf.lease(pgb, (C,), dev) if dual else None
+        dbb = _gradbuf.lease(pbb, (C,), dev) if dual else None
         with torch.cuda.device(dev):
             _lib.check(L.icn_bn_relu_bwd(gyp.data_ptr(), ap.data_ptr(), bp.data_ptr() if dual else None, stat_a.data_ptr(),
                                          stat_b.data_ptr() if dual else None, ga.data_ptr(), ba.data_ptr(),
                                          gb.data_ptr() if dual else None, bb.data_ptr() if dual else None, da.data_ptr(),
-                                         db.data_ptr() if dual else None, sums.data_ptr(), ws.data_ptr(), M, C, _stream()),
-                       'icn_bn_relu_bwd')
-        dbeta, dga = sums[:C], sums[C:2 * C]
-        out = [da.permute(0, 3, 1, 2), dga, dbeta, None, None, None, None]
+                                         db.data_ptr() if dual else None, sums.data_ptr(), ws.data_ptr(), M, C, dba.data_ptr(),
+                                         dga.data_ptr(), dbb.data_ptr() if dual else None, dgb.data_ptr() if dual else None,
+                                         _stream()), 'icn_bn_relu_bwd')
+        out = [da.permute(0, 3, 1, 2), dga, dba, None, None, None, None]
         if dual:
-            out += [db.permute(0, 3, 1, 2), sums[2 * C:3 * C], dbeta, None, None, None, None]
+            out += [db.permute(0, 3, 1, 2), dgb, dbb, None, None, None, None]
         else:
             out += [None] * 7
         return tuple(out)
@@ -200,6 +207,7 @@ class _HeadFn(torch.autograd.Function):
                                       _stream()), 'icn_head_fwd')
         ctx.save_for_backward(xp, w2, y)
         ctx.wshape, ctx.wstride = weight.shape, weight.stride()
+        ctx.params = (weight, bias)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -212,16 +220,16 @@ class _HeadFn(torch.autograd.Function):
         gyp = _nhwc(gy)
         dev = gyp.device
         dx = torch.empty_like(xp) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w2)
-        db = torch.empty(Cout, dtype=torch.float32, device=dev)
+        # (Cout, Cin, 1, 1) in the parameter's own strides -- (Cin, 1, Cin, Cin) for a channels_last weight, i.e. the kernel's
+        # (Cout, Cin) row-major order -- so that DistributedDataParallel can alias it (gradient_as_bucket_view)
+        dw = _gradbuf.lease(ctx.params[0], ctx.wshape, dev, stride=ctx.wstride)
+        db = _gradbuf.lease(ctx.params[1], (Cout,), dev)
         ws = torch.empty(L.icn_head_workspace_floats(M, Cin), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.icn_head_bwd(gyp.data_ptr(), y.data_ptr(), xp.data_ptr(), w2.data_ptr(),
                                       dx.data_ptr() if dx is not None else None, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), M,
                                       Cin, Cout, _stream()), 'icn_head_bwd')
-        # the gradient in the parameter's own layout (a channels_last (Cout, Cin, 1, 1) weight has strides (Cin, 1, Cin, Cin)):
-        # DistributedDataParallel with gradient_as_bucket_view can then alias it instead of warning and copying
-        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dw.as_strided(ctx.wshape, ctx.wstride), db
+        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dw, db
 
 
 def can_fuse_head(x, seq):

@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _gradbuf, _lib
 
 
 def _require_gpu(x, who):
@@ -69,6 +69,7 @@ class _IcoConvFn(torch.autograd.Function):
         _lib.check(rc, 'icn_conv_fwd')
         ctx.save_for_backward(xp, w)
         ctx.cfg = (B, Cin, Cout, r, stride, mode, bias is not None)
+        ctx.params = (weight, bias)                      # where their gradients go (_gradbuf.lease)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -89,8 +90,8 @@ class _IcoConvFn(torch.autograd.Function):
                 _lib.check(rc, 'icn_conv_bwd_data')
                 dx = dxp.permute(0, 3, 1, 2)
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-                dw = torch.empty_like(w)
-                db = torch.empty(Cout, dtype=torch.float32, device=w.device) if has_bias else None
+                dw = _gradbuf.lease(ctx.params[0], w.shape, w.device)
+                db = _gradbuf.lease(ctx.params[1], (Cout,), w.device) if has_bias else None
                 ws_bytes = L.icn_conv_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, B, Cin, Cout, r, stride)
                 ws = _workspace(ws_bytes, gyp.device)
                 rc = L.icn_conv_bwd_weight(xp.data_ptr(), gyp.data_ptr(), dw.data_ptr(),
@@ -126,6 +127,7 @@ class _IcoConvPairFn(torch.autograd.Function):
         _lib.check(rc, 'icn_conv_pair_fwd')
         ctx.save_for_backward(xp, w0c, w1c)
         ctx.cfg = (B, Cin, C0, C1, r, stride, mode, b0 is not None)
+        ctx.params = (w0, b0, w1, b1)
         return y0.permute(0, 3, 1, 2), y1.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -147,10 +149,11 @@ class _IcoConvPairFn(torch.autograd.Function):
                 _lib.check(rc, 'icn_conv_pair_bwd_data')
                 dx = dxp.permute(0, 3, 1, 2)
             if need[1] or need[3] or (has_bias and (need[2] or need[4])):
-                dw0, dw1 = torch.empty_like(w0), torch.empty_like(w1)
+                pw0, pb0, pw1, pb1 = ctx.params
+                dw0, dw1 = _gradbuf.lease(pw0, w0.shape, w0.device), _gradbuf.lease(pw1, w1.shape, w1.device)
                 if has_bias:
-                    db0 = torch.empty(C0, dtype=torch.float32, device=w0.device)
-                    db1 = torch.empty(C1, dtype=torch.float32, device=w1.device)
+                    db0 = _gradbuf.lease(pb0, (C0,), w0.device)
+                    db1 = _gradbuf.lease(pb1, (C1,), w1.device)
                 ws_bytes = L.icn_conv_pair_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, B, Cin, C0, C1, r, stride)
                 ws = _workspace(ws_bytes, g0.device)
                 rc = L.icn_conv_pair_bwd_weight(xp.data_ptr(), g0.data_ptr(), g1.data_ptr(), dw0.data_ptr(),
@@ -219,6 +222,7 @@ class _IcoUpConvPairFn(torch.autograd.Function):
         _lib.check(rc, 'icn_upconv_fwd')
         ctx.save_for_backward(xp, w0c, w1c)
         ctx.cfg = (B, Cin, C0, C1, r, mode, b0 is not None)
+        ctx.params = (w0, b0, w1, b1)
         return y0.permute(0, 3, 1, 2), y1.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -237,10 +241,11 @@ class _IcoUpConvPairFn(torch.autograd.Function):
             # both gradients from one coarse-level aggregate of (gy0 | gy1): a quarter of the fine level's multiply-adds
             dxp = torch.empty(B, 5 * n, 2 * n, Cin, dtype=torch.float32, device=dev) if need[0] else None
             if want_w:
-                dw0, dw1 = torch.empty_like(w0), torch.empty_like(w1)
+                pw0, pb0, pw1, pb1 = ctx.params
+                dw0, dw1 = _gradbuf.lease(pw0, w0.shape, dev), _gradbuf.lease(pw1, w1.shape, dev)
                 if has_bias:
-                    db0 = torch.empty(C0, dtype=torch.float32, device=dev)
-                    db1 = torch.empty(C1, dtype=torch.float32, device=dev)
+                    db0 = _gradbuf.lease(pb0, (C0,), dev)
+                    db1 = _gradbuf.lease(pb1, (C1,), dev)
             ws_bytes = L.icn_upconv_bwd_workspace_bytes(B, Cin, C0, C1, r)
             ws = _workspace(ws_bytes, dev)
             ptr = lambda t: t.data_ptr() if t is not None else None

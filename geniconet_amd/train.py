@@ -18,7 +18,7 @@ import re
 import torch
 import torch.distributed as dist
 
-from . import losses, models, optim
+from . import _gradbuf, losses, models, optim
 
 GRAD_BUCKET_MB = 5   # ~4 buckets for the 18.5 MB (AE) / 24 MB (VAE) of fp32 gradients, decoder first
 
@@ -107,6 +107,18 @@ class Trainer:
                 broadcast_buffers=False, init_sync=not staged)
             if staged:
                 self.net.register_comm_hook(None, _host_staged_allreduce_hook(self.world))
+            else:
+                # torch's built-in C++ all-reduce comm hook: the bucket is all-reduced and divided by the world size ONCE -- the
+                # same averaging as the reducer's default path, which however scales every parameter's gradient separately as it
+                # enters its bucket (one launch per parameter: 78 per step here, 0.36 ms of GPU time).  Together with gradients
+                # that the backward kernels write straight into the bucket views (_gradbuf) the reducer launches nothing per
+                # parameter.  Measured at world size 1 over RCCL (I5, 36 meshes; tools/_exp/ddp_host.py, ms per step): no DDP
+                # 8.78, default reducer 9.06, built-in hook + views 8.92; the Python hook of torch.distributed.algorithms
+                # costs more than it saves (9.11: its future chain is completed from the host).
+                hook_type = getattr(dist, 'BuiltinCommHookType', None)
+                if hook_type is not None and hasattr(self.net, '_register_builtin_comm_hook'):
+                    self.net._register_builtin_comm_hook(hook_type.ALLREDUCE)
+            self._grads_in_buckets = os.environ.get('ICN_NO_GRAD_VIEWS', '') != '1'
         self.optimizer = optim.Adam(self.model.parameters(), lr=cfg['lr'])    # run.py:446 (torch.optim.Adam, step on HIP)
         self.scheduler = None
         if 'lr_base' in cfg and 'lr_max' in cfg:                                               # run.py:448-450
@@ -114,6 +126,8 @@ class Trainer:
                                                                cycle_momentum=False)
         self.model.train()
         self.last_output = None
+        if not hasattr(self, '_grads_in_buckets'):
+            self._grads_in_buckets = False
 
     def _broadcast_initial_state_via_host(self):
         """Rank 0's parameters and buffers to every rank through CPU tensors (what DDP's init_sync does on the device)."""
@@ -134,6 +148,9 @@ class Trainer:
             loss = self.criterion(output, lbl)
             self.optimizer.zero_grad()
             loss.backward()
+            if self._grads_in_buckets:
+                # after the reducer's hooks every .grad is a view into its bucket: the next backward writes there directly
+                _gradbuf.refresh(self.model.parameters())
             self.optimizer.step()
             if self.scheduler is not None:
                 self.scheduler.step()

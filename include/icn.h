@@ -127,7 +127,10 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
  * icn_bn_relu_fwd : y = relu(bn_a(a) [+ bn_b(b)])            (b == NULL: single input)
  * icn_bn_relu_bwd : da [, db], and sums[k*C + c]: k = 0 -> d(beta), 1 -> d(gamma_a), 2 -> d(gamma_b).  The ReLU mask is
  *                   recomputed from a (, b) and the affine parameters with the forward's own expression, so the saved
- *                   output y is not read (one tensor less to stream in each of the two backward passes).              */
+ *                   output y is not read (one tensor less to stream in each of the two backward passes).  The parameter
+ *                   gradients are ALSO written to dbeta_a / dgamma_a / dbeta_b / dgamma_b [C] where not NULL (ABI 4): their
+ *                   own tensors, which may be views into a DistributedDataParallel bucket; `sums` stays the contiguous
+ *                   copy the second pass reads.                                                                     */
 size_t icn_bn_workspace_floats(int M, int C);
 /* icn_bn_stats2: the statistics of the two inputs of relu(bn_a(a) + bn_b(b)) in one pass (two launches instead of four);
  * same results as two icn_bn_stats calls. */
@@ -140,7 +143,7 @@ int icn_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const f
                     const float* beta_a, const float* gamma_b, const float* beta_b, float* y, int M, int C, void* stream);
 int icn_bn_relu_bwd(const float* dy, const float* a, const float* b, const float* stat_a, const float* stat_b, const float* gamma_a,
                     const float* beta_a, const float* gamma_b, const float* beta_b, float* da, float* db, float* sums, float* ws, int M,
-                    int C, void* stream);
+                    int C, float* dbeta_a, float* dgamma_a, float* dbeta_b, float* dgamma_b, void* stream);
 
 /* Fused output head  y = tanh(x W^T + b)  (reference models.py:151-154: Conv2d(64, 3, 1x1) + Tanh).
  * x (M, Cin) channels-last rows, w (Cout, Cin), Cin in {16,32,64,128,256}, Cout <= 4; y (M, Cout).

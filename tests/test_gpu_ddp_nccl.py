@@ -1,6 +1,7 @@
 """The PRODUCTION communication path on the one GPU a test box has: an RCCL (backend 'nccl') process group of world size 1,
-DistributedDataParallel around the product model exactly as geniconet_amd/train.py builds it for N > 1 (no comm hook,
-init_sync, gradient_as_bucket_view, 5 MB buckets), device barriers, destroy_process_group.  World size 1 over RCCL runs
+DistributedDataParallel around the product model exactly as geniconet_amd/train.py builds it for N > 1 (init_sync,
+gradient_as_bucket_view, 5 MB buckets, torch's built-in C++ all-reduce comm hook, gradients written straight into the bucket
+views from the third backward on), device barriers, destroy_process_group.  World size 1 over RCCL runs
 everything N ranks would run except the wire: communicator creation, DDP's reducer over the pair / upconv / BN / head /
 loss autograd Functions with bucket-view gradients feeding icn_adam_step, and the bucket all-reduce kernels queued on
 RCCL's stream while the persistent, spin-waiting stream-K conv kernels own every CU.
@@ -62,10 +63,14 @@ def _worker(rank, port, out_path):
         # after the first backward DDP has re-pointed .grad at views of its buckets (gradient_as_bucket_view)
         case['params'] = len(gp)
         # three full steps (the weights moved above by nothing: no optimiser step yet; BN statistics moved equally on both)
+        from geniconet_amd import _gradbuf
         for step in range(3):
             for tr in (plain, ddp):
                 torch.manual_seed(100 + step)
+                before = dict(_gradbuf.counts)
                 loss = tr.step(x, t)
+                if tr is ddp:
+                    case['leases_step%d' % step] = (_gradbuf.counts['view'] - before['view'], _gradbuf.counts['new'] - before['new'])
             dist.barrier(device_ids=[0])
         sp, sd = plain.model.state_dict(), ddp.model.state_dict()
         for k in sp:
@@ -91,3 +96,7 @@ def test_ddp_over_rccl_at_world_size_one_is_bit_identical_to_the_plain_trainer(t
         assert c['grad_mismatch'] == [], (c['name'], c['R'], c['grad_mismatch'][:5])
         assert c['weight_mismatch'] == [], (c['name'], c['R'], c['weight_mismatch'][:5])
         assert c['finite'] and c['status'] == 0, c
+        # in the last step every gradient the package's backward kernels produce went straight into a bucket view (all
+        # parameters but the 4 of the VAE latent heads' torch-native BatchNorms), none into a new tensor
+        served, new = c['leases_step2']
+        assert served >= c['params'] - 4 and new == 0, c
