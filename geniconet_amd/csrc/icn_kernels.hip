@@ -452,6 +452,10 @@ __device__ __forceinline__ void conv_dma_body(
                                                            0x00020000);
     const auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(dcode), 0, T * Pd * 4, 0x00020000);
     const auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(perm ? perm : dcode), 0, Pd * 4, 0x00020000);
+    // destinations as buffers of exactly (rows x row stride) bytes: the epilogue's range check drops what must not be stored
+    const unsigned d_rows = SEG ? (unsigned)segs.B * (unsigned)Pd : (unsigned)M;
+    const auto rsrc_d = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(d_rows * (unsigned)N0 * 4u), 0x00020000);
+    const auto rsrc_d2 = __builtin_amdgcn_make_buffer_rsrc(dst2 ? dst2 : dst, 0, dst2 ? (int)(d_rows * (unsigned)(N - N0) * 4u) : 0, 0x00020000);
     const auto rsrc_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias ? bias : src), 0, bias ? N * 4 : 0, 0x00020000);
 
     // XCD-aware tile order: tiles with equal index mod 8 (one persistent block's residue class, hence one XCD
@@ -533,7 +537,7 @@ __device__ __forceinline__ void conv_dma_body(
             for (int row = tid; row < BM; row += 256) {
                 int b, q;
                 decode_row(m0 + row, b, q);
-                drow_s[row] = b >= 0 ? (unsigned)(b * Pd + perm[q]) : (SEG ? INVALID_ROW : 0u);
+                drow_s[row] = b >= 0 ? (unsigned)(b * Pd + perm[q]) : INVALID_ROW;
             }
         if (bias)
             for (int c = tid; c < BN; c += 256) bias_s[c] = bias[n0 + c];
@@ -630,7 +634,8 @@ __device__ __forceinline__ void conv_dma_body(
     // waits for lower block ids of its own launch -- dispatched before it, whatever else shares the GPU -- and those never
     // wait for anything before parking their piece.  (A ticket drawn from an atomic counter instead of blockIdx would not
     // even need in-order dispatch; its round trip at the top of every launch cost half of what stream-K gains.)
-    unsigned long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_split = 0, tr_wait = 0;
+    unsigned long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_split = 0, tr_wait = 0, tr_epi = 0, tr_e0 = 0;
+    unsigned tr_nseg = 0;
     if (trace) tr_t0 = __builtin_amdgcn_s_memrealtime();
     SkWalk skw{};                                         // (icn_streamk.h; plain ints: stays in scalar registers)
     const int sk_S = (SEG ? __popc(segs.mask[0]) : 7) * nk;   // SK: K-steps of a tile (every tile of an SK launch runs the same taps)
@@ -802,7 +807,7 @@ _Pragma("unroll") \
         if (perm && wave < RL) { \
             const int b_ = RL == 1 ? mb[0] : (wave ? mb[RL - 1] : mb[0]); \
             unsigned* e_ = drow_s + ne_ * BM + wave * 64 + lane; \
-            *e_ = b_ >= 0 ? (unsigned)(b_ * Pd) + *e_ : (SEG ? INVALID_ROW : 0u); \
+            *e_ = b_ >= 0 ? (unsigned)(b_ * Pd) + *e_ : INVALID_ROW; \
         } \
     } while (0)
     // End of a K-step: retire the previous stage (and the metadata fetched ahead of this step's stage), publish.
@@ -832,6 +837,7 @@ _Pragma("unroll") \
             ICN_RETIRE_AND_PUBLISH(meta);                 // stage s+1 landed and visible
             c_ring = c_ring == 2 ? 0 : c_ring + 1;
         }
+        if (trace) tr_e0 = __builtin_amdgcn_s_memrealtime();          // K-steps of the segment done: epilogue + switch from here
         bool sk_store = true;
         if constexpr (SK) {
             // A tile cut in K: the block holding its LAST k-chunks finishes it (that segment is the last thing the block does,
@@ -921,28 +927,48 @@ _Pragma("unroll") \
             }
         }
         // ---- tile epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        // Buffer stores (round 3): the output tensor is a buffer resource of exactly rows * row-stride bytes, a lane's byte offset
+        // is row * stride + column, and everything that must not be stored -- rows past M, padding rows of a permuted launch
+        // (INVALID_ROW in the destination-row table) -- is simply out of range, so the epilogue is four instructions per element
+        // (accumulator read, bias add, offset add, store) with no exec-mask branch and no 64-bit arithmetic.  The per-element
+        // `if (m < M) dst[(size_t)drow * stride + col] = ...` it replaces compiled to ~40 VALU instructions per element and cost
+        // 4-5 us per tile (icn_debug_trace: 7-9 % of a launch of 28-step tiles, a third of one of 4-8-step tiles), which was
+        // not the stores: leaving them out changed nothing, leaving the loop out took the launch from 215 to 205 us.
+        if (sk_store) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int cl = wc * (BN / 2) + j * 32 + l31, col = n0 + cl;
-            const float bv = bias ? bias_s[eslot * BN + cl] : 0.f;
-            // pair forward: 32-column groups at or beyond N0 belong to the second output tensor
-            const bool second = n0 + wc * (BN / 2) + j * 32 >= N0;
-            float* const dcol = second ? dst2 + (col - N0) : dst + col;
-            const size_t dstride = second ? (size_t)(N - N0) : (size_t)N0;
+            for (int j = 0; j < TN; ++j) {
+                const int cl = wc * (BN / 2) + j * 32 + l31, col = n0 + cl;
+                const float bv = bias ? bias_s[eslot * BN + cl] : 0.f;
+                // pair forward: 32-column groups at or beyond N0 belong to the second output tensor (wave-uniform)
+                const bool second = __builtin_amdgcn_readfirstlane(n0 + wc * (BN / 2) + j * 32 >= N0 ? 1 : 0) != 0;
+                const unsigned rs = (unsigned)(second ? N - N0 : N0) * 4u;                  // row stride of the tensor, bytes
+                const auto rd = second ? rsrc_d2 : rsrc_d;
+                const unsigned cb = (unsigned)(second ? col - N0 : col) * 4u;
+                if (!SEG && !perm) {
+                    const unsigned base = (unsigned)(m0 + wr * (BM / 2) + 4 * h) * rs + cb;  // (rows >= M: >= num_records, dropped)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, m = m0 + rl;
-                    if constexpr (SEG) {
-                        const unsigned drow = drow_s[eslot * BM + rl];
-                        if (drow != INVALID_ROW && sk_store) dcol[(size_t)drow * dstride] = acc[i][j][r] + bv;
-                    } else if (m < M && sk_store) {
-                        const size_t drow = perm ? (size_t)drow_s[eslot * BM + rl] : (size_t)m;
-                        dcol[drow * dstride] = acc[i][j][r] + bv;
-                    }
+                        for (int r = 0; r < 16; ++r)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r] + bv), rd,
+                                                                  base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rs, 0, 0);
+                } else {
+                    unsigned dr[TM][16];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            dr[i][r] = drow_s[eslot * BM + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r] + bv), rd,
+                                                                  dr[i][r] == INVALID_ROW ? 0xFFFFFF00u : dr[i][r] * rs + cb, 0, 0);
                 }
+            }
         }
+        if (trace) { tr_epi += __builtin_amdgcn_s_memrealtime() - tr_e0; ++tr_nseg; }
         if (!has_next) break;
         zero_acc();
         tile = next_tile;
@@ -971,7 +997,7 @@ _Pragma("unroll") \
     }
     if (trace && tid == 0) {
         unsigned long long* o = trace + (size_t)blockIdx.x * 8;
-        o[0] = tr_t0; o[1] = tr_t1; o[2] = tr_t2; o[3] = tr_split; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = tr_wait;
+        o[0] = tr_t0; o[1] = tr_t1; o[2] = tr_t2; o[3] = tr_split; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = tr_wait | ((unsigned long long)tr_nseg << 48) | (tr_epi << 24);   // wait (24 bits) | epilogue time (24 bits) | segments
         o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // XCC_ID (HW_REG 20, bits 3:0)
         o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);    // HW_ID
     }
@@ -1243,6 +1269,9 @@ bool conv_dma_usable(const GatherGemmArgs& a) {
     // step and published by that step's barrier, and the DMA pointer (2 steps ahead) prefetches the next stage's row
     // offsets one step earlier still, i.e. in step S-3 >= 1.  With tap masks a tile may use a single tap.
     if (a.segs.nseg == 0 && (a.mask32 ? 1 : 7) * (a.K / BK) < 4) return false;
+    // the epilogue addresses the outputs through 32-bit buffer offsets (rows past M must land beyond the buffer, not wrap)
+    const size_t dst_bytes = nb * a.Pd * (size_t)std::max(a.dst2 ? a.N0 : a.N, a.dst2 ? a.N - a.N0 : 0) * 4;
+    if (dst_bytes >= (size_t)0xFFF00000u) return false;
     return src_bytes < ((size_t)1 << 31) && wt_bytes < ((size_t)1 << 31);
 }
 

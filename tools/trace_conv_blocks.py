@@ -112,7 +112,12 @@ def main():
             sp = t[:, 3] != 0
             if sp.any():
                 pct((t[sp, 3] - t0) / 100.0, 'split phase starts at')
-            pct(t[:, 5] / 100.0, 'waiting for partners')
+            pct((t[:, 5] & 0xFFFFFF) / 100.0, 'waiting for partners')
+            nseg = (t[:, 5] >> 48) & 0xFFFF
+            epi = ((t[:, 5] >> 24) & 0xFFFFFF) / 100.0
+            pct(epi, 'epilogues (K-steps done -> stored)')
+            pct(epi / np.maximum(nseg, 1), '   per segment')
+            pct(nseg, 'segments per workgroup', unit='')
             pct(end, 'exit at')
             pct(end.max() - end, 'idle before the launch ends')
             busy = (t[:, 4] - t[:, 2]).sum() / 100.0
