@@ -970,7 +970,7 @@ int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const fl
             p.bias = bias0; p.bias2 = bias1; p.bias_cat = bias_cat;
             icn::launch_conv_prologue(p, s);
             icn::GatherGemmArgs a{};
-            a.src = x; a.wt = wf; a.dst = z; a.N0 = 7 * C; a.dcode = d.iota; a.perm = d.iota;
+            a.src = x; a.wt = wf; a.dst = z; a.N0 = 7 * C; a.dcode = d.iota; a.perm = nullptr;   // identity rows: no destination-row table
             a.Ps = d.Pc; a.Pd = d.Pc; a.K = Cin; a.N = 7 * C; a.E = 1; a.T = 1; a.M = B * d.Pc;
             a.segs.nseg = 1; a.segs.B = B; a.segs.cnt[0] = d.Pc; a.segs.off[0] = 0; a.segs.mask[0] = 1u;
             a.algo_flops = 2.0 * 7 * Cin * C * (double)B * d.Pc;                  // executed: a quarter of the fine-level forward
@@ -1088,7 +1088,7 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
             p.zero = sk_flag; p.n_zero = icn::CONV_SK_FLAGS;
             icn::launch_conv_prologue(p, s);
             icn::GatherGemmArgs a{};
-            a.src = g; a.wt = wb; a.dst = dx; a.N0 = Cin; a.dcode = t.iota; a.perm = t.iota;
+            a.src = g; a.wt = wb; a.dst = dx; a.N0 = Cin; a.dcode = t.iota; a.perm = nullptr;   // identity rows
             a.Ps = t.Pc; a.Pd = t.Pc; a.K = 7 * C; a.N = Cin; a.E = 1; a.T = 1; a.M = M;
             a.segs.nseg = 1; a.segs.B = B; a.segs.cnt[0] = t.Pc; a.segs.off[0] = 0; a.segs.mask[0] = 1u;
             a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pc;            // executed: a quarter of the fine-level bwd-data it replaces

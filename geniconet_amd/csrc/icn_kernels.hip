@@ -935,6 +935,14 @@ _Pragma("unroll") \
         // 4-5 us per tile (icn_debug_trace: 7-9 % of a launch of 28-step tiles, a third of one of 4-8-step tiles), which was
         // not the stores: leaving them out changed nothing, leaving the loop out took the launch from 215 to 205 us.
         if (sk_store) {
+            unsigned dr[TM][16];                              // destination rows of this lane's elements (permuted launches)
+            if (perm) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        dr[i][r] = drow_s[eslot * BM + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int cl = wc * (BN / 2) + j * 32 + l31, col = n0 + cl;
@@ -944,8 +952,8 @@ _Pragma("unroll") \
                 const unsigned rs = (unsigned)(second ? N - N0 : N0) * 4u;                  // row stride of the tensor, bytes
                 const auto rd = second ? rsrc_d2 : rsrc_d;
                 const unsigned cb = (unsigned)(second ? col - N0 : col) * 4u;
-                if (!SEG && !perm) {
-                    const unsigned base = (unsigned)(m0 + wr * (BM / 2) + 4 * h) * rs + cb;  // (rows >= M: >= num_records, dropped)
+                if (!perm) {      // GEMM row m is output row m (also the dense one-tap GEMMs: one identity segment)
+                    const unsigned base = (unsigned)(m0 + wr * (BM / 2) + 4 * h) * rs + cb;  // (rows >= d_rows: >= num_records, dropped)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -953,12 +961,6 @@ _Pragma("unroll") \
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r] + bv), rd,
                                                                   base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rs, 0, 0);
                 } else {
-                    unsigned dr[TM][16];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            dr[i][r] = drow_s[eslot * BM + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1255,7 +1257,9 @@ bool conv_dma_usable(const GatherGemmArgs& a) {
     const size_t side_bytes = nb * a.n_slots * Ks * 4;
     if (a.segs.nseg > 0) {
         // class-major rows: permuted, every tile's tap mask comes from its segment (1..7 taps); the launch pads the segments
-        if (a.perm == nullptr || a.segs.nseg > MAX_SEGS || a.segs.B < 1 || seg_rows(a.segs, 128, nullptr) >= (1L << 31)) return false;
+        // (no row permutation: only the single-segment identity layout of the dense GEMMs -- GEMM row m IS output row m)
+        const bool ident = a.perm == nullptr && a.segs.nseg == 1 && a.segs.off[0] == 0 && a.segs.cnt[0] == a.Pd;
+        if ((a.perm == nullptr && !ident) || a.segs.nseg > MAX_SEGS || a.segs.B < 1 || seg_rows(a.segs, 128, nullptr) >= (1L << 31)) return false;
         for (int i = 0; i < a.segs.nseg; ++i) {
             const int pc = __builtin_popcount(a.segs.mask[i]);
             if (pc < 1 || pc > 7 || pc * (a.K / BK) < 4 || a.segs.cnt[i] < 1) return false;

@@ -30,7 +30,7 @@ def main():
     ap.add_argument('--cout', type=int, default=128)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--dump', default='')
-    ap.add_argument('--mode', default='fwd', choices=['fwd', 'dgrad', 'wgrad'])
+    ap.add_argument('--mode', default='fwd', choices=['fwd', 'dgrad', 'wgrad', 'upfwd'])
     ap.add_argument('--stride', type=int, default=1)
     ap.add_argument('--pair', action='store_true')
     a = ap.parse_args()
@@ -45,7 +45,13 @@ def main():
     xs = x.clone().requires_grad_(a.mode == 'dgrad')
     ws = [w.clone().requires_grad_(a.mode == 'wgrad'), w2.clone().requires_grad_(a.mode == 'wgrad')]
     bs = [b.clone().requires_grad_(a.mode == 'wgrad'), b.clone().requires_grad_(a.mode == 'wgrad')]
-    if a.mode != 'fwd':
+    if a.mode == 'upfwd':
+        from geniconet_amd.ico_conv import ico_upconv_pair
+
+        def run():
+            with torch.no_grad():
+                ico_upconv_pair(x, w, b, w2, b, a.r, 'average')      # the dense z-GEMM is the call's only stream-K launch
+    elif a.mode != 'fwd':
         if a.pair:
             ys = ico_conv_pair(xs, ws[0], bs[0], ws[1], bs[1], a.r, a.stride, 'average')
         else:
