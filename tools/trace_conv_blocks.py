@@ -124,6 +124,10 @@ def main():
             pct(epi, 'epilogues (K-steps done -> stored)')
             pct(epi / np.maximum(nseg, 1), '   per segment')
             pct(nseg, 'segments per workgroup', unit='')
+            vm = ((t[:, 6] >> 8) & 0xFFFFFFF) / 100.0
+            if vm.any():        # experiment builds only (ICN_EXP & 512): wave 0's time in the per-step vmcnt wait / barrier
+                pct(vm, 'in the counted vmcnt waits')
+                pct(((t[:, 6] >> 36) & 0xFFFFFFF) / 100.0, 'in the K-step barriers')
             pct(end, 'exit at')
             pct(end.max() - end, 'idle before the launch ends')
             busy = (t[:, 4] - t[:, 2]).sum() / 100.0
