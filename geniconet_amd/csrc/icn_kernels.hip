@@ -755,43 +755,6 @@ _Pragma("unroll") \
             } \
         } \
     } while (0)
-    // The K-step loop's own, straight-line form of the stage issue (round 3).  Compiled out piece by piece, the stage issue
-    // cost 13 % of a launch's cycles although its instructions are few: the general macro above is five TAKEN branches per
-    // K-step (side-row vote, segment end, tap wrap, pointer alive, counted / full wait), each a refetch of the wave's
-    // instruction buffer, all of them between the step's barrier and its first MFMA, where every wave of the workgroup
-    // pays them at the same moment and the other workgroup of the CU -- which runs in phase -- does not fill the hole.
-    // The common step (pointer alive and not on the last step of its segment, no side-buffer row among this wave's rows,
-    // not the tile's metadata step) takes no branch at all: the tap advance is arithmetic, everything else falls through;
-    // any other step goes the general way, out of line.
-#define ICN_ISSUE_STAGE_FAST() do { \
-        issued = 1; \
-        p_exact = 1; \
-        const int tn0 = __builtin_amdgcn_readfirstlane(i_own ? n0 : nn0); \
-        const int sec_ = __builtin_amdgcn_readfirstlane(i_kc >= nk0); \
-        const int a_soff = __builtin_amdgcn_readfirstlane((sec_ ? i_kc - nk0 : i_kc) * (BK * 4)); \
-        const int b_soff = __builtin_amdgcn_readfirstlane(((i_t * N + tn0) * K + i_kc * BK) * 4); \
-        const auto ra_ = sec_ ? rsrc_a2 : rsrc_a; \
-_Pragma("unroll") \
-        for (int i = 0; i < RA; ++i) { \
-            float* lds_dst = As + __builtin_amdgcn_readfirstlane(i_ring * BM * BK + 8 * (wave + 4 * i) * BK); \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_ptr_t)lds_dst, 16, pbase[i] + achunk[i], a_soff, 0, 0); \
-        } \
-_Pragma("unroll") \
-        for (int i = 0; i < RB; ++i) { \
-            float* lds_dst = Bs + __builtin_amdgcn_readfirstlane(i_ring * BN * BK + 8 * (wave + 4 * i) * BK); \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)lds_dst, 16, bconst[i], b_soff, 0, 0); \
-        } \
-        i_ring = i_ring == 2 ? 0 : i_ring + 1; \
-        --i_left; \
-        const unsigned mk_ = i_own ? mask_c : mask_n; \
-        const unsigned higher_ = mk_ & ~((2u << i_t) - 1u); \
-        i_kc += higher_ == 0u; \
-        i_t = __ffs(higher_ ? higher_ : mk_) - 1; \
-        const int rk_ = SEG ? __popc(mk_ & ((1u << i_t) - 1u)) : i_t; \
-        const int tb = __builtin_amdgcn_readfirstlane(((i_own ? slot : slot ^ 1) * 7 + rk_) * BM); \
-_Pragma("unroll") \
-        for (int i = 0; i < RA; ++i) pbase[i] = otab[tb + 8 * (wave + 4 * i) + rsub]; \
-    } while (0)
     // Metadata of the NEXT tile (rows nm0.., columns nn0..), fetched by LDS-DMA: code DMA j (of NJ, wave j % 4) brings the
     // 64 codes of tap j / RL, rows (j % RL) * 64 + lane, to their final place in the offset table; waves < RL fetch the
     // destination-row permutation, the last BN / 64 waves the bias.
@@ -849,9 +812,9 @@ _Pragma("unroll") \
     } while (0)
     // End of a K-step: retire the previous stage (and the metadata fetched ahead of this step's stage), publish.
 #define ICN_RETIRE_AND_PUBLISH(META) do { \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); \
-        if (__builtin_expect(!(issued && p_exact), 0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-        if (__builtin_expect(META, 0)) ICN_META_CONVERT(); \
+        if (issued && p_exact) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        if (META) ICN_META_CONVERT(); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         __builtin_amdgcn_s_barrier(); \
     } while (0)
@@ -868,16 +831,8 @@ _Pragma("unroll") \
         for (int step = 0; step < S; ++step) {
             const bool meta = step == 0 && has_next;      // wave-uniform
             frag0(c_ring);
-            bool side_row = false;
-#pragma unroll
-            for (int i = 0; i < RA; ++i) side_row |= (int)pbase[i] < (int)NOTHING_OFFSET;
-            const int plain = (int)!meta & (i_live != 0) & (i_left > 1) & (int)(__builtin_amdgcn_ballot_w64(side_row) == 0);   // wave-uniform; '&': one test, no short-circuit branches
-            if (__builtin_expect(plain, 1)) {
-                ICN_ISSUE_STAGE_FAST();                   // stage s+2, no branch
-            } else {
-                if (meta) ICN_META_ISSUE();               // next tile's tables: consumed >= 2 K-steps from now
-                ICN_ISSUE_STAGE();                        // stage s+2, any case
-            }
+            if (meta) ICN_META_ISSUE();                   // next tile's tables: consumed >= 2 K-steps from now
+            ICN_ISSUE_STAGE();                            // stage s+2
             compute(c_ring);
             ICN_RETIRE_AND_PUBLISH(meta);                 // stage s+1 landed and visible
             c_ring = c_ring == 2 ? 0 : c_ring + 1;
@@ -1049,7 +1004,6 @@ _Pragma("unroll") \
         o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);    // HW_ID
     }
 #undef ICN_ISSUE_STAGE
-#undef ICN_ISSUE_STAGE_FAST
 #undef ICN_META_ISSUE
 #undef ICN_META_CONVERT
 #undef ICN_RETIRE_AND_PUBLISH
