@@ -37,6 +37,16 @@ def _check_grid(x, r, who):
 _NO_UPCONV_BWD = os.environ.get('ICN_NO_UPCONV_BWD', '') == '1'    # developer switch: backward of the separate operators
 
 
+def _empty_batch(x, channels, n_out, *params):
+    """An empty batch (B = 0): the empty output of the right shape, still attached to the graph -- x and the parameters get
+    all-zero gradients, as torch's own conv2d gives them -- without a kernel launch (the C ABI rejects B < 1)."""
+    keep = x.sum() * 0
+    for p in params:
+        if p is not None:
+            keep = keep + p.sum() * 0
+    return x.new_zeros((0, channels, 5 * n_out, 2 * n_out)) + keep
+
+
 def _nhwc(x):
     """(B,C,H,W) logical -> contiguous (B,H,W,C) storage; free when x is already channels_last."""
     return x.permute(0, 2, 3, 1).contiguous()
@@ -302,6 +312,9 @@ def ico_upconv_pair(x, weight0, bias0, weight1, bias1, subdivisions, corner_mode
             raise ValueError('ico_upconv_pair: weight must be (Cout, %d, 7), got %s' % (x.shape[1], tuple(w.shape)))
     if (bias0 is None) != (bias1 is None):
         raise ValueError('ico_upconv_pair: both convolutions carry a bias or neither does')
+    if x.shape[0] == 0:
+        n_out = 2 ** (subdivisions + 1)
+        return _empty_batch(x, weight0.shape[0], n_out, weight0, bias0), _empty_batch(x, weight1.shape[0], n_out, weight1, bias1)
     return _IcoUpConvPairFn.apply(x, weight0, bias0, weight1, bias1, subdivisions, _lib.corner_code(corner_mode))
 
 
@@ -313,6 +326,8 @@ def ico_conv(x, weight, bias, subdivisions, stride=1, corner_mode='zeros'):
         raise ValueError('ico_conv: weight must be (Cout, %d, 7), got %s' % (x.shape[1], tuple(weight.shape)))
     if stride not in (1, 2):
         raise ValueError('ico_conv: stride must be 1 or 2')
+    if x.shape[0] == 0:
+        return _empty_batch(x, weight.shape[0], 2 ** subdivisions // stride, weight, bias)
     return _IcoConvFn.apply(x, weight, bias, subdivisions, stride, _lib.corner_code(corner_mode))
 
 
@@ -336,6 +351,9 @@ def ico_conv_pair(x, weight0, bias0, weight1, bias1, subdivisions, stride=1, cor
         raise ValueError('ico_conv_pair: both convolutions carry a bias or neither does')
     if stride not in (1, 2):
         raise ValueError('ico_conv_pair: stride must be 1 or 2')
+    if x.shape[0] == 0:
+        n_out = 2 ** subdivisions // stride
+        return _empty_batch(x, weight0.shape[0], n_out, weight0, bias0), _empty_batch(x, weight1.shape[0], n_out, weight1, bias1)
     return _IcoConvPairFn.apply(x, weight0, bias0, weight1, bias1, subdivisions, stride, _lib.corner_code(corner_mode))
 
 
@@ -343,6 +361,8 @@ def ico_upsample(x, subdivisions, corner_mode='zeros'):
     """Functional form of IcoUpsampleS2S.forward."""
     _require_gpu(x, 'ico_upsample')
     _check_grid(x, subdivisions, 'ico_upsample')
+    if x.shape[0] == 0:
+        return _empty_batch(x, x.shape[1], 2 ** (subdivisions + 1))
     return _IcoUpsampleFn.apply(x, subdivisions, _lib.corner_code(corner_mode))
 
 

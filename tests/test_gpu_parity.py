@@ -373,6 +373,28 @@ def test_conv_without_bias_and_noncontiguous_input():
         assert rel_l2(ico_conv(xg, w.cuda(), None, 2, 1, 'average').cpu().numpy(), want.numpy()) < TOL
 
 
+def test_an_empty_batch_gives_the_oracles_empty_output_and_zero_gradients():
+    """B = 0 (a ragged last batch of a loader): torch's conv2d -- hence the oracle and the reference -- returns an empty tensor
+    and all-zero gradients; the C ABI rejects B < 1, so the operators answer it themselves, without a launch."""
+    from geniconet_amd.ico_conv import ico_conv, ico_conv_pair, ico_upsample, ico_upconv_pair
+    x = torch.zeros(0, 64, 20, 8, device='cuda', requires_grad=True)
+    w = torch.randn(128, 64, 7, device='cuda', requires_grad=True)
+    b = torch.randn(128, device='cuda', requires_grad=True)
+    xr = torch.zeros(0, 64, 20, 8)
+    for stride in (1, 2):
+        y = ico_conv(x, w, b, 2, stride, 'average')
+        assert y.shape == ico_ref.ico_conv(xr, w.detach().cpu(), b.detach().cpu(), 2, stride, 'average').shape
+        gx, gw, gb = torch.autograd.grad(y.sum(), (x, w, b))
+        assert gx.shape == x.shape and not gw.any() and not gb.any()
+    y0, y1 = ico_conv_pair(x, w, b, w, b, 2, 2, 'zeros')
+    assert y0.shape == y1.shape == (0, 128, 10, 4)
+    u = ico_upsample(x, 2, 'average')
+    assert u.shape == ico_ref.ico_upsample(xr, 2, 'average').shape and torch.autograd.grad(u.sum(), x)[0].shape == x.shape
+    z0, z1 = ico_upconv_pair(x, w, b, w, b, 2, 'average')
+    assert z0.shape == z1.shape == (0, 128, 40, 16)
+    assert not torch.autograd.grad(z0.sum() + z1.sum(), w)[0].any()
+
+
 def test_argument_errors_on_gpu():
     from geniconet_amd.ico_conv import ico_conv, ico_upsample
     x = torch.zeros(1, 4, 20, 8, device='cuda')
