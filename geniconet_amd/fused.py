@@ -5,10 +5,13 @@ The reference strings torch builtins together (models.py:36-40,58-62):
     relu(icobn01(conv01(.)) + icobn10(conv10(.))) -> bn_add_relu(a, icobn01, b, icobn10)
 Here each is one autograd Function over libicn's icn_bn_* kernels (two streaming passes forward, two backward, instead
 of 4-7 separate elementwise passes).  The `nn.BatchNorm2d` modules stay in the module tree (state_dict keys, running
-statistics, `num_batches_tracked` are updated exactly as torch does in training mode); the fused path is only taken in
-training mode on ROCm tensors when nobody hooked those modules -- otherwise the modules are called as usual.
+statistics, `num_batches_tracked` are updated exactly as torch does in training mode); the fused path is taken in
+training mode on ROCm tensors when nobody hooked those modules, and -- as one streaming pass with the running statistics
+(bn_relu_eval / bn_add_relu_eval) -- in eval mode when no autograd graph is being recorded (inference); otherwise the
+modules are called as usual.
 """
 import os
+import weakref
 
 import torch
 
@@ -19,18 +22,31 @@ from .ico_conv import (_nhwc, _stream, ico_conv_pair, ico_conv_pair_supported, i
 _DISABLED = os.environ.get('ICN_NO_FUSED_BN', '') == '1'
 
 
-def can_fuse(x, *bns):
-    if _DISABLED or not x.is_cuda or x.dtype != torch.float32 or not torch.is_grad_enabled():
+def _bn_shape_ok(bn):
+    if not (bn.affine and bn.track_running_stats):
         return False
-    for bn in bns:
-        if not (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None):
-            return False
-        if bn._forward_hooks or bn._forward_pre_hooks or bn._backward_hooks:
-            return False
-        c = bn.num_features
-        if c % 4 or c > 1024 or 256 % (c // 4):
-            return False
-    return True
+    if bn._forward_hooks or bn._forward_pre_hooks or bn._backward_hooks:
+        return False
+    c = bn.num_features
+    return not (c % 4 or c > 1024 or 256 % (c // 4))
+
+
+def can_fuse(x, *bns):
+    """Training-mode BatchNorms (batch statistics) on a ROCm fp32 tensor, nobody hooked them.  With or without autograd: under
+    torch.no_grad() the same Function runs and nothing is kept for a backward."""
+    if _DISABLED or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    return all(bn.training and bn.momentum is not None and _bn_shape_ok(bn) for bn in bns)
+
+
+def can_fuse_eval(x, *bns):
+    """Eval-mode BatchNorms (running statistics) in an inference forward: no autograd graph is being recorded for the input or
+    the BatchNorm parameters (serving, `--process test`).  Anything else in eval mode takes the torch modules."""
+    if _DISABLED or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or any(bn.weight.requires_grad or bn.bias.requires_grad for bn in bns)):
+        return False
+    return all((not bn.training) and _bn_shape_ok(bn) for bn in bns)
 
 
 _NO_PAIR = os.environ.get('ICN_NO_PAIR', '') == '1'
@@ -189,6 +205,50 @@ def bn_add_relu(a, bn_a, b, bn_b):
     _bump(bn_a)
     _bump(bn_b)
     return _BnReluFn.apply(a, *_args(bn_a), b, *_args(bn_b))
+
+
+# ---- inference: relu(bn(a) [+ bn(b)]) with the RUNNING statistics, one streaming pass (icn_bn_relu_fwd; no statistics pass)
+_eval_stats = weakref.WeakKeyDictionary()    # bn module -> (versions / storage of its running statistics, [mean | 1/sqrt(var + eps)])
+
+
+def _eval_stat(bn):
+    """[running_mean | rsqrt(running_var + eps)] of an eval-mode BatchNorm, rebuilt only when the statistics changed (their
+    tensors' version counters / storage): a serving forward pays for it once."""
+    rm, rv = bn.running_mean, bn.running_var
+    key = (rm._version, rv._version, rm.data_ptr(), rv.data_ptr(), float(bn.eps))
+    hit = _eval_stats.get(bn)
+    if hit is None or hit[0] != key:
+        hit = (key, torch.cat([rm.detach().float(), torch.rsqrt(rv.detach().float() + bn.eps)]))
+        _eval_stats[bn] = hit
+    return hit[1]
+
+
+def _bn_relu_eval(a, bn_a, b=None, bn_b=None):
+    L = _lib.lib()
+    ap = _nhwc(a.detach())
+    Bn, H, W, C = ap.shape
+    M = Bn * H * W
+    dual = b is not None
+    bp = _nhwc(b.detach()) if dual else None
+    stat_a = _eval_stat(bn_a)
+    stat_b = _eval_stat(bn_b) if dual else None
+    y = torch.empty_like(ap)
+    with torch.cuda.device(a.device):
+        _lib.check(L.icn_bn_relu_fwd(ap.data_ptr(), bp.data_ptr() if dual else None, stat_a.data_ptr(),
+                                     stat_b.data_ptr() if dual else None, bn_a.weight.data_ptr(), bn_a.bias.data_ptr(),
+                                     bn_b.weight.data_ptr() if dual else None, bn_b.bias.data_ptr() if dual else None,
+                                     y.data_ptr(), M, C, _stream()), 'icn_bn_relu_fwd')
+    return y.permute(0, 3, 1, 2)
+
+
+def bn_relu_eval(a, bn):
+    """relu(bn(a)) for an eval-mode BatchNorm2d in an inference forward (can_fuse_eval)."""
+    return _bn_relu_eval(a, bn)
+
+
+def bn_add_relu_eval(a, bn_a, b, bn_b):
+    """relu(bn_a(a) + bn_b(b)), eval mode, inference forward."""
+    return _bn_relu_eval(a, bn_a, b, bn_b)
 
 
 class _HeadFn(torch.autograd.Function):

@@ -41,6 +41,9 @@ class BasicIcoS2SDownBlock(nn.Module):
         if fused.can_fuse(x, self.icobn00, self.icobn01, self.icobn10):    # same math, fused HIP BN / ReLU passes
             h = fused.bn_relu(c00, self.icobn00)
             return fused.bn_add_relu(self.conv01(h), self.icobn01, c10, self.icobn10)
+        if fused.can_fuse_eval(x, self.icobn00, self.icobn01, self.icobn10):   # inference: running statistics, one pass each
+            h = fused.bn_relu_eval(c00, self.icobn00)
+            return fused.bn_add_relu_eval(self.conv01(h), self.icobn01, c10, self.icobn10)
         main = self.icobn01(self.conv01(F.relu(self.icobn00(c00))))
         skip = self.icobn10(c10)
         return F.relu(main + skip)
@@ -70,6 +73,9 @@ class BasicIcoS2SUpBlock(nn.Module):
         if fused.can_fuse(x, self.icobn00, self.icobn01, self.icobn10):
             h = fused.bn_relu(c00, self.icobn00)
             return fused.bn_add_relu(self.conv01(h), self.icobn01, c10, self.icobn10)
+        if fused.can_fuse_eval(x, self.icobn00, self.icobn01, self.icobn10):   # inference: running statistics, one pass each
+            h = fused.bn_relu_eval(c00, self.icobn00)
+            return fused.bn_add_relu_eval(self.conv01(h), self.icobn01, c10, self.icobn10)
         main = self.icobn01(self.conv01(F.relu(self.icobn00(c00))))
         skip = self.icobn10(c10)
         return F.relu(main + skip)
@@ -103,6 +109,8 @@ class _Encoder(nn.Sequential):
         hooked = relu._forward_hooks or relu._forward_pre_hooks or relu._backward_hooks
         if isinstance(relu, nn.ReLU) and not hooked and fused.can_fuse(x, mods[1]):
             x = fused.bn_relu(x, mods[1])
+        elif isinstance(relu, nn.ReLU) and not hooked and isinstance(mods[1], nn.BatchNorm2d) and fused.can_fuse_eval(x, mods[1]):
+            x = fused.bn_relu_eval(x, mods[1])
         else:
             x = relu(mods[1](x))
         for m in mods[3:]:

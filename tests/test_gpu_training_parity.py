@@ -340,6 +340,44 @@ def test_eval_mode_forward_matches_the_oracle(name):
             assert rel_l2(net.encode(xg)[0].cpu().numpy(), mu_r.numpy()) < TOL
 
 
+def test_inference_batchnorm_runs_fused_on_the_running_statistics():
+    """Eval mode without an autograd graph (serving, `--process test`): relu(bn(a) [+ bn(b)]) is ONE pass of icn_bn_relu_fwd on
+    the running statistics.  Against torch's own eval-mode modules to 1e-6; the cached [mean | 1/std] vector follows the
+    statistics when they change; with a graph being recorded the torch modules are taken (their backward is torch's)."""
+    import torch.nn.functional as F
+    from geniconet_amd import fused
+    torch.manual_seed(3)
+    for C in (64, 128, 512):
+        bns = [torch.nn.BatchNorm2d(C).cuda() for _ in range(2)]
+        for bn in bns:
+            with torch.no_grad():
+                bn.running_mean.normal_(0.3, 0.5)
+                bn.running_var.uniform_(0.2, 3.0)
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_(0, 0.3)
+            bn.eval()
+        a = torch.randn(3, C, 20, 8, device='cuda').contiguous(memory_format=torch.channels_last)
+        b = torch.randn(3, C, 20, 8, device='cuda').contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            assert fused.can_fuse_eval(a, *bns) and not fused.can_fuse(a, *bns)
+            want1, want2 = F.relu(bns[0](a)), F.relu(bns[0](a) + bns[1](b))
+            got1, got2 = fused.bn_relu_eval(a, bns[0]), fused.bn_add_relu_eval(a, bns[0], b, bns[1])
+            assert got1.shape == want1.shape and rel_l2(got1.cpu().numpy(), want1.cpu().numpy()) < 1e-6
+            assert rel_l2(got2.cpu().numpy(), want2.cpu().numpy()) < 1e-6
+            # the statistics move (a training step, load_state_dict): the cached vector must follow
+            bns[0].running_mean.add_(0.7)
+            bns[0].running_var.mul_(1.9)
+            assert rel_l2(fused.bn_relu_eval(a, bns[0]).cpu().numpy(), F.relu(bns[0](a)).cpu().numpy()) < 1e-6
+            bns[0].load_state_dict({k: v.clone() for k, v in bns[1].state_dict().items()})
+            assert rel_l2(fused.bn_relu_eval(a, bns[0]).cpu().numpy(), F.relu(bns[1](a)).cpu().numpy()) < 1e-6
+        assert not fused.can_fuse_eval(a, *bns)                      # a graph would be recorded for the BatchNorm parameters
+        for bn in bns:
+            bn.requires_grad_(False)
+        assert fused.can_fuse_eval(a, *bns) and not fused.can_fuse_eval(a.clone().requires_grad_(True), *bns)
+        bns[0].train()
+        assert not fused.can_fuse_eval(a, *bns)
+
+
 # ---- (d) VAE loss on the device ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('factor_kl', [1.0, 0.81])
 def test_p2pkld_loss_value_and_gradient_match_the_oracle(factor_kl):
