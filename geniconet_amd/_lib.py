@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('ICN_LIB_PATH') or os.path.join(_HERE, 'libicn.so')
 
 OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT = 0, 1, 2
 CORNER_MODES = {'zeros': 0, 'average': 1}
-ABI_VERSION = 4
+ABI_VERSION = 5
 LAP_MODES = {'mean-v': 0, 'v-mean': 1, 'sum-kv': 2, 'kv-sum': 3}   # ICN_LAP_* of include/icn.h
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses
@@ -43,6 +43,7 @@ SIGNATURES = {
     'icn_upconv_bwd_supported': (ctypes.c_int, [ctypes.c_int] * 6),
     'icn_upconv_bwd_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 5),
     'icn_upconv_bwd': (ctypes.c_int, [_c_float_p] * 10 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'icn_upconv_bwd_streams': (ctypes.c_int, [_c_float_p] * 10 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     'icn_upsample_fwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'icn_upsample_bwd': (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'icn_bn_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),

@@ -1060,6 +1060,13 @@ size_t icn_upconv_bwd_workspace_bytes(int B, int Cin, int Cout0, int Cout1, int 
 int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const float* w0, const float* w1, float* dx, float* dw0,
                    float* dbias0, float* dw1, float* dbias1, int B, int Cin, int Cout0, int Cout1, int r_in, int corner_mode, void* ws,
                    size_t ws_bytes, void* stream) {
+    return icn_upconv_bwd_streams(x, dy0, dy1, w0, w1, dx, dw0, dbias0, dw1, dbias1, B, Cin, Cout0, Cout1, r_in, corner_mode, ws, ws_bytes,
+                                  stream, nullptr);
+}
+
+int icn_upconv_bwd_streams(const float* x, const float* dy0, const float* dy1, const float* w0, const float* w1, float* dx, float* dw0,
+                           float* dbias0, float* dw1, float* dbias1, int B, int Cin, int Cout0, int Cout1, int r_in, int corner_mode,
+                           void* ws, size_t ws_bytes, void* stream, void* weight_stream) {
     try {
         if (!dy0 || (Cout1 > 0) != (dy1 != nullptr)) throw std::invalid_argument("icn_upconv_bwd: dy1 goes with Cout1 > 0");
         if (dx && (!w0 || (Cout1 > 0 && !w1))) throw std::invalid_argument("icn_upconv_bwd: dx needs the weights");
@@ -1079,6 +1086,16 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
         else
             icn::launch_upconv_gather_px(dy0, dy1, g, t.px_srcs, t.px_cls, t.cls_coef, t.n_cls, B, t.Pf, t.Pc, Cout0, Cout1, s);
         icn::launch_upconv_gather(dy0, dy1, g, ga.ovf_idx, ga.ovf_coef, ga.ovf_rows, B, t.Pf, ga.n_ovf, 7 * t.Pc, Cout0, Cout1, ga.W_ovf, 0, s);
+        // the weight gradients' stream (icn_upconv_bwd_streams): ordered after the aggregate pass, beside everything that follows
+        hipStream_t sw = (dw0 && weight_stream) ? static_cast<hipStream_t>(weight_stream) : s;
+        if (sw != s) {
+            hipEvent_t ev;
+            ICN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            const hipError_t e1 = hipEventRecord(ev, s);
+            const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(sw, ev, 0) : e1;
+            (void)hipEventDestroy(ev);                                      // (released by the runtime once the wait has consumed it)
+            ICN_HIP(e2);
+        }
         if (dx) {
             // 2. dx[b, s, :] = g[b, s, (t, c)] . Wb[(t, c), :]: a dense GEMM, K = 7 * C (one "tap" whose gather is the identity)
             float* wb = reinterpret_cast<float*>(at(ws, wo.wb));
@@ -1105,7 +1122,7 @@ int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const flo
             a.dw = dw0; a.dbias = dbias0; a.dw2 = dw1; a.dbias2 = dbias1;
             a.M = M; a.Ps = t.Pc; a.Pd = t.Pc; a.Cin = Cin; a.Cout = C; a.ns = 1 << r_in;
             a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pc;            // executed: a quarter of the fine-level bwd-weight
-            icn::launch_wgrad(a, s);
+            icn::launch_wgrad(a, sw);
         }
         ICN_HIP(hipGetLastError());
         return 0;

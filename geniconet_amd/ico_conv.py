@@ -37,6 +37,102 @@ def _check_grid(x, r, who):
 _NO_UPCONV_BWD = os.environ.get('ICN_NO_UPCONV_BWD', '') == '1'    # developer switch: backward of the separate operators
 
 
+# Weight gradients on a second HIP stream (round 3).  A layer's weight gradient depends on nothing that follows it in the backward
+# pass and nothing in the pass depends on it, so it can run beside the chain data gradient -> BatchNorm backward -> next data
+# gradient -> ...: its workgroups fill the tails of the chain's persistent launches and run under its HBM-bound passes
+# (+2.4 - 3.1 % of a training step, measured).  What has to be certain is that nobody reads a gradient before it is complete:
+#   'off'       everything on the current stream.  The default: safe for any caller.
+#   'deferred'  weight gradients go to the side stream; the current stream waits for it once, when the whole backward pass has
+#               run (autograd engine callback).  For callers that do not look at parameter gradients before backward()
+#               returns: the Trainer without DistributedDataParallel sets it for the duration of its step.
+#   'bucketed'  as 'deferred', and additionally the current stream waits for the side stream at the moment the LAST gradient
+#               of a DistributedDataParallel bucket is handed to autograd -- i.e. just before the reducer launches that
+#               bucket's all-reduce, the only reader of gradients inside a backward pass (the Trainer arms it with the
+#               parameter -> bucket map it reads off the reducer's gradient views; tensor hooks on the parameters count).
+#   'eager'     the current stream waits before every backward Function returns (a weight gradient then only overlaps its own
+#               layer's data gradient).  Measured SLOWER than 'off' (two MFMA-bound launches side by side): kept for tests.
+_MODES = ('off', 'eager', 'deferred', 'bucketed')
+_wgrad_mode = [os.environ.get('ICN_WGRAD_STREAM', 'off')]
+if _wgrad_mode[0] not in _MODES:
+    raise ValueError('ICN_WGRAD_STREAM must be one of %s' % (_MODES,))
+_side_streams = {}
+_join_queued = [False]
+_buckets = {'of': {}, 'size': {}, 'left': {}}       # id(param) -> bucket key; bucket key -> parameters in it / still to come
+wgrad_stream_counts = {'side': 0, 'joins': 0}        # launches put on the side stream / waits issued (tests, diagnostics)
+
+
+def set_weight_gradient_stream(mode, bucket_of=None):
+    """Select the mode (see above); 'bucketed' needs bucket_of = {parameter: bucket key}.  Returns the previous (mode, map)."""
+    if mode not in _MODES:
+        raise ValueError('mode must be one of %s' % (_MODES,))
+    prev = (_wgrad_mode[0], _buckets.get('map'))
+    if mode == 'bucketed':
+        if not bucket_of:
+            raise ValueError("mode 'bucketed' needs the parameter -> bucket map")
+        if bucket_of is not _buckets.get('map'):
+            _buckets['map'] = bucket_of
+            _buckets['of'] = {id(p): k for p, k in bucket_of.items()}
+            size = {}
+            for k in bucket_of.values():
+                size[k] = size.get(k, 0) + 1
+            _buckets['size'] = size
+        _buckets['left'] = dict(_buckets['size'])
+    _wgrad_mode[0] = mode
+    return prev
+
+
+def _join_now():
+    for dev_index, side in _side_streams.items():
+        torch.cuda.current_stream(dev_index).wait_stream(side)
+    wgrad_stream_counts['joins'] += 1
+
+
+def _backward_pass_over():
+    _join_queued[0] = False
+    _join_now()
+    _buckets['left'] = dict(_buckets['size'])
+
+
+def parameter_gradient_ready(param):
+    """Tensor hook of a parameter (registered by the Trainer under DistributedDataParallel): its gradient is about to be
+    accumulated, after which the reducer may launch the all-reduce of the parameter's bucket."""
+    if _wgrad_mode[0] != 'bucketed' or not _join_queued[0]:      # (nothing was put on the side stream in this pass so far)
+        return
+    k = _buckets['of'].get(id(param))
+    if k is None:                                                # not in the map: take no chances
+        _join_now()
+        return
+    left = _buckets['left'][k] = _buckets['left'].get(k, 1) - 1
+    if left <= 0:
+        _join_now()
+
+
+def _wgrad_stream(dev, *tensors):
+    """The side stream for a weight-gradient launch issued from inside a backward pass, ordered after everything the current
+    stream has been given so far; `tensors` (allocated on the current stream) are kept alive for it.  None: mode 'off'."""
+    if _wgrad_mode[0] == 'off':
+        return None
+    side = _side_streams.get(dev.index)
+    if side is None:
+        side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    if _wgrad_mode[0] != 'eager' and not _join_queued[0]:
+        _join_queued[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_backward_pass_over)
+    wgrad_stream_counts['side'] += 1
+    return side
+
+
+def _wgrad_done(dev, side):
+    """End of a backward Function that put its weight gradient on `side`: in 'eager' mode the current stream waits for it."""
+    if side is not None and _wgrad_mode[0] == 'eager':
+        torch.cuda.current_stream(dev).wait_stream(side)
+        wgrad_stream_counts['joins'] += 1
+
+
 def _empty_batch(x, channels, n_out, *params):
     """An empty batch (B = 0): the empty output of the right shape, still attached to the graph -- x and the parameters get
     all-zero gradients, as torch's own conv2d gives them -- without a kernel launch (the C ABI rejects B < 1)."""
@@ -89,8 +185,18 @@ class _IcoConvFn(torch.autograd.Function):
         xp, w = ctx.saved_tensors
         B, Cin, Cout, r, stride, mode, has_bias = ctx.cfg
         gyp = _nhwc(gy)
-        dx = dw = db = None
+        dx = dw = db = side = None
         with torch.cuda.device(gyp.device):
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):     # first: it goes to the side stream
+                dw = _gradbuf.lease(ctx.params[0], w.shape, w.device)
+                db = _gradbuf.lease(ctx.params[1], (Cout,), w.device) if has_bias else None
+                ws_bytes = L.icn_conv_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, B, Cin, Cout, r, stride)
+                ws = _workspace(ws_bytes, gyp.device)
+                side = _wgrad_stream(gyp.device, xp, gyp, dw, db, ws)
+                rc = L.icn_conv_bwd_weight(xp.data_ptr(), gyp.data_ptr(), dw.data_ptr(),
+                                           db.data_ptr() if db is not None else None, B, Cin, Cout, r, stride, mode,
+                                           ws.data_ptr(), ws_bytes, side.cuda_stream if side is not None else _stream())
+                _lib.check(rc, 'icn_conv_bwd_weight')
             if ctx.needs_input_grad[0]:
                 dxp = torch.empty_like(xp)
                 ws_bytes = L.icn_conv_workspace_bytes(_lib.OP_CONV_BWD_DATA, B, Cin, Cout, r, stride)
@@ -99,15 +205,7 @@ class _IcoConvFn(torch.autograd.Function):
                                          ws.data_ptr(), ws_bytes, _stream())
                 _lib.check(rc, 'icn_conv_bwd_data')
                 dx = dxp.permute(0, 3, 1, 2)
-            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-                dw = _gradbuf.lease(ctx.params[0], w.shape, w.device)
-                db = _gradbuf.lease(ctx.params[1], (Cout,), w.device) if has_bias else None
-                ws_bytes = L.icn_conv_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, B, Cin, Cout, r, stride)
-                ws = _workspace(ws_bytes, gyp.device)
-                rc = L.icn_conv_bwd_weight(xp.data_ptr(), gyp.data_ptr(), dw.data_ptr(),
-                                           db.data_ptr() if db is not None else None, B, Cin, Cout, r, stride, mode,
-                                           ws.data_ptr(), ws_bytes, _stream())
-                _lib.check(rc, 'icn_conv_bwd_weight')
+            _wgrad_done(gyp.device, side)
         return dx, dw, db, None, None, None
 
 
@@ -147,9 +245,23 @@ class _IcoConvPairFn(torch.autograd.Function):
         xp, w0, w1 = ctx.saved_tensors
         B, Cin, C0, C1, r, stride, mode, has_bias = ctx.cfg
         g0, g1 = _nhwc(gy0), _nhwc(gy1)
-        dx = dw0 = db0 = dw1 = db1 = None
+        dx = dw0 = db0 = dw1 = db1 = side = None
         need = ctx.needs_input_grad
         with torch.cuda.device(g0.device):
+            if need[1] or need[3] or (has_bias and (need[2] or need[4])):                # first: it goes to the side stream
+                pw0, pb0, pw1, pb1 = ctx.params
+                dw0, dw1 = _gradbuf.lease(pw0, w0.shape, w0.device), _gradbuf.lease(pw1, w1.shape, w1.device)
+                if has_bias:
+                    db0 = _gradbuf.lease(pb0, (C0,), w0.device)
+                    db1 = _gradbuf.lease(pb1, (C1,), w1.device)
+                ws_bytes = L.icn_conv_pair_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, B, Cin, C0, C1, r, stride)
+                ws = _workspace(ws_bytes, g0.device)
+                side = _wgrad_stream(g0.device, xp, g0, g1, dw0, db0, dw1, db1, ws)
+                rc = L.icn_conv_pair_bwd_weight(xp.data_ptr(), g0.data_ptr(), g1.data_ptr(), dw0.data_ptr(),
+                                                db0.data_ptr() if db0 is not None else None, dw1.data_ptr(),
+                                                db1.data_ptr() if db1 is not None else None, B, Cin, C0, C1, r, stride, mode,
+                                                ws.data_ptr(), ws_bytes, side.cuda_stream if side is not None else _stream())
+                _lib.check(rc, 'icn_conv_pair_bwd_weight')
             if need[0]:
                 dxp = torch.empty_like(xp)
                 ws_bytes = L.icn_conv_pair_workspace_bytes(_lib.OP_CONV_BWD_DATA, B, Cin, C0, C1, r, stride)
@@ -158,19 +270,7 @@ class _IcoConvPairFn(torch.autograd.Function):
                                               B, Cin, C0, C1, r, stride, mode, ws.data_ptr(), ws_bytes, _stream())
                 _lib.check(rc, 'icn_conv_pair_bwd_data')
                 dx = dxp.permute(0, 3, 1, 2)
-            if need[1] or need[3] or (has_bias and (need[2] or need[4])):
-                pw0, pb0, pw1, pb1 = ctx.params
-                dw0, dw1 = _gradbuf.lease(pw0, w0.shape, w0.device), _gradbuf.lease(pw1, w1.shape, w1.device)
-                if has_bias:
-                    db0 = _gradbuf.lease(pb0, (C0,), w0.device)
-                    db1 = _gradbuf.lease(pb1, (C1,), w1.device)
-                ws_bytes = L.icn_conv_pair_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, B, Cin, C0, C1, r, stride)
-                ws = _workspace(ws_bytes, g0.device)
-                rc = L.icn_conv_pair_bwd_weight(xp.data_ptr(), g0.data_ptr(), g1.data_ptr(), dw0.data_ptr(),
-                                                db0.data_ptr() if db0 is not None else None, dw1.data_ptr(),
-                                                db1.data_ptr() if db1 is not None else None, B, Cin, C0, C1, r, stride, mode,
-                                                ws.data_ptr(), ws_bytes, _stream())
-                _lib.check(rc, 'icn_conv_pair_bwd_weight')
+            _wgrad_done(g0.device, side)
         return dx, dw0, db0, dw1, db1, None, None, None
 
 
@@ -260,9 +360,13 @@ class _IcoUpConvPairFn(torch.autograd.Function):
             ws = _workspace(ws_bytes, dev)
             ptr = lambda t: t.data_ptr() if t is not None else None
             with torch.cuda.device(dev):
-                _lib.check(L.icn_upconv_bwd(xp.data_ptr(), g0.data_ptr(), g1.data_ptr(), w0.data_ptr(), w1.data_ptr(), ptr(dxp),
-                                            ptr(dw0), ptr(db0), ptr(dw1), ptr(db1), B, Cin, C0, C1, r, mode, ws.data_ptr(),
-                                            ws_bytes, _stream()), 'icn_upconv_bwd')
+                # the weight gradients (after the aggregate pass, which stays on the current stream) on the side stream
+                side = _wgrad_stream(dev, xp, ws, dw0, db0, dw1, db1) if want_w else None
+                _lib.check(L.icn_upconv_bwd_streams(xp.data_ptr(), g0.data_ptr(), g1.data_ptr(), w0.data_ptr(), w1.data_ptr(),
+                                                    ptr(dxp), ptr(dw0), ptr(db0), ptr(dw1), ptr(db1), B, Cin, C0, C1, r, mode,
+                                                    ws.data_ptr(), ws_bytes, _stream(),
+                                                    side.cuda_stream if side is not None else None), 'icn_upconv_bwd_streams')
+                _wgrad_done(dev, side)
             return (dxp.permute(0, 3, 1, 2) if dxp is not None else None), dw0, db0, dw1, db1, None, None
         with torch.cuda.device(dev):
             st = _stream()

@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from . import _gradbuf, losses, models, optim
+from .ico_conv import parameter_gradient_ready, set_weight_gradient_stream
 
 GRAD_BUCKET_MB = 5   # ~4 buckets for the 18.5 MB (AE) / 24 MB (VAE) of fp32 gradients, decoder first
 
@@ -119,6 +120,17 @@ class Trainer:
                 if hook_type is not None and hasattr(self.net, '_register_builtin_comm_hook'):
                     self.net._register_builtin_comm_hook(hook_type.ALLREDUCE)
             self._grads_in_buckets = os.environ.get('ICN_NO_GRAD_VIEWS', '') != '1'
+            if self.device.type == 'cuda' and not staged:
+                # weight gradients beside the backward chain (ico_conv: 'bucketed'): every parameter reports when its gradient
+                # is handed to autograd, so that the current stream can wait for the side stream just before a bucket's
+                # all-reduce is launched
+                for q in self.model.parameters():
+                    q.register_hook(lambda g, q=q: parameter_gradient_ready(q))
+                self._param_hooks = True
+        ddp = self.net is not self.model
+        self._wgrad_side = (self.device.type == 'cuda' and os.environ.get('ICN_WGRAD_STREAM', '') != 'off'
+                            and (not ddp or (self._grads_in_buckets and getattr(self, '_param_hooks', False))))
+        self._bucket_of, self._bucket_sig = None, None
         self.optimizer = optim.Adam(self.model.parameters(), lr=cfg['lr'])    # run.py:446 (torch.optim.Adam, step on HIP)
         self.scheduler = None
         if 'lr_base' in cfg and 'lr_max' in cfg:                                               # run.py:448-450
@@ -137,6 +149,35 @@ class Trainer:
                 dist.broadcast(host, src=0)
                 t.copy_(host)
 
+    def _weight_gradient_mode(self):
+        """Where this step's weight gradients run (ico_conv.set_weight_gradient_stream).  Without DistributedDataParallel nobody
+        looks at a gradient before backward() returns: 'deferred'.  With it: 'bucketed' once the reducer's bucket views have
+        been the same for two steps in a row (it rebuilds its buckets after the first iteration), 'off' until then."""
+        if not self._wgrad_side:
+            return 'off', None
+        if self.net is self.model:
+            return 'deferred', None
+        if self._bucket_of is None:
+            return 'off', None
+        return 'bucketed', self._bucket_of
+
+    def _read_bucket_map(self):
+        """After a backward under DistributedDataParallel: parameter -> bucket, read off the gradient views' storages."""
+        of, sig = {}, []
+        for q in self.model.parameters():
+            g = q.grad
+            if g is None:
+                self._bucket_of, self._bucket_sig = None, None
+                return
+            key = g.untyped_storage().data_ptr()
+            of[q] = key
+            sig.append((key, g.data_ptr()))
+        if sig == self._bucket_sig:
+            if self._bucket_of is None:
+                self._bucket_of = of                      # stable for two steps: arm
+        else:
+            self._bucket_of, self._bucket_sig = None, sig
+
     def step(self, img, lbl, keep_output=False):
         """One batch of run.py:244-254.  Returns the loss tensor (no host sync).  keep_output: leave the model's output
         of this batch in self.last_output (the reference's train() keeps the last one for the VAE `misc`, run.py:274-276)."""
@@ -147,10 +188,16 @@ class Trainer:
                 self.last_output = output
             loss = self.criterion(output, lbl)
             self.optimizer.zero_grad()
-            loss.backward()
+            prev = set_weight_gradient_stream(*self._weight_gradient_mode())
+            try:
+                loss.backward()
+            finally:
+                set_weight_gradient_stream(*prev)
             if self._grads_in_buckets:
                 # after the reducer's hooks every .grad is a view into its bucket: the next backward writes there directly
                 _gradbuf.refresh(self.model.parameters())
+                if self._wgrad_side:
+                    self._read_bucket_map()
             self.optimizer.step()
             if self.scheduler is not None:
                 self.scheduler.step()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ICN_ABI_VERSION 4
+#define ICN_ABI_VERSION 5
 
 #define ICN_CORNER_ZEROS 0
 #define ICN_CORNER_AVERAGE 1
@@ -118,6 +118,13 @@ size_t icn_upconv_bwd_workspace_bytes(int B, int Cin, int Cout0, int Cout1, int 
 int icn_upconv_bwd(const float* x, const float* dy0, const float* dy1, const float* w0, const float* w1, float* dx, float* dw0,
                    float* dbias0, float* dw1, float* dbias1, int B, int Cin, int Cout0, int Cout1, int r_in, int corner_mode, void* ws,
                    size_t ws_bytes, void* stream);
+/* The same with the weight gradients on a stream of their own (ABI 5): the aggregate pass and dx run on `stream`; the weight
+ * gradient (and its slab reduction) on `weight_stream`, ordered after the aggregate pass by an event, so that it can run beside
+ * whatever the caller gives `stream` next.  The caller owns the join (weight_stream -> whoever reads dw*) and keeps x, dw*, ws
+ * alive for weight_stream.  weight_stream == NULL or == stream: exactly icn_upconv_bwd. */
+int icn_upconv_bwd_streams(const float* x, const float* dy0, const float* dy1, const float* w0, const float* w1, float* dx, float* dw0,
+                           float* dbias0, float* dw1, float* dbias1, int B, int Cin, int Cout0, int Cout1, int r_in, int corner_mode,
+                           void* ws, size_t ws_bytes, void* stream, void* weight_stream);
 
 /* Fused BatchNorm + ReLU of the residual blocks (training mode; replaces the torch builtins at models.py:36-40,58-62).
  * Tensors are channels-last rows (M = B * pixels, C), C in {64, 128, 256, 512, ...: C % 4 == 0 and 256 % (C/4) == 0}.

@@ -6,7 +6,7 @@ everything N ranks would run except the wire: communicator creation, DDP's reduc
 loss autograd Functions with bucket-view gradients feeding icn_adam_step, and the bucket all-reduce kernels queued on
 RCCL's stream while the persistent, spin-waiting stream-K conv kernels own every CU.
 
-Checked: gradients and the weights / BatchNorm statistics after 3 optimiser + scheduler steps are BIT-IDENTICAL to the
+Checked: gradients and the weights / BatchNorm statistics after 6 optimiser + scheduler steps are BIT-IDENTICAL to the
 trainer without DDP (a one-rank sum followed by a division by 1 must change nothing), at a small size and at the
 BASELINE configs[1] size (I5, 36 meshes).  The worker is a freshly started interpreter (spawn): the process group is
 created before anything else touches the GPU.  2 processes use the GPU (pytest + 1 worker)."""
@@ -64,14 +64,21 @@ def _worker(rank, port, out_path):
         case['params'] = len(gp)
         # three full steps (the weights moved above by nothing: no optimiser step yet; BN statistics moved equally on both)
         from geniconet_amd import _gradbuf
-        for step in range(3):
+        from geniconet_amd.ico_conv import wgrad_stream_counts
+        nsteps = 6          # the reducer rebuilds its buckets after the first iteration; the weight gradients' side stream is armed
+        #                     once the bucket views have been the same for two steps in a row
+        for step in range(nsteps):
             for tr in (plain, ddp):
                 torch.manual_seed(100 + step)
-                before = dict(_gradbuf.counts)
+                before, wb = dict(_gradbuf.counts), dict(wgrad_stream_counts)
                 loss = tr.step(x, t)
                 if tr is ddp:
                     case['leases_step%d' % step] = (_gradbuf.counts['view'] - before['view'], _gradbuf.counts['new'] - before['new'])
+                case['side_%s_step%d' % ('ddp' if tr is ddp else 'plain', step)] = (
+                    wgrad_stream_counts['side'] - wb['side'], wgrad_stream_counts['joins'] - wb['joins'])
             dist.barrier(device_ids=[0])
+        case['nsteps'] = nsteps
+        case['buckets'] = len(set(ddp._bucket_of.values())) if ddp._bucket_of else 0
         sp, sd = plain.model.state_dict(), ddp.model.state_dict()
         for k in sp:
             if not torch.equal(sp[k], sd[k]):
@@ -98,5 +105,12 @@ def test_ddp_over_rccl_at_world_size_one_is_bit_identical_to_the_plain_trainer(t
         assert c['finite'] and c['status'] == 0, c
         # in the last step every gradient the package's backward kernels produce went straight into a bucket view (all
         # parameters but the 4 of the VAE latent heads' torch-native BatchNorms), none into a new tensor
-        served, new = c['leases_step2']
+        served, new = c['leases_step%d' % (c['nsteps'] - 1)]
         assert served >= c['params'] - 4 and new == 0, c
+        # weight gradients beside the backward chain: the plain trainer joins once per backward pass; under DDP the side stream
+        # is armed by the last step, with one wait per bucket (+ the one at the end of the pass) -- and the weights above are
+        # bit-identical all the same
+        side, joins = c['side_plain_step%d' % (c['nsteps'] - 1)]
+        assert side >= 5 and joins == 1, c
+        side, joins = c['side_ddp_step%d' % (c['nsteps'] - 1)]
+        assert c['buckets'] >= 1 and side >= 5 and 1 <= joins <= c['buckets'] + 1, c
