@@ -153,7 +153,7 @@ class Trainer:
         """Where this step's weight gradients run (ico_conv.set_weight_gradient_stream).  Without DistributedDataParallel nobody
         looks at a gradient before backward() returns: 'deferred'.  With it: 'bucketed' once the reducer's bucket views have
         been the same for two steps in a row (it rebuilds its buckets after the first iteration), 'off' until then."""
-        if not self._wgrad_side:
+        if not self._wgrad_side or self.anomaly:            # (detect_anomaly reads every gradient inside the pass)
             return 'off', None
         if self.net is self.model:
             return 'deferred', None

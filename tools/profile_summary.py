@@ -29,20 +29,31 @@ def newest_run(directory, suffix):
     return [f for f in files if os.path.basename(f).split('_')[0] == pid and os.path.dirname(f) == os.path.dirname(latest)]
 
 
-# ---- 1. kernel stats of the bench command
-stats = newest_run(os.path.join(src, 'stats'), 'kernel_stats.csv')
-bench = json.loads(open(os.path.join(src, 'bench_stats.json')).read().strip().splitlines()[-1])
-steps_total = bench['steps'] + bench['warmup']
-rows = list(csv.DictReader(open(stats[0])))
-with open(os.path.join(dst, rnd + '_bench_kernel_stats.csv'), 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup %d --no-cpu-baseline  (%d steps traced; '
-            'bench line under the profiler: %.1f meshes/s, %.3f ms/step)\n' % (bench['steps'], bench['warmup'], steps_total,
-                                                                           bench['value'], bench['ms_per_step']))
-    f.write('kernel,calls,calls_per_step,total_ms,avg_us,min_us,max_us,percent\n')
-    for r in rows:
-        f.write('%s,%s,%.2f,%.3f,%.2f,%.2f,%.2f,%s\n' % (short(r['Name']).replace(',', ';'), r['Calls'], int(r['Calls']) / steps_total,
-                                                       float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3,
-                                                       float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
+# ---- 1. kernel stats of the bench command (as it runs: weight gradients on a second stream beside the other launches, so
+#         durations overlap and sum to more than the step), and of the same command with every kernel on one stream
+def write_stats(sub, bench_json, out_name, note):
+    stats = newest_run(os.path.join(src, sub), 'kernel_stats.csv')
+    if not stats or not os.path.exists(os.path.join(src, bench_json)):
+        return None
+    bench = json.loads([l for l in open(os.path.join(src, bench_json)).read().strip().splitlines() if l.startswith('{')][-1])
+    steps_total = bench['steps'] + bench['warmup']
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(dst, rnd + out_name), 'w') as f:
+        f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup %d --no-cpu-baseline%s  (%d steps traced; '
+                'bench line under the profiler: %.1f meshes/s, %.3f ms/step)\n' % (bench['steps'], bench['warmup'], note, steps_total,
+                                                                               bench['value'], bench['ms_per_step']))
+        f.write('kernel,calls,calls_per_step,total_ms,avg_us,min_us,max_us,percent\n')
+        for r in rows:
+            f.write('%s,%s,%.2f,%.3f,%.2f,%.2f,%.2f,%s\n' % (short(r['Name']).replace(',', ';'), r['Calls'], int(r['Calls']) / steps_total,
+                                                           float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3,
+                                                           float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
+    return stats
+
+
+stats = write_stats('stats', 'bench_stats.json', '_bench_kernel_stats.csv', '')
+write_stats('stats_one_stream', 'bench_stats_one_stream.json', '_bench_kernel_stats_one_stream.csv',
+            '  [ICN_WGRAD_STREAM=off: every kernel on one stream]')
+bench = json.loads([l for l in open(os.path.join(src, 'bench_stats.json')).read().strip().splitlines() if l.startswith('{')][-1])
 
 # ---- 2. PMC passes: per-kernel mean counter value per dispatch
 pmc = collections.defaultdict(dict)
