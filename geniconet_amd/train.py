@@ -21,7 +21,12 @@ import torch.distributed as dist
 from . import _gradbuf, losses, models, optim
 from .ico_conv import parameter_gradient_ready, set_weight_gradient_stream
 
-GRAD_BUCKET_MB = 5   # ~4 buckets for the 18.5 MB (AE) / 24 MB (VAE) of fp32 gradients, decoder first
+# DistributedDataParallel's gradient buckets, decoder first: 18.5 MB (AE) / 24 MB (VAE) of fp32 gradients.  Every bucket boundary
+# is a point where the weight gradients on the second stream have to be complete (ico_conv: 'bucketed'), so fewer buckets
+# cost less there -- measured at world size 1 over RCCL, meshes/s: 5 MB 4215, 10 MB 4295, 25 MB 4304, no DDP 4320 -- and more
+# all-reduce time is left uncovered behind the last gradient (estimated at N = 8 over xGMI: ~0.07 / 0.10 / 0.17 ms for the
+# three sizes).  10 MB is the better trade on those numbers; ICN_BUCKET_MB overrides it for tuning on a real node.
+GRAD_BUCKET_MB = float(os.environ.get('ICN_BUCKET_MB', '10'))
 
 
 def force_ddp_requested():
