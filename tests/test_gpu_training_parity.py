@@ -340,6 +340,58 @@ def test_eval_mode_forward_matches_the_oracle(name):
             assert rel_l2(net.encode(xg)[0].cpu().numpy(), mu_r.numpy()) < TOL
 
 
+@pytest.mark.parametrize('name', ['ico2ico', 'ico2ico_vae'])
+def test_weight_gradients_on_the_second_stream_change_nothing(name):
+    """the Trainer puts the weight-gradient launches on a second HIP stream and joins once per backward pass
+    ('deferred').  Same kernels, same order per tensor: weights, BatchNorm statistics and Adam state after four steps are
+    BIT-identical to a trainer that keeps everything on one stream, at a small size and at I5 / batch 36; also the 'eager'
+    mode (join before every Function returns) through the operators directly, and the mode switch's argument checks."""
+    from geniconet_amd import data, models
+    from geniconet_amd.ico_conv import set_weight_gradient_stream, wgrad_stream_counts
+    from geniconet_amd.train import Trainer
+    dev = torch.device('cuda', 0)
+    for R, B in ((3, 3), (5, 36)) if name == 'ico2ico' else ((3, 2),):
+        p = models.default_params(name, subdivisions=R)
+        p[name].update(lr=1e-4, lr_base=1e-4, lr_max=1e-3)
+        two, one = Trainer(p, dev, seed=21), Trainer(p, dev, seed=22)
+        one.model.load_state_dict(two.model.state_dict())
+        assert two._wgrad_side and two._weight_gradient_mode()[0] == 'deferred'
+        one._wgrad_side = False
+        x, t = data.synthetic_batch(B, R, seed=70, device=dev)
+        x = x.contiguous(memory_format=torch.channels_last)
+        for step in range(4):
+            for tr in (two, one):
+                torch.manual_seed(300 + step)                 # the VAE draws its noise from the default generator
+                before = dict(wgrad_stream_counts)
+                loss = tr.step(x, t)
+                d_side, d_join = wgrad_stream_counts['side'] - before['side'], wgrad_stream_counts['joins'] - before['joins']
+                assert (d_side >= 5 and d_join == 1) if tr is two else (d_side == 0 and d_join == 0), (name, step, d_side, d_join)
+        assert torch.isfinite(loss)
+        s2, s1 = two.model.state_dict(), one.model.state_dict()
+        assert [k for k in s1 if not torch.equal(s1[k], s2[k])] == []
+        for q2, q1 in zip(two.model.parameters(), one.model.parameters()):
+            assert torch.equal(two.optimizer.state[q2]['exp_avg_sq'], one.optimizer.state[q1]['exp_avg_sq'])
+        del two, one
+    # the operators by themselves: 'off' unless somebody opts in; 'eager' waits before each backward Function returns
+    from geniconet_amd.ico_conv import ico_conv
+    assert set_weight_gradient_stream('off')[0] == 'off'
+    xs = torch.randn(2, 64, 20, 8, device='cuda', requires_grad=True)
+    w = (torch.randn(64, 64, 7, device='cuda') / 21).requires_grad_(True)
+    b = torch.randn(64, device='cuda', requires_grad=True)
+    want = torch.autograd.grad(ico_conv(xs, w, b, 2, 1, 'average').square().sum(), (xs, w, b))
+    for mode in ('eager', 'deferred'):
+        set_weight_gradient_stream(mode)
+        try:
+            got = torch.autograd.grad(ico_conv(xs, w, b, 2, 1, 'average').square().sum(), (xs, w, b))
+        finally:
+            set_weight_gradient_stream('off')
+        assert all(torch.equal(g, h) for g, h in zip(got, want)), mode
+    with pytest.raises(ValueError):
+        set_weight_gradient_stream('sideways')
+    with pytest.raises(ValueError):
+        set_weight_gradient_stream('bucketed')                # needs the parameter -> bucket map
+
+
 def test_inference_batchnorm_runs_fused_on_the_running_statistics():
     """Eval mode without an autograd graph (serving, `--process test`): relu(bn(a) [+ bn(b)]) is ONE pass of icn_bn_relu_fwd on
     the running statistics.  Against torch's own eval-mode modules to 1e-6; the cached [mean | 1/std] vector follows the
