@@ -8,8 +8,11 @@ A step = one pass of the hot path over one batch: forward -> P2P loss -> zero_gr
 (reference run.py:244-254) on 36 synthetic I5 meshes per GPU already resident in HBM.  Weak scaling: per-GPU
 batch fixed; gradients averaged by bucketed RCCL all-reduce overlapped with backward.
 Rank 0 prints ONE JSON line, with
-  roofline     : the dominant MFMA kernel, timed live with HIP events on its launch stream over the timed region
-                 (achieved = algorithmic FLOPs per launch / mean launch duration), vs 157.3 TFLOP/s dense fp32 MFMA;
+  roofline     : the dominant MFMA kernel, timed live with HIP events on its launch stream (achieved = algorithmic FLOPs per
+                 launch / mean launch duration), vs 157.3 TFLOP/s dense fp32 MFMA.  The training step runs its weight
+                 gradients on a second stream beside the other launches; a launch that shares the chip has no
+                 roofline of its own, so the events are taken in the survey steps, which run on one stream, and the timed
+                 region carries none (ICN_WGRAD_STREAM=off: one stream throughout, events over the timed region);
   cpu_baseline : the CPU restatement of the same step (oracle/) timed on this host's cores (N=1 only).
 """
 import argparse
