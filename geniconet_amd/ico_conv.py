@@ -96,14 +96,16 @@ def _backward_pass_over():
 def parameter_gradient_ready(param):
     """Tensor hook of a parameter (registered by the Trainer under DistributedDataParallel): its gradient is about to be
     accumulated, after which the reducer may launch the all-reduce of the parameter's bucket."""
-    if _wgrad_mode[0] != 'bucketed' or not _join_queued[0]:      # (nothing was put on the side stream in this pass so far)
+    if _wgrad_mode[0] != 'bucketed':
         return
+    pending = _join_queued[0]                                    # something was put on the side stream in this pass so far
     k = _buckets['of'].get(id(param))
     if k is None:                                                # not in the map: take no chances
-        _join_now()
+        if pending:
+            _join_now()
         return
-    left = _buckets['left'][k] = _buckets['left'].get(k, 1) - 1
-    if left <= 0:
+    left = _buckets['left'][k] = _buckets['left'].get(k, 1) - 1  # (every gradient counts, also those that arrive before the
+    if left <= 0 and pending:                                    #  first weight gradient of the pass went to the side stream)
         _join_now()
 
 

@@ -113,4 +113,5 @@ def test_ddp_over_rccl_at_world_size_one_is_bit_identical_to_the_plain_trainer(t
         side, joins = c['side_plain_step%d' % (c['nsteps'] - 1)]
         assert side >= 5 and joins == 1, c
         side, joins = c['side_ddp_step%d' % (c['nsteps'] - 1)]
-        assert c['buckets'] >= 1 and side >= 5 and 1 <= joins <= c['buckets'] + 1, c
+        # (the first bucket to complete may hold nothing from the side stream yet -- no wait then --, every later one waits)
+        assert c['buckets'] >= 2 and side >= 5 and c['buckets'] <= joins <= c['buckets'] + 1, c

@@ -1,0 +1,74 @@
+"""The bookkeeping that decides when the current stream has to wait for the weight gradients' stream under
+DistributedDataParallel (geniconet_amd/ico_conv.py, mode 'bucketed'), on the CPU with the stream wait replaced
+by a recorder: a wait is due exactly when the LAST gradient of a bucket is handed to autograd and something has gone to the
+side stream in this backward pass -- gradients that arrive before the first side launch count too."""
+import importlib
+
+import pytest
+import torch
+
+ic = importlib.import_module('geniconet_amd.ico_conv')
+
+
+@pytest.fixture
+def recorder(monkeypatch):
+    calls = []
+    monkeypatch.setattr(ic, '_join_now', lambda: calls.append('join'))
+    prev = ic.set_weight_gradient_stream('off')
+    yield calls
+    ic._join_queued[0] = False
+    ic.set_weight_gradient_stream(*prev) if prev[0] != 'bucketed' else ic.set_weight_gradient_stream('off')
+
+
+def test_a_wait_is_issued_when_a_buckets_last_gradient_arrives(recorder):
+    ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(7)]
+    bucket_of = {ps[0]: 'A', ps[1]: 'A', ps[2]: 'A', ps[3]: 'B', ps[4]: 'B', ps[5]: 'C', ps[6]: 'C'}
+    for _pass in range(2):                                    # the countdown is rearmed for every pass
+        ic.set_weight_gradient_stream('bucketed', bucket_of)
+        del recorder[:]
+        ic.parameter_gradient_ready(ps[0])                    # head / BatchNorm gradients: nothing on the side stream yet
+        ic.parameter_gradient_ready(ps[1])
+        assert recorder == []
+        ic._join_queued[0] = True                             # the first weight gradient of the pass went to the side stream
+        ic.parameter_gradient_ready(ps[3])
+        assert recorder == []                                 # B is not complete
+        ic.parameter_gradient_ready(ps[2])                    # A complete -- its first two gradients arrived before the side launch
+        assert recorder == ['join']
+        ic.parameter_gradient_ready(ps[4])                    # B complete
+        assert recorder == ['join', 'join']
+        ic.parameter_gradient_ready(ps[5])
+        assert recorder == ['join', 'join']
+        ic.parameter_gradient_ready(ps[6])                    # C complete
+        assert recorder == ['join', 'join', 'join']
+        ic._backward_pass_over()                              # end of the pass: the final wait, counters rearmed
+        assert recorder == ['join'] * 4 and not ic._join_queued[0]
+        assert ic._buckets['left'] == {'A': 3, 'B': 2, 'C': 2}
+
+
+def test_a_bucket_that_completes_before_any_side_launch_needs_no_wait_and_unknown_parameters_take_no_chances(recorder):
+    ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(3)]
+    ic.set_weight_gradient_stream('bucketed', {ps[0]: 'A', ps[1]: 'B'})
+    ic.parameter_gradient_ready(ps[0])                        # A complete, nothing pending
+    assert recorder == []
+    ic.parameter_gradient_ready(ps[2])                        # not in the map, nothing pending
+    assert recorder == []
+    ic._join_queued[0] = True
+    ic.parameter_gradient_ready(ps[2])                        # not in the map, something pending: wait
+    assert recorder == ['join']
+    ic.parameter_gradient_ready(ps[1])
+    assert recorder == ['join', 'join']
+
+
+def test_modes_other_than_bucketed_ignore_the_hooks_and_the_switch_checks_its_arguments(recorder):
+    p = torch.nn.Parameter(torch.zeros(1))
+    for mode in ('off', 'deferred', 'eager'):
+        ic.set_weight_gradient_stream(mode)
+        ic._join_queued[0] = True
+        ic.parameter_gradient_ready(p)
+        assert recorder == []
+    ic._join_queued[0] = False
+    with pytest.raises(ValueError):
+        ic.set_weight_gradient_stream('bucketed')
+    with pytest.raises(ValueError):
+        ic.set_weight_gradient_stream('both')
+    assert ic.set_weight_gradient_stream('off')[0] == 'eager'
