@@ -23,7 +23,7 @@ from .ico_conv import parameter_gradient_ready, set_weight_gradient_stream
 
 # DistributedDataParallel's gradient buckets, decoder first: 18.5 MB (AE) / 24 MB (VAE) of fp32 gradients.  Every bucket boundary
 # is a point where the weight gradients on the second stream have to be complete (ico_conv: 'bucketed'), so fewer buckets
-# cost less there -- measured at world size 1 over RCCL, meshes/s: 5 MB 4215, 10 MB 4295, 25 MB 4304, no DDP 4320 -- and more
+# cost less there -- measured at world size 1 over RCCL, meshes/s: 5 MB 4160, 10 MB 4222, 25 MB 4276, no DDP 4322 -- and more
 # all-reduce time is left uncovered behind the last gradient (estimated at N = 8 over xGMI: ~0.07 / 0.10 / 0.17 ms for the
 # three sizes).  10 MB is the better trade on those numbers; ICN_BUCKET_MB overrides it for tuning on a real node.
 GRAD_BUCKET_MB = float(os.environ.get('ICN_BUCKET_MB', '10'))
