@@ -56,7 +56,7 @@ _wgrad_mode = [os.environ.get('ICN_WGRAD_STREAM', 'off')]
 if _wgrad_mode[0] not in _MODES:
     raise ValueError('ICN_WGRAD_STREAM must be one of %s' % (_MODES,))
 _side_streams = {}
-_join_queued = [False]
+_pending = [False]                                  # something went to the side stream since the current stream last waited for it
 _buckets = {'of': {}, 'size': {}, 'left': {}}       # id(param) -> bucket key; bucket key -> parameters in it / still to come
 wgrad_stream_counts = {'side': 0, 'joins': 0}        # launches put on the side stream / waits issued (tests, diagnostics)
 
@@ -84,12 +84,15 @@ def set_weight_gradient_stream(mode, bucket_of=None):
 def _join_now():
     for dev_index, side in _side_streams.items():
         torch.cuda.current_stream(dev_index).wait_stream(side)
+    _pending[0] = False
     wgrad_stream_counts['joins'] += 1
 
 
 def _backward_pass_over():
-    _join_queued[0] = False
-    _join_now()
+    """Autograd-engine callback at the end of a backward pass (queued by every side-stream launch of the pass, so that a pass is
+    never left without it; the first one to run does the waiting)."""
+    if _pending[0]:
+        _join_now()
     _buckets['left'] = dict(_buckets['size'])
 
 
@@ -98,7 +101,7 @@ def parameter_gradient_ready(param):
     accumulated, after which the reducer may launch the all-reduce of the parameter's bucket."""
     if _wgrad_mode[0] != 'bucketed':
         return
-    pending = _join_queued[0]                                    # something was put on the side stream in this pass so far
+    pending = _pending[0]                                        # something is on the side stream that nobody has waited for
     k = _buckets['of'].get(id(param))
     if k is None:                                                # not in the map: take no chances
         if pending:
@@ -121,8 +124,8 @@ def _wgrad_stream(dev, *tensors):
     for t in tensors:
         if t is not None:
             t.record_stream(side)
-    if _wgrad_mode[0] != 'eager' and not _join_queued[0]:
-        _join_queued[0] = True
+    _pending[0] = True
+    if _wgrad_mode[0] != 'eager':
         torch.autograd.Variable._execution_engine.queue_callback(_backward_pass_over)
     wgrad_stream_counts['side'] += 1
     return side
@@ -132,6 +135,7 @@ def _wgrad_done(dev, side):
     """End of a backward Function that put its weight gradient on `side`: in 'eager' mode the current stream waits for it."""
     if side is not None and _wgrad_mode[0] == 'eager':
         torch.cuda.current_stream(dev).wait_stream(side)
+        _pending[0] = False
         wgrad_stream_counts['joins'] += 1
 
 

@@ -13,10 +13,13 @@ ic = importlib.import_module('geniconet_amd.ico_conv')
 @pytest.fixture
 def recorder(monkeypatch):
     calls = []
-    monkeypatch.setattr(ic, '_join_now', lambda: calls.append('join'))
+    def join():
+        calls.append('join')
+        ic._pending[0] = False
+    monkeypatch.setattr(ic, '_join_now', join)
     prev = ic.set_weight_gradient_stream('off')
     yield calls
-    ic._join_queued[0] = False
+    ic._pending[0] = False
     ic.set_weight_gradient_stream(*prev) if prev[0] != 'bucketed' else ic.set_weight_gradient_stream('off')
 
 
@@ -29,19 +32,22 @@ def test_a_wait_is_issued_when_a_buckets_last_gradient_arrives(recorder):
         ic.parameter_gradient_ready(ps[0])                    # head / BatchNorm gradients: nothing on the side stream yet
         ic.parameter_gradient_ready(ps[1])
         assert recorder == []
-        ic._join_queued[0] = True                             # the first weight gradient of the pass went to the side stream
+        ic._pending[0] = True                                 # the first weight gradient of the pass went to the side stream
         ic.parameter_gradient_ready(ps[3])
         assert recorder == []                                 # B is not complete
         ic.parameter_gradient_ready(ps[2])                    # A complete -- its first two gradients arrived before the side launch
         assert recorder == ['join']
-        ic.parameter_gradient_ready(ps[4])                    # B complete
-        assert recorder == ['join', 'join']
+        ic.parameter_gradient_ready(ps[4])                    # B complete, but nothing went to the side stream since the last wait
+        assert recorder == ['join']
+        ic._pending[0] = True                                 # another weight gradient
         ic.parameter_gradient_ready(ps[5])
-        assert recorder == ['join', 'join']
+        assert recorder == ['join']
         ic.parameter_gradient_ready(ps[6])                    # C complete
-        assert recorder == ['join', 'join', 'join']
+        assert recorder == ['join', 'join']
+        ic._pending[0] = True                                 # the last layer's weight gradient
         ic._backward_pass_over()                              # end of the pass: the final wait, counters rearmed
-        assert recorder == ['join'] * 4 and not ic._join_queued[0]
+        ic._backward_pass_over()                              # (queued once per side launch: the later ones find nothing to wait for)
+        assert recorder == ['join'] * 3 and not ic._pending[0]
         assert ic._buckets['left'] == {'A': 3, 'B': 2, 'C': 2}
 
 
@@ -52,9 +58,10 @@ def test_a_bucket_that_completes_before_any_side_launch_needs_no_wait_and_unknow
     assert recorder == []
     ic.parameter_gradient_ready(ps[2])                        # not in the map, nothing pending
     assert recorder == []
-    ic._join_queued[0] = True
+    ic._pending[0] = True
     ic.parameter_gradient_ready(ps[2])                        # not in the map, something pending: wait
     assert recorder == ['join']
+    ic._pending[0] = True
     ic.parameter_gradient_ready(ps[1])
     assert recorder == ['join', 'join']
 
@@ -63,10 +70,10 @@ def test_modes_other_than_bucketed_ignore_the_hooks_and_the_switch_checks_its_ar
     p = torch.nn.Parameter(torch.zeros(1))
     for mode in ('off', 'deferred', 'eager'):
         ic.set_weight_gradient_stream(mode)
-        ic._join_queued[0] = True
+        ic._pending[0] = True
         ic.parameter_gradient_ready(p)
         assert recorder == []
-    ic._join_queued[0] = False
+    ic._pending[0] = False
     with pytest.raises(ValueError):
         ic.set_weight_gradient_stream('bucketed')
     with pytest.raises(ValueError):
