@@ -178,18 +178,18 @@ def main():
     for _ in range(args.warmup - n_survey):
         tr.step(x, t)
     survey = []
-    overlapped = bool(getattr(tr, '_wgrad_side', False))    # weight gradients on a second stream beside the backward chain
+    overlapped = bool(getattr(tr, 'overlap_weight_gradients', False))    # weight gradients on a second stream beside the backward chain
     if n_survey:
         # The survey steps run every kernel on ONE stream: a launch's duration is a property of the kernel only when nothing
         # else shares the chip with it.  (In the timed region the weight gradients overlap the other launches; their
         # durations there are longer and sum to more than the step.)
-        tr._wgrad_side = False
+        tr.overlap_weight_gradients = False
         torch.cuda.synchronize()
         _lib.profile_start(200 * n_survey)
         for _ in range(n_survey):
             tr.step(x, t)
         survey = _lib.profile_stop()
-        tr._wgrad_side = overlapped
+        tr.overlap_weight_gradients = overlapped
     dominant = max(survey, key=lambda e: e['total_ms'])['kernel'] if survey else None
     barrier()
     # One stream: the dominant kernel carries events through the timed region (the roofline measurement).  Overlapped: its

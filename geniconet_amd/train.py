@@ -133,7 +133,9 @@ class Trainer:
                     q.register_hook(lambda g, q=q: parameter_gradient_ready(q))
                 self._param_hooks = True
         ddp = self.net is not self.model
-        self._wgrad_side = (self.device.type == 'cuda' and os.environ.get('ICN_WGRAD_STREAM', '') != 'off'
+        # public switch: weight gradients on a second HIP stream beside the backward chain (ico_conv / DESIGN 4.2b); may be
+        # turned off (and on again) between steps
+        self.overlap_weight_gradients = (self.device.type == 'cuda' and os.environ.get('ICN_WGRAD_STREAM', '') != 'off'
                             and (not ddp or (self._grads_in_buckets and getattr(self, '_param_hooks', False))))
         self._bucket_of, self._bucket_sig = None, None
         self.optimizer = optim.Adam(self.model.parameters(), lr=cfg['lr'])    # run.py:446 (torch.optim.Adam, step on HIP)
@@ -158,7 +160,7 @@ class Trainer:
         """Where this step's weight gradients run (ico_conv.set_weight_gradient_stream).  Without DistributedDataParallel nobody
         looks at a gradient before backward() returns: 'deferred'.  With it: 'bucketed' once the reducer's bucket views have
         been the same for two steps in a row (it rebuilds its buckets after the first iteration), 'off' until then."""
-        if not self._wgrad_side or self.anomaly:            # (detect_anomaly reads every gradient inside the pass)
+        if not self.overlap_weight_gradients or self.anomaly:            # (detect_anomaly reads every gradient inside the pass)
             return 'off', None
         if self.net is self.model:
             return 'deferred', None
@@ -201,7 +203,7 @@ class Trainer:
             if self._grads_in_buckets:
                 # after the reducer's hooks every .grad is a view into its bucket: the next backward writes there directly
                 _gradbuf.refresh(self.model.parameters())
-                if self._wgrad_side:
+                if self.overlap_weight_gradients:
                     self._read_bucket_map()
             self.optimizer.step()
             if self.scheduler is not None:

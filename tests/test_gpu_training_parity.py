@@ -355,8 +355,8 @@ def test_weight_gradients_on_the_second_stream_change_nothing(name):
         p[name].update(lr=1e-4, lr_base=1e-4, lr_max=1e-3)
         two, one = Trainer(p, dev, seed=21), Trainer(p, dev, seed=22)
         one.model.load_state_dict(two.model.state_dict())
-        assert two._wgrad_side and two._weight_gradient_mode()[0] == 'deferred'
-        one._wgrad_side = False
+        assert two.overlap_weight_gradients and two._weight_gradient_mode()[0] == 'deferred'
+        one.overlap_weight_gradients = False
         x, t = data.synthetic_batch(B, R, seed=70, device=dev)
         x = x.contiguous(memory_format=torch.channels_last)
         for step in range(4):
