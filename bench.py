@@ -174,8 +174,10 @@ def main():
     # kernels are timed during the last warm-up steps (table of kernels, executed FLOPs per step, which kernel dominates),
     # and in the timed region only the dominant kernel carries events -- that is the `roofline` measurement.
     events = not args.no_kernel_events
-    n_survey = min(2, args.warmup) if events else 0
-    for _ in range(args.warmup - n_survey):
+    # (two survey steps always -- they count towards the W warm-up steps when W >= 2, and are extra untimed steps otherwise:
+    #  a roofline block must not depend on the caller asking for warm-up)
+    n_survey = 2 if events else 0
+    for _ in range(max(args.warmup - n_survey, 0)):
         tr.step(x, t)
     survey = []
     overlapped = bool(getattr(tr, 'overlap_weight_gradients', False))    # weight gradients on a second stream beside the backward chain
