@@ -198,7 +198,11 @@ class _IcoConvFn(torch.autograd.Function):
                 db = _gradbuf.lease(ctx.params[1], (Cout,), w.device) if has_bias else None
                 ws_bytes = L.icn_conv_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, B, Cin, Cout, r, stride)
                 ws = _workspace(ws_bytes, gyp.device)
-                side = _wgrad_stream(gyp.device, xp, gyp, dw, db, ws)
+                # (a convolution whose input needs no gradient -- the stem -- is the last thing in the pass: its weight gradient
+                #  stays on the current stream, which has nothing else left to do, instead of queueing behind the side stream's
+                #  backlog: +1.2 %, 4346-4370 against 4298-4314 meshes/s; keeping the last one or two OTHER weight gradients on
+                #  the current stream as well loses 1 - 1.5 %)
+                side = _wgrad_stream(gyp.device, xp, gyp, dw, db, ws) if ctx.needs_input_grad[0] else None
                 rc = L.icn_conv_bwd_weight(xp.data_ptr(), gyp.data_ptr(), dw.data_ptr(),
                                            db.data_ptr() if db is not None else None, B, Cin, Cout, r, stride, mode,
                                            ws.data_ptr(), ws_bytes, side.cuda_stream if side is not None else _stream())
