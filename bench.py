@@ -174,10 +174,11 @@ def main():
     # kernels are timed during the last warm-up steps (table of kernels, executed FLOPs per step, which kernel dominates),
     # and in the timed region only the dominant kernel carries events -- that is the `roofline` measurement.
     events = not args.no_kernel_events
-    # (two survey steps always -- they count towards the W warm-up steps when W >= 2, and are extra untimed steps otherwise:
-    #  a roofline block must not depend on the caller asking for warm-up)
-    n_survey = 2 if events else 0
-    for _ in range(max(args.warmup - n_survey, 0)):
+    # (four survey steps -- 52 launches of the dominant kernel -- after the W warm-up steps the caller asked for and before the
+    #  timed region, untimed like them: surveyed earlier, among the first steps of the process, the same launches take 3 - 4 %
+    #  longer; and a roofline block must not depend on the caller asking for warm-up)
+    n_survey = 4 if events else 0
+    for _ in range(args.warmup):
         tr.step(x, t)
     survey = []
     overlapped = bool(getattr(tr, 'overlap_weight_gradients', False))    # weight gradients on a second stream beside the backward chain
@@ -187,7 +188,7 @@ def main():
         # durations there are longer and sum to more than the step.)
         tr.overlap_weight_gradients = False
         torch.cuda.synchronize()
-        _lib.profile_start(200 * n_survey)
+        _lib.profile_start(250 * n_survey)
         for _ in range(n_survey):
             tr.step(x, t)
         survey = _lib.profile_stop()
@@ -262,7 +263,7 @@ def main():
                 # per-kernel figures count the FLOPs a launch executes (= algorithmic for ordinary convolutions; the composite
                 # upsample+conv launches of the decoder execute 0.68 x / 0.25 x of the operators they replace), so frac <= 1
                 'flops_counted': 'executed',
-                # the other MFMA kernels: from the 2 surveyed warm-up steps (events around every launch)
+                # the other MFMA kernels: from the survey steps (events around every launch)
                 'all_mfma_kernels': [{'kernel': e['kernel'], 'launches_per_step': e['launches'] / n_survey,
                                       'avg_launch_us': round(e['total_ms'] / e['launches'] * 1e3, 2),
                                       'tflops': round(e['total_flops'] / (e['total_ms'] * 1e-3) / 1e12, 2)} for e in survey],

@@ -36,8 +36,8 @@ def write_stats(sub, bench_json, out_name, note):
     if not stats or not os.path.exists(os.path.join(src, bench_json)):
         return None
     bench = json.loads([l for l in open(os.path.join(src, bench_json)).read().strip().splitlines() if l.startswith('{')][-1])
-    # (an overlapped run has 2 more, untimed, steps behind the timed region: bench.py)
-    steps_total = bench['steps'] + bench['warmup'] + (2 if (bench.get('roofline') or {}).get('weight_gradients_on_second_stream') else 0)
+    # (bench.py runs 4 survey steps between warm-up and timed region, and an overlapped run 2 more, untimed, behind it)
+    steps_total = bench['steps'] + bench['warmup'] + 4 + (2 if (bench.get('roofline') or {}).get('weight_gradients_on_second_stream') else 0)
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(dst, rnd + out_name), 'w') as f:
         f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup %d --no-cpu-baseline%s  (%d steps traced; '
