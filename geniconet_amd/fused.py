@@ -188,6 +188,9 @@ class counters_deferred:
 
 
 def _bump(bn):
+    # the fused statistics kernels update running_mean / running_var through raw pointers, which does not move the tensors'
+    # version counters: the eval-mode cache (below) keyed on them would go stale after a training step -> drop the entry here
+    _eval_stats.pop(bn, None)
     if _defer_depth > 0:
         _pending_counters.append(bn.num_batches_tracked)
     else:
