@@ -6,9 +6,10 @@ its bucket view with one small kernel per parameter (`mul_out(bucket_view, grad,
 launches and 0.36 ms per step for this model (measured with rocprofv3, profiles/r03_ddp_vs_plain.txt), 3 % of a step.  The
 backward kernels of this package can write a gradient wherever they are told, so the trainer remembers each parameter's bucket
 view after a backward (`refresh`) and the Functions ask for it (`lease`) instead of allocating: the reducer finds the gradient
-already aliasing its bucket and launches nothing.  Purely an optimisation: a stale or missing view only means the reducer
-copies as before (it checks `is_alias_of`), and a parameter is leased at most once per backward, so a parameter used twice in
-a graph accumulates correctly through freshly allocated tensors.
+already aliasing its bucket and launches nothing.  A stale or missing view means the reducer copies as before (it checks
+`is_alias_of`) -- ON THE CURRENT STREAM, so a gradient that was not served from its view must not be written on the weight
+gradients' side stream (ico_conv._readers_can_wait asks `served_from_view`); a parameter is leased at most once per backward,
+so a parameter used twice in a graph accumulates correctly through freshly allocated tensors.
 
 Nothing here is specific to DDP: any `.grad` tensor kept from the previous backward is a valid destination.
 """
@@ -49,3 +50,10 @@ def lease(param, shape, device, dtype=torch.float32, stride=None):
     if stride is not None:
         return torch.empty_strided(tuple(shape), tuple(stride), dtype=dtype, device=device)
     return torch.empty(tuple(shape), dtype=dtype, device=device)
+
+
+def served_from_view(param, grad):
+    """True when `grad` (returned by lease) IS the remembered view of param's gradient storage."""
+    v = getattr(param, _ATTR, None) if isinstance(param, torch.nn.Parameter) else None
+    return (v is not None and grad is not None and v.data_ptr() == grad.data_ptr() and tuple(v.shape) == tuple(grad.shape)
+            and v.stride() == grad.stride())

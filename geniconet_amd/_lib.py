@@ -134,9 +134,10 @@ def device_status(device=None, clear=True, synchronize=True):
     return v
 
 
-def raise_on_device_status(device=None):
-    """Synchronise `device` and raise if a kernel reported a failure since the last check."""
-    v = device_status(device)
+def raise_on_device_status(device=None, synchronize=True):
+    """Raise if a kernel reported a failure since the last check; `synchronize` first waits for the device (without it only
+    the kernels that have completed are covered: use it right after a point that synchronised anyway)."""
+    v = device_status(device, synchronize=synchronize)
     if v:
         raise RuntimeError('libicn: asynchronous kernel failure on %s: %s' % (
             device if device is not None else 'the current device',

@@ -1114,8 +1114,21 @@ static const int* tile_lists(const GatherGemmArgs& a, int bm, int bn, int ntiles
     return cache.emplace(key, d).first->second;
 }
 
+
+// The DMA kernels address sources, side buffers and (since the buffer-store epilogue) destinations through 32-bit buffer
+// offsets.  launch_gather_gemm_auto only routes here after conv_dma_usable(); a direct caller that skipped it gets an
+// exception instead of wrapped offsets (silently dropped or misplaced stores).
+static void check_dma_ranges(const GatherGemmArgs& a) {
+    const size_t Ks = a.src2 ? a.K / 2 : a.K;
+    const size_t nb = a.segs.nseg > 0 ? (size_t)a.segs.B : (size_t)(a.M / a.Pd);
+    const size_t dst_bytes = nb * a.Pd * (size_t)std::max(a.dst2 ? a.N0 : a.N, a.dst2 ? a.N - a.N0 : 0) * 4;
+    if (nb * a.Ps * Ks * 4 >= ((size_t)1 << 31) || nb * a.n_slots * Ks * 4 >= ((size_t)1 << 30) || dst_bytes >= (size_t)0xFFF00000u)
+        throw std::invalid_argument("icn: tensor beyond the LDS-DMA kernels' 32-bit buffer offsets");
+}
+
 template <int BM, int BN, bool SEG>
 static void launch_conv_dma_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
+    check_dma_ranges(a);
     const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);   // class-major rows: M is a multiple of 8 * BM
     int grid = std::min(ntiles, 256 * occ);              // (more blocks than slots: measured, no difference -- DESIGN 4.2)
     if (grid >= 8) grid -= grid % 8;                     // keep a block's tiles in one residue class mod 8 (one XCD)
@@ -1199,6 +1212,7 @@ static const int* sk_boundary_tables(int ntiles, int grid, int S, int occ) {
 
 template <int BM, int BN, bool SEG>
 static void launch_conv_dma_sk_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
+    check_dma_ranges(a);
     const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);   // SEG: M is the padded row count
     const int grid = 256 * occ;                           // every block slot of the chip: all of them resident at once
     if ((size_t)grid * BM * BN * sizeof(float) > conv_sk_part_bytes() || grid > CONV_SK_ERROR)

@@ -57,8 +57,11 @@ if _wgrad_mode[0] not in _MODES:
     raise ValueError('ICN_WGRAD_STREAM must be one of %s' % (_MODES,))
 _side_streams = {}
 _pending = [False]                                  # something went to the side stream since the current stream last waited for it
+_seen = {}                                          # id(parameter) -> one of its gradients of THIS backward pass is on the side stream
+_callback_queued = [False]                          # the end-of-pass callback has been queued for this backward pass
 _buckets = {'of': {}, 'size': {}, 'left': {}}       # id(param) -> bucket key; bucket key -> parameters in it / still to come
-wgrad_stream_counts = {'side': 0, 'joins': 0}        # launches put on the side stream / waits issued (tests, diagnostics)
+wgrad_stream_counts = {'side': 0, 'joins': 0, 'kept': 0}   # launches put on the side stream / waits issued / launches kept on
+                                                          # the current stream because a reader could not wait (tests, diagnostics)
 
 
 def set_weight_gradient_stream(mode, bucket_of=None):
@@ -89,10 +92,12 @@ def _join_now():
 
 
 def _backward_pass_over():
-    """Autograd-engine callback at the end of a backward pass (queued by every side-stream launch of the pass, so that a pass is
-    never left without it; the first one to run does the waiting)."""
+    """Autograd-engine callback at the end of a backward pass (queued by the pass's first weight-gradient launch in a
+    side-stream mode): the current stream waits for the side stream, the per-pass bookkeeping is forgotten."""
     if _pending[0]:
         _join_now()
+    _seen.clear()
+    _callback_queued[0] = False
     _buckets['left'] = dict(_buckets['size'])
 
 
@@ -112,21 +117,54 @@ def parameter_gradient_ready(param):
         _join_now()
 
 
-def _wgrad_stream(dev, *tensors):
+def _readers_can_wait(q, g):
+    """True when nothing reads the gradient tensor `g` of parameter `q` on the CURRENT stream before the pass's join, i.e. when
+    writing it on the side stream is safe.  Autograd and DistributedDataParallel do read it whenever it is not simply taken as
+    `q.grad` (or found aliasing its bucket):
+      * `q.grad` exists (gradient accumulation, `zero_grad(set_to_none=False)`): AccumulateGrad runs `q.grad += g`;
+      * `q` already received a gradient in this pass (a module applied twice in one graph): the engine adds the two;
+      * `q` is not a leaf: `g` flows on into other backward nodes;
+      * somebody's tensor hook / post-accumulate hook on `q` looks at it ('deferred'; under 'bucketed' the Trainer's own
+        countdown hooks are the ones registered);
+      * 'bucketed': `g` is not the parameter's bucket view (the lease fell back to a new tensor), so the reducer copies it
+        into the bucket -- on the current stream, and only the bucket's LAST gradient is preceded by a join."""
+    if not isinstance(q, torch.Tensor) or not q.is_leaf or q.grad is not None or id(q) in _seen:
+        return False
+    if _wgrad_mode[0] == 'bucketed':
+        return _gradbuf.served_from_view(q, g)
+    return not (q._backward_hooks or getattr(q, '_post_accumulate_grad_hooks', None))
+
+
+def _wgrad_stream(dev, dests, *tensors):
     """The side stream for a weight-gradient launch issued from inside a backward pass, ordered after everything the current
-    stream has been given so far; `tensors` (allocated on the current stream) are kept alive for it.  None: mode 'off'."""
+    stream has been given so far; `dests` = [(parameter, tensor its gradient is about to be written to)], `tensors` (allocated
+    on the current stream) are kept alive for the side stream.  None -- the launch stays on the current stream -- in mode 'off'
+    and whenever one of the destinations could be read on the current stream before the join (_readers_can_wait); when an
+    earlier gradient of one of these parameters is still on the side stream, the current stream waits for it first."""
     if _wgrad_mode[0] == 'off':
+        return None
+    dests = [(q, g) for q, g in dests if g is not None]
+    ok = _wgrad_mode[0] == 'eager' or (all(_readers_can_wait(q, g) for q, g in dests)
+                                        and len({id(q) for q, _ in dests}) == len(dests))        # (one tensor as both weights)
+    if _wgrad_mode[0] != 'eager' and not _callback_queued[0]:
+        torch.autograd.Variable._execution_engine.queue_callback(_backward_pass_over)     # once per pass: join + forget `_seen`
+        _callback_queued[0] = True
+    again = any(_seen.get(id(q), False) for q, _ in dests)
+    for q, _ in dests:
+        _seen[id(q)] = _seen.get(id(q), False) or ok
+    if not ok:
+        if again and _pending[0]:
+            _join_now()
+        wgrad_stream_counts['kept'] += 1
         return None
     side = _side_streams.get(dev.index)
     if side is None:
         side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
-    for t in tensors:
+    for t in tensors + tuple(g for _, g in dests):
         if t is not None:
             t.record_stream(side)
     _pending[0] = True
-    if _wgrad_mode[0] != 'eager':
-        torch.autograd.Variable._execution_engine.queue_callback(_backward_pass_over)
     wgrad_stream_counts['side'] += 1
     return side
 
@@ -202,7 +240,8 @@ class _IcoConvFn(torch.autograd.Function):
                 #  stays on the current stream, which has nothing else left to do, instead of queueing behind the side stream's
                 #  backlog: +1.2 %, 4346-4370 against 4298-4314 meshes/s; keeping the last one or two OTHER weight gradients on
                 #  the current stream as well loses 1 - 1.5 %)
-                side = _wgrad_stream(gyp.device, xp, gyp, dw, db, ws) if ctx.needs_input_grad[0] else None
+                side = (_wgrad_stream(gyp.device, [(ctx.params[0], dw), (ctx.params[1], db)], xp, gyp, ws)
+                        if ctx.needs_input_grad[0] else None)
                 rc = L.icn_conv_bwd_weight(xp.data_ptr(), gyp.data_ptr(), dw.data_ptr(),
                                            db.data_ptr() if db is not None else None, B, Cin, Cout, r, stride, mode,
                                            ws.data_ptr(), ws_bytes, side.cuda_stream if side is not None else _stream())
@@ -266,7 +305,7 @@ class _IcoConvPairFn(torch.autograd.Function):
                     db1 = _gradbuf.lease(pb1, (C1,), w1.device)
                 ws_bytes = L.icn_conv_pair_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, B, Cin, C0, C1, r, stride)
                 ws = _workspace(ws_bytes, g0.device)
-                side = _wgrad_stream(g0.device, xp, g0, g1, dw0, db0, dw1, db1, ws)
+                side = _wgrad_stream(g0.device, [(pw0, dw0), (pb0, db0), (pw1, dw1), (pb1, db1)], xp, g0, g1, ws)
                 rc = L.icn_conv_pair_bwd_weight(xp.data_ptr(), g0.data_ptr(), g1.data_ptr(), dw0.data_ptr(),
                                                 db0.data_ptr() if db0 is not None else None, dw1.data_ptr(),
                                                 db1.data_ptr() if db1 is not None else None, B, Cin, C0, C1, r, stride, mode,
@@ -371,7 +410,8 @@ class _IcoUpConvPairFn(torch.autograd.Function):
             ptr = lambda t: t.data_ptr() if t is not None else None
             with torch.cuda.device(dev):
                 # the weight gradients (after the aggregate pass, which stays on the current stream) on the side stream
-                side = _wgrad_stream(dev, xp, ws, dw0, db0, dw1, db1) if want_w else None
+                side = (_wgrad_stream(dev, [(pw0, dw0), (pb0, db0), (pw1, dw1), (pb1, db1)], xp, ws)
+                        if want_w else None)
                 _lib.check(L.icn_upconv_bwd_streams(xp.data_ptr(), g0.data_ptr(), g1.data_ptr(), w0.data_ptr(), w1.data_ptr(),
                                                     ptr(dxp), ptr(dw0), ptr(db0), ptr(dw1), ptr(db1), B, Cin, C0, C1, r, mode,
                                                     ws.data_ptr(), ws_bytes, _stream(),

@@ -208,10 +208,19 @@ class Trainer:
             self.optimizer.step()
             if self.scheduler is not None:
                 self.scheduler.step()
-        if self.check_device_status and self.device.type == 'cuda':
-            from . import _lib
-            _lib.raise_on_device_status(self.device)
+        if self.check_device_status:
+            self.check_status(synchronize=True)
         return loss.detach()
+
+    def check_status(self, synchronize=False):
+        """Raise if a kernel reported an asynchronous failure (icn_device_status: e.g. a lost stream-K partner, which otherwise
+        only shows as NaNs that Adam then writes into every weight).  Without `synchronize` this only reads a word in pinned
+        host memory, so it is called wherever the host has just synchronised anyway -- a loss converted to a float
+        (validate, fit), a checkpoint written -- and covers every kernel that ran before that point.  ICN_CHECK=1 /
+        check_device_status=True additionally synchronises and checks after every step."""
+        if self.device.type == 'cuda':
+            from . import _lib
+            _lib.raise_on_device_status(self.device, synchronize=synchronize)
 
     @torch.no_grad()
     def evaluate(self, img, lbl):
@@ -250,6 +259,7 @@ def save_checkpoint(trainer, log_dir, epoch, val_loss=None, misc=None, model_nam
     os.makedirs(os.path.dirname(path), exist_ok=True)
     torch.save({'model_state_dict': trainer.model.state_dict(), 'optimizer_state_dict': trainer.optimizer.state_dict(),
                 'epoch': epoch if isinstance(epoch, int) else int(str(epoch)[1:]), 'loss': val_loss, 'misc': misc}, path)
+    trainer.check_status()                    # (the tensors were just copied to the host: everything before is complete)
     return path
 
 
@@ -294,7 +304,9 @@ def train_epoch(trainer, dataset, batch_size, shuffle=True, generator=None, misc
 @torch.no_grad()
 def validate(trainer, dataset, batch_size):
     """run.py:280-315 (validate()): eval mode, no grad, the unweighted mean over batches of the criterion's total loss."""
-    return float(torch.stack([trainer.evaluate(img, lbl) for img, lbl in dataset.batches(batch_size)]).mean())
+    loss = float(torch.stack([trainer.evaluate(img, lbl) for img, lbl in dataset.batches(batch_size)]).mean())
+    trainer.check_status()                    # (the float() synchronised)
+    return loss
 
 
 def fit(trainer, trn, val, epochs, batch_size, log_dir=None, model_name=None, seed=0, first_epoch=1, best_loss=float('inf'),
@@ -320,6 +332,7 @@ def fit(trainer, trn, val, epochs, batch_size, log_dir=None, model_name=None, se
     for epoch in range(first_epoch, first_epoch + epochs):
         got = {}
         trn_loss = float(train_epoch(trainer, trn, batch_size, True, gen, misc=got).mean())
+        trainer.check_status()                # (the float() synchronised: covers the epoch's kernels)
         misc = got or None
         val_loss = validate(trainer, val, batch_size)
         history.append((epoch, trn_loss, val_loss))

@@ -12,9 +12,11 @@ import torch
 
 from conftest import rel_l2
 from oracle import loss_ref, models_ref
+from relu_pattern import capture_relu_outputs, check_flips, gradient_errors, relu_pattern, worst
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+GRAD_TOL = 1e-3         # network gradients at a fixed activation pattern (relu_pattern.py); the contract's bound is 2e-3
 
 
 def _product(ref, name, R):
@@ -56,9 +58,10 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
     from identical state and nothing is amplified from step to step (Adam's first steps are ~ lr * sign(g): free-running
     trajectories drift apart at rounding-noise-level gradient elements, which is why the earlier free-running form of this
     test needed a 15 % bound and a list of exempt tensors).  Per step k = 0..3, a different batch each:
-      1. forward + loss + backward on both sides: loss to 1e-4 relative, every parameter gradient to 2e-3 rel-L2 (denominators
-         floored at 1e-3 of the largest gradient norm: conv biases in front of a train-mode BatchNorm have a zero true
-         gradient), BatchNorm running statistics to 1e-4;
+      1. forward + loss + backward on both sides: loss to 1e-4 relative, BatchNorm running statistics to 1e-4; EVERY parameter
+         gradient to 1e-3 rel-L2 (half the contract's 2e-3; denominators floored at 1e-3 of the largest gradient norm: conv
+         biases in front of a train-mode BatchNorm have a zero true gradient) against the float64 oracle evaluated at the GPU
+         forward's own ReLU activation pattern -- tests/relu_pattern.py; one acceptance path, no calibration;
       2. the CPU gradients are copied into the GPU parameters' .grad, and Adam + CyclicLR step on both sides from IDENTICAL
          gradients, moments, step counts and learning rate.  The HIP Adam (icn_adam_step) must then reproduce torch's update on
          EVERY tensor, no exemptions: exp_avg and exp_avg_sq to 1e-6 rel-L2, every weight element within 2 ulp (of the
@@ -79,7 +82,11 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
     noise_step = _fixed_noise(monkeypatch, R, B, STEPS) if name == 'ico2ico_vae' else {'k': 0}
     names = [k for k, _ in cpu.model.named_parameters()]
     pg, pc = dict(gpu.model.named_parameters()), dict(cpu.model.named_parameters())
+    relu_outs, _hooks = capture_relu_outputs(gpu.model)
+    n_relu = 1 + 2 * (6 if name == 'ico2ico' else 5)              # stem + two per residual block
+    flips_seen = []
     for k in range(STEPS):
+        relu_outs.clear()
         # -- teacher forcing: CPU state -> GPU (weights + BN buffers, Adam moments and step counts, scheduler position)
         gpu.model.load_state_dict(cpu.model.state_dict())
         if k > 0:
@@ -100,46 +107,34 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
             loss.backward()
             outs[tr.device.type] = float(loss)
         assert abs(outs['cuda'] - outs['cpu']) <= 1e-4 * abs(outs['cpu']), (k, outs)
-        floor = 1e-3 * max(float(q.grad.norm()) for q in pc.values())
-        g64 = None
-        for key in names:
-            err = float((pg[key].grad.cpu() - pc[key].grad).norm()) / max(float(pc[key].grad.norm()), floor)
-            if err >= 2e-3:
-                # The gradient of this network is a DISCONTINUOUS function of the forward pass: a ReLU pre-activation within fp32
-                # rounding of zero (13 layers x 1e5 values at this test size: a few per evaluation are expected) passes or blocks
-                # its whole upstream gradient depending on which side the rounding lands, and one such flip moves the small
-                # cancelling sums of the BatchNorm backward below it by 1e-3 .. 1e-2 (measured: tools/diag_gradient_error.py; torch's
-                # own device kernels show the same).  So beyond the usual bound the question is whether the GPU result lies
-                # within what fp32-level perturbations do to the float64 gradient itself: the float64 oracle is re-evaluated
-                # with every weight and input perturbed by 1e-6 relative (the size of the forward's accumulated rounding),
-                # three times, and the GPU gradient may be as far from float64 as 3 x the largest of those changes, or
-                # 1.5 x the CPU fp32 oracle's distance + 5e-4.
-                if g64 is None:
-                    def grad64(seed):
-                        ref64 = getattr(models_ref, name)(R=R).train()
-                        ref64.load_state_dict(before_fwd)
-                        ref64 = ref64.double()
-                        xx = x.double()
-                        if seed is not None:
-                            gen = torch.Generator().manual_seed(seed)
-                            with torch.no_grad():
-                                for q in ref64.parameters():
-                                    q.mul_(1 + 1e-6 * torch.randn(q.shape, generator=gen, dtype=torch.float64))
-                                xx = xx * (1 + 1e-6 * torch.randn(xx.shape, generator=gen, dtype=torch.float64))
-                        build_criterion(p, 'cpu').double()(ref64(xx), t.double()).backward()
-                        return {kk: q.grad for kk, q in ref64.named_parameters()}
-                    g64 = grad64(None)
-                    sens = {}
-                    for trial in range(3):
-                        gp = grad64(1000 + 10 * k + trial)
-                        for kk in g64:
-                            d_ = float((gp[kk] - g64[kk]).norm()) / max(float(g64[kk].norm()), floor)
-                            sens[kk] = max(sens.get(kk, 0.0), d_)
-                den = max(float(g64[key].norm()), floor)
-                e_gpu = float((pg[key].grad.cpu().double() - g64[key]).norm()) / den
-                e_cpu = float((pc[key].grad.double() - g64[key]).norm()) / den
-                assert e_gpu <= max(1.5 * e_cpu + 5e-4, 3.0 * sens[key]), (k, key, err, e_gpu, e_cpu, sens[key])
-                assert e_gpu < 3e-2, (k, key, e_gpu)           # and never grossly off
+        # -- gradients: the float64 oracle evaluated AT THE GPU'S ACTIVATION PATTERN (tests/relu_pattern.py: the gradient is a
+        #    discontinuous function of the forward pass, a ReLU pre-activation within fp32 rounding of zero flips it by
+        #    1e-3 .. 1e-2; with the pattern fixed both sides are smooth functions of identical structure) -- every tensor
+        #    to GRAD_TOL, one acceptance path.  Where the GPU's pattern differs from the oracle's own, the oracle's
+        #    pre-activation must be < 1e-4 of its tensor's rms (the flip is a rounding event, not a forward error).
+        ref64 = getattr(models_ref, name)(R=R).train()
+        ref64.load_state_dict(before_fwd)
+        ref64 = ref64.double()
+        with relu_pattern(relu_outs) as pat:
+            out64 = ref64(x.double())
+        build_criterion(p, 'cpu').double()(out64, t.double()).backward()
+        n_flips = check_flips(pat, n_relu)
+        errs = gradient_errors(pg, dict(ref64.named_parameters()))
+        assert set(errs) == set(names)
+        assert worst(errs)[0] < GRAD_TOL, (k, n_flips, sorted(((v, kk) for kk, v in errs.items()), reverse=True)[:5])
+        flips_seen.append(n_flips)
+        if n_flips:
+            # what the flips do to a comparison that ignores them (the unpatterned float64 oracle): reported, and capped --
+            # never grossly off, and the CPU fp32 oracle is the same distance from float64 at the tensors it flips itself
+            ref64u = getattr(models_ref, name)(R=R).train()
+            ref64u.load_state_dict(before_fwd)
+            ref64u = ref64u.double()
+            build_criterion(p, 'cpu').double()(ref64u(x.double()), t.double()).backward()
+            eu = gradient_errors(pg, dict(ref64u.named_parameters()))
+            over = sorted(((v, kk) for kk, v in eu.items() if v >= GRAD_TOL), reverse=True)
+            print('step %d: %d ReLU flips %s; %d tensors beyond %.0e against the unpatterned oracle: %s'
+                  % (k, n_flips, pat.flips, len(over), GRAD_TOL, over[:6]))
+            assert all(v < 3e-2 for v, _ in over), over
         sg, sc = gpu.model.state_dict(), cpu.model.state_dict()
         for key in sc:
             if 'num_batches_tracked' in key:
@@ -390,6 +385,94 @@ def test_weight_gradients_on_the_second_stream_change_nothing(name):
         set_weight_gradient_stream('sideways')
     with pytest.raises(ValueError):
         set_weight_gradient_stream('bucketed')                # needs the parameter -> bucket map
+
+
+def test_second_stream_guards_readers_it_cannot_see():
+    """ico_conv._readers_can_wait on the device (VERDICT r3 / ADVICE r3): under 'deferred' a weight gradient that autograd
+    would READ on the current stream before the join stays there.
+      (1) gradient accumulation: two backward passes without zero_grad -- in the second every .grad exists, AccumulateGrad runs
+          `grad += dw` on the current stream;
+      (2) zero_grad(set_to_none=False);
+      (3) a module applied twice in one graph: the engine adds the two weight gradients on the current stream.
+    All three bit-identical to mode 'off', with the counters showing who went where."""
+    from geniconet_amd import data, models
+    from geniconet_amd.ico_conv import IcoConvS2S, set_weight_gradient_stream, wgrad_stream_counts
+    from geniconet_amd.train import build_criterion
+    R, B = 4, 8
+    p = models.default_params('ico2ico', subdivisions=R)
+    crit = build_criterion(p, 'cuda')
+    xs = [data.synthetic_batch(B, R, seed=90 + k, device='cuda') for k in range(2)]
+    xs = [(x.contiguous(memory_format=torch.channels_last), t) for x, t in xs]
+
+    def run(mode, set_to_none):
+        torch.manual_seed(7)
+        net = models.ico2ico(p).cuda().to(memory_format=torch.channels_last).train()
+        counts = []
+        for k, (x, t) in enumerate(xs):
+            if k == 1 and not set_to_none:
+                net.zero_grad(set_to_none=False)              # (2): grads stay allocated (zeros)
+            before = dict(wgrad_stream_counts)
+            prev = set_weight_gradient_stream(mode)
+            try:
+                crit(net(x), t).backward()                    # (1): no zero_grad between the two passes when set_to_none
+            finally:
+                set_weight_gradient_stream(*prev)
+            counts.append({c: wgrad_stream_counts[c] - before[c] for c in before})
+        torch.cuda.synchronize()
+        return {k: q.grad.clone() for k, q in net.named_parameters()}, counts
+
+    for set_to_none in (True, False):
+        want, _ = run('off', set_to_none)
+        got, counts = run('deferred', set_to_none)
+        assert counts[0]['side'] >= 5 and counts[0]['kept'] == 0 and counts[0]['joins'] == 1, counts      # first pass: grads are None
+        assert counts[1]['side'] == 0 and counts[1]['kept'] >= 5, counts                                   # second: every .grad exists
+        assert [k for k in want if not torch.equal(want[k], got[k])] == []
+    # (3) one IcoConvS2S applied twice in a graph
+    torch.manual_seed(8)
+    conv = IcoConvS2S(64, 64, 1, True, 3, 'average').cuda()
+    x = torch.randn(4, 64, 40, 16, device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_()
+    res = {}
+    for mode in ('off', 'deferred'):
+        conv.zero_grad()
+        x.grad = None
+        before = dict(wgrad_stream_counts)
+        prev = set_weight_gradient_stream(mode)
+        try:
+            conv(torch.relu(conv(x))).square().mean().backward()
+        finally:
+            set_weight_gradient_stream(*prev)
+        torch.cuda.synchronize()
+        res[mode] = (conv.weight.grad.clone(), conv.bias.grad.clone(), x.grad.clone(),
+                     {c: wgrad_stream_counts[c] - before[c] for c in before})
+    assert res['deferred'][3]['side'] == 1 and res['deferred'][3]['kept'] == 1, res['deferred'][3]
+    assert all(torch.equal(a, b) for a, b in zip(res['off'][:3], res['deferred'][:3]))
+
+
+def test_validation_after_fused_training_steps_uses_the_current_running_statistics():
+    """the fused training path updates running_mean / running_var through raw pointers (no version bump), so
+    the eval-mode cache of [mean | 1/std] must be dropped by the training step itself.  The loop of run.py:479-487 -- step,
+    validate, step, validate -- against the same model evaluated through torch's own BatchNorm modules (hooked BatchNorms take
+    the module path), each time."""
+    from geniconet_amd import data, models
+    from geniconet_amd.train import Trainer
+    R, B = 3, 4
+    p = models.default_params('ico2ico', subdivisions=R)
+    p['ico2ico'].update(lr=1e-3, lr_base=1e-3, lr_max=1e-2)
+    tr = Trainer(p, 'cuda', seed=5)
+    xv, tv = data.synthetic_batch(B, R, seed=7, device='cuda')
+    xv = xv.contiguous(memory_format=torch.channels_last)
+    seen = []
+    for k in range(3):
+        x, t = data.synthetic_batch(B, R, seed=20 + k, device='cuda')
+        tr.step(x.contiguous(memory_format=torch.channels_last), t)
+        fused_val = float(tr.evaluate(xv, tv))                                 # fused eval path (cached statistics vector)
+        hooks = [m.register_forward_hook(lambda *a: None) for m in tr.model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        plain_val = float(tr.evaluate(xv, tv))                                 # torch's eval-mode BatchNorm modules
+        for h in hooks:
+            h.remove()
+        assert abs(fused_val - plain_val) <= 1e-5 * abs(plain_val), (k, fused_val, plain_val)
+        seen.append(fused_val)
+    assert len(set(seen)) == 3                                                # the statistics (and weights) did move
 
 
 def test_inference_batchnorm_runs_fused_on_the_running_statistics():

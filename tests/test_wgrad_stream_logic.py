@@ -79,3 +79,39 @@ def test_modes_other_than_bucketed_ignore_the_hooks_and_the_switch_checks_its_ar
     with pytest.raises(ValueError):
         ic.set_weight_gradient_stream('both')
     assert ic.set_weight_gradient_stream('off')[0] == 'eager'
+
+
+def test_a_weight_gradient_stays_on_the_current_stream_when_somebody_could_read_it_before_the_join(recorder):
+    """ico_conv._readers_can_wait: the side stream is only taken for a gradient that autograd simply adopts as `.grad` (or, under
+    DistributedDataParallel, finds aliasing its bucket).  Anything that makes autograd or the reducer READ it on the current
+    stream -- an existing .grad, a second use of the parameter in the same pass, a non-leaf weight, a tensor hook, a lease that
+    was not served from the bucket view -- keeps the launch on the current stream."""
+    from geniconet_amd import _gradbuf
+    ic._seen.clear()
+    q = torch.nn.Parameter(torch.zeros(4))
+    g = torch.zeros(4)
+    ic.set_weight_gradient_stream('deferred')
+    assert ic._readers_can_wait(q, g)
+    q.grad = torch.zeros(4)                                   # accumulation / zero_grad(set_to_none=False)
+    assert not ic._readers_can_wait(q, g)
+    q.grad = None
+    ic._seen[id(q)] = True                                    # already received a gradient in this pass
+    assert not ic._readers_can_wait(q, g)
+    ic._seen.clear()
+    assert not ic._readers_can_wait(q * 2, g)                 # non-leaf: the gradient flows on
+    h = q.register_hook(lambda grad: None)                    # somebody looks at it
+    assert not ic._readers_can_wait(q, g)
+    h.remove()
+    assert ic._readers_can_wait(q, g)
+    # 'bucketed': only when the lease was served from the remembered bucket view
+    ic.set_weight_gradient_stream('bucketed', {q: 'A'})
+    assert not ic._readers_can_wait(q, g)                     # no view remembered: the reducer would copy on the current stream
+    q.grad = torch.zeros(4)
+    _gradbuf.refresh([q])
+    q.grad = None
+    leased = _gradbuf.lease(q, (4,), torch.device('cpu'))
+    assert _gradbuf.served_from_view(q, leased) and ic._readers_can_wait(q, leased)
+    again = _gradbuf.lease(q, (4,), torch.device('cpu'))      # second lease in one pass: a new tensor
+    assert not _gradbuf.served_from_view(q, again) and not ic._readers_can_wait(q, again)
+    ic._backward_pass_over()
+    assert ic._seen == {} and not ic._callback_queued[0]
