@@ -12,7 +12,8 @@ import torch
 
 from conftest import rel_l2
 from oracle import loss_ref, models_ref
-from relu_pattern import capture_relu_outputs, check_flips, gradient_errors, relu_pattern, worst
+from relu_pattern import capture_relu_outputs, check_flips, gradient_errors, relu_pattern
+from relu_pattern import worst as worst_of
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -105,7 +106,7 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
             tr.optimizer.zero_grad()
             loss = tr.criterion(tr.net(xx), tt)
             loss.backward()
-            outs[tr.device.type] = float(loss)
+            outs[tr.device.type] = float(loss.detach())
         assert abs(outs['cuda'] - outs['cpu']) <= 1e-4 * abs(outs['cpu']), (k, outs)
         # -- gradients: the float64 oracle evaluated AT THE GPU'S ACTIVATION PATTERN (tests/relu_pattern.py: the gradient is a
         #    discontinuous function of the forward pass, a ReLU pre-activation within fp32 rounding of zero flips it by
@@ -121,7 +122,7 @@ def test_training_steps_teacher_forced_against_the_oracle_trainer(name, monkeypa
         n_flips = check_flips(pat, n_relu)
         errs = gradient_errors(pg, dict(ref64.named_parameters()))
         assert set(errs) == set(names)
-        assert worst(errs)[0] < GRAD_TOL, (k, n_flips, sorted(((v, kk) for kk, v in errs.items()), reverse=True)[:5])
+        assert worst_of(errs)[0] < GRAD_TOL, (k, n_flips, sorted(((v, kk) for kk, v in errs.items()), reverse=True)[:5])
         flips_seen.append(n_flips)
         if n_flips:
             # what the flips do to a comparison that ignores them (the unpatterned float64 oracle): reported, and capped --

@@ -220,6 +220,120 @@ void run_w(int blocks_per_cu, const float* src, unsigned src_bytes, float* out) 
     printf("tile %3dx%-3d  %d waves (%d x %d)  %d block(s)/CU  %.3f ms  %.1f TFLOP/s\n", BM, BN, WR * WC, WR, WC, blocks_per_cu, best, flops / best / 1e9);
 }
 
+// Producer / consumer waves ("warp specialisation"): WR x WC consumer waves do nothing but fragment reads + MFMAs + the step
+// barrier; ONE extra wave issues every LDS-DMA of a stage (all (BM + BN) / 8 instructions), waits for the previous stage with
+// the counted vmcnt and joins the same barrier.  The consumers' instruction streams then contain no DMA issue, no address
+// arithmetic and no vmcnt wait -- the 13 % "stage issue" of the production K-step (profiles/r03_kstep_decomposition.txt) moves
+// to a wave that does not use the MFMA pipe.  Level-4 traffic, 3-stage ring.
+template <int BM, int BN, int WR, int WC>
+__global__ __launch_bounds__(64 * (WR * WC + 1)) void k_ladder_p(const float* src, unsigned src_bytes, float* out, int steps, int rows_total) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WR * WC, NST = 3;
+    constexpr int TM = BM / WR / 32, TN = BN / WC / 32, NA = BM / 8, NB = BN / 8, NDMA = NA + NB;   // DMA instructions per stage (one wave)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);
+    float* Bs = As + NST * BM * BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5, rsub = lane >> 3, pc = lane & 7;
+    for (int i = tid; i < NST * (BM + BN) * BK; i += 64 * (NW + 1)) As[i] = 1e-3f * (float)((i * 37) % 101 - 50);
+    __syncthreads();
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+    const int a_rows = 92160;
+    const unsigned b_base = (unsigned)a_rows * 1024u;
+    const int shift[7] = {0, 64, 1, -63, -64, -1, 63};
+    if (wave == NW) {
+        // ---- producer
+        auto dma = [&](int slot, int step) {
+            const int tile = (blockIdx.x + (step / 56) * gridDim.x) % (a_rows / BM);
+            const int t = step % 7, kc = (step / 7) % 8;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                int row = tile * BM + 8 * i + rsub + shift[t];
+                row = row < 0 ? row + a_rows : (row >= a_rows ? row - a_rows : row);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(As + slot * BM * BK + 8 * i * BK), 16,
+                                                         (unsigned)row * 1024u + 16u * (pc ^ swz(8 * i + rsub)), kc * 128, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(Bs + slot * BN * BK + 8 * i * BK), 16,
+                                                         b_base + (unsigned)(t * BN + 8 * i + rsub) * 1024u + 16u * (pc ^ swz(8 * i + rsub)),
+                                                         kc * 128, 0, 0);
+        };
+        dma(0, 0);
+        dma(1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int iring = NST - 1;
+        for (int step = 0; step < steps; ++step) {
+            dma(iring, step + NST - 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA > 63 ? 63 : NDMA) : "memory");
+            __builtin_amdgcn_s_barrier();
+            iring = iring == NST - 1 ? 0 : iring + 1;
+        }
+        return;
+    }
+    // ---- consumers
+    const int wr = wave / WC, wc = wave % WC;
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fl = swz(l31);
+    f32x4 fa[2][TM], fb[2][TN];
+    int ring = 0;
+    __builtin_amdgcn_s_barrier();
+    for (int step = 0; step < steps; ++step) {
+        const float* a_base = As + ring * BM * BK + (wr * (BM / WR) + l31) * BK;
+        const float* b_base = Bs + ring * BN * BK + (wc * (BN / WC) + l31) * BK;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + 4 * (h ^ fl));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BK + 4 * (h ^ fl));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                const int off = 4 * ((2 * (kk + 1) + h) ^ fl);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[(kk + 1) & 1][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + off);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[(kk + 1) & 1][j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BK + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i][s], fb[kk & 1][j][s], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ring = ring == NST - 1 ? 0 : ring + 1;
+    }
+    float sum = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    out[(blockIdx.x * 64 * NW + tid) % (1024 * 256)] = sum;
+#endif
+}
+
+template <int BM, int BN, int WR, int WC>
+void run_p(int blocks_per_cu, const float* src, unsigned src_bytes, float* out) {
+    const int blocks = 256 * blocks_per_cu, steps = 4000 / blocks_per_cu * 8192 / (BM * BN);
+    const size_t lds = (size_t)3 * (BM + BN) * BK * 4;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ladder_p<BM, BN, WR, WC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_ladder_p<BM, BN, WR, WC>), dim3(blocks), dim3(64 * (WR * WC + 1)), lds, 0, src, src_bytes, out, steps, (int)(src_bytes / 1024));
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+    }
+    const double flops = (double)blocks * steps * 2.0 * BM * BN * BK;
+    printf("tile %3dx%-3d  %d consumer waves (%d x %d) + 1 producer  %d block(s)/CU  %.3f ms  %.1f TFLOP/s\n", BM, BN, WR * WC, WR, WC, blocks_per_cu, best, flops / best / 1e9);
+}
+
 // "BK = 64 as two stages": 4 ring slots = 2 double-stages; at the top of a double-step the two stages of the NEXT double-step
 // are issued, both stages are computed, then vmcnt(0) + one barrier -- half the barriers per FLOP, 2 blocks per CU for 64x64.
 template <int BM, int BN>
@@ -392,6 +506,21 @@ int main(int argc, char** argv) {
             run_w<128, 128, 2, 4>(1, src, src_bytes, out);    // 8 waves of 64 x 32
             run_w<128, 128, 4, 4>(1, src, src_bytes, out);    // 16 waves of 32 x 32
             run_w<128, 256, 2, 4>(1, src, src_bytes, out);    // 144 KB: 8 waves of 64 x 64
+        }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'p') {   // producer / consumer waves against the production structure
+        for (int rep = 0; rep < 2; ++rep) {
+            run_w<64, 128, 2, 2>(2, src, src_bytes, out);     // production shape
+            run_p<64, 128, 2, 2>(2, src, src_bytes, out);
+            run_w<64, 64, 2, 2>(3, src, src_bytes, out);      // production shape
+            run_p<64, 64, 2, 2>(3, src, src_bytes, out);
+            run_w<128, 64, 2, 2>(2, src, src_bytes, out);
+            run_p<128, 64, 2, 2>(2, src, src_bytes, out);
+            run_w<128, 128, 2, 2>(1, src, src_bytes, out);
+            run_p<128, 128, 2, 2>(1, src, src_bytes, out);
+            run_p<128, 128, 2, 4>(1, src, src_bytes, out);    // 8 consumers of 64 x 32 + 1 producer
+            run_p<64, 128, 2, 4>(2, src, src_bytes, out);     // 8 consumers of 32 x 32 + 1 producer
         }
         return 0;
     }
