@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('ICN_LIB_PATH') or os.path.join(_HERE, 'libicn.so')
 
 OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT = 0, 1, 2
 CORNER_MODES = {'zeros': 0, 'average': 1}
-ABI_VERSION = 5
+ABI_VERSION = 6
 LAP_MODES = {'mean-v': 0, 'v-mean': 1, 'sum-kv': 2, 'kv-sum': 3}   # ICN_LAP_* of include/icn.h
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses
@@ -72,6 +72,7 @@ SIGNATURES = {
     'icn_debug_trace': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     'icn_point_to_mesh': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [ctypes.c_void_p]),
     'icn_table_conv_fwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t]),
+    'icn_table_wgrad7': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint16), ctypes.c_size_t, _intp]),
     'icn_table_conv_bwd': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, ctypes.c_size_t, _intp]),
     'icn_table_upsample': (ctypes.c_long, [ctypes.c_int] * 3 + [_i32p, _f32p, ctypes.c_size_t, _intp]),
     'icn_table_upsample_pairs': (ctypes.c_long, [ctypes.c_int, _i32p, ctypes.c_size_t]),
@@ -160,6 +161,22 @@ def table_conv_fwd(r_in, stride, corner_mode):
     out = np.empty(n, dtype=np.int32)
     L.icn_table_conv_fwd(r_in, stride, m, out.ctypes.data_as(_i32p), n)
     return out.reshape(7, -1)
+
+
+def table_wgrad7(r_in, stride, corner_mode):
+    """Patch form of the forward table for the all-taps weight-gradient kernel: (rows [npatch][U], pos [npatch][16][8]) or
+    None when the table does not exist for this level / stride."""
+    L, m = lib(), corner_code(corner_mode)
+    meta = (ctypes.c_int * 2)()
+    n = L.icn_table_wgrad7(r_in, stride, m, None, 0, None, 0, meta)
+    if n < 0:
+        check(-1, 'icn_table_wgrad7')
+    if n == 0:
+        return None
+    U, npatch = meta[0], meta[1]
+    rows, pos = np.empty(n, dtype=np.int32), np.empty(npatch * 16 * 8, dtype=np.uint16)
+    L.icn_table_wgrad7(r_in, stride, m, rows.ctypes.data_as(_i32p), n, pos.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), pos.size, meta)
+    return rows.reshape(npatch, U), pos.reshape(npatch, 16, 8)
 
 
 def table_conv_bwd(r_in, stride, corner_mode):

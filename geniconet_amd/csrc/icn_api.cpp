@@ -81,6 +81,9 @@ struct ConvTables {
     std::vector<uint32_t> mask32_h;   // host copy: the launcher balances the tiles of a masked launch by their step counts
     int key = 0;                  // (r, stride, mode) packed: names this table set in the launcher's tile-list cache
     DevDma d_fwd, d_bwd, d_bwd1, d_virt, d_bwdp;   // DmaTable forms of fwd, bwd, bwd1, vidx, bwd_perm
+    int32_t* w7_rows = nullptr;   // patch form of d_fwd for the all-taps weight gradient (icn::Wg7Table), or null (stride 2, r < 2)
+    uint16_t* w7_pos = nullptr;
+    int w7_U = 0;
 };
 struct UpTables {
     int Pc = 0, Pf = 0, Wf = 0, Wb = 0;
@@ -220,6 +223,16 @@ ConvTables make_conv_tables(int r_in, int stride, int mode) {
     t.bwd = upload(bwd);
     t.d_fwd = upload_dma(fwd, 1, t.Pout);
     t.d_bwd = upload_dma(bwd, t.E, t.Pin);
+    {
+        icn::DmaTable h;
+        icn::build_dma_table(fwd, 1, t.Pout, h);
+        icn::Wg7Table w7;
+        if (icn::build_wgrad7(h, t.Pout, stride == 1 ? 64 : 112, w7)) {
+            t.w7_rows = upload(w7.urow);
+            t.w7_pos = upload(w7.upos);
+            t.w7_U = w7.U;
+        }
+    }
     std::vector<int32_t> primary;
     icn::VirtualRows vr;
     icn::split_conv_bwd(r_in, stride, bwd, t.E, primary, vr);
@@ -642,6 +655,7 @@ void conv_bwd_weight_impl(const float* x, const float* dy0, const float* dy1, fl
     a.n_slots = t.d_fwd.n_slots; a.partial = partial; a.bias_partial = bpart; a.dw = dw0; a.dbias = db0; a.dw2 = dw1; a.dbias2 = db1;
     a.M = M; a.Ps = t.Pin; a.Pd = t.Pout; a.Cin = Cin; a.Cout = C; a.ns = t.n_in;
     a.algo_flops = 2.0 * 7 * Cin * C * (double)M;
+    a.w7_rows = t.w7_rows; a.w7_pos = t.w7_pos; a.w7_U = t.w7_U;
     icn::launch_wgrad(a, s);
 }
 
@@ -657,7 +671,7 @@ const char* const PROF_NAMES[PROF_KINDS] = {"k_conv_dma<128, 128, false>", "k_co
                                             "k_wgrad<64, 128>", "k_wgrad<64, 64>", "k_conv_dma<128, 128, true>",
                                             "k_conv_dma<128, 64, true>", "k_conv_dma<64, 128, true>", "k_conv_dma<64, 64, true>",
                                             "k_conv_dma_sk<64, 128, false>", "k_conv_dma_sk<64, 64, false>", "k_conv_dma_sk<64, 128, true>",
-                                            "k_conv_dma_sk<64, 64, true>"};
+                                            "k_conv_dma_sk<64, 64, true>", "k_wgrad7<4>"};
 void prof_mark_begin(int kind, double flops, hipStream_t s) {
     if (!g_prof_on) return;
     g_prof_mu.lock();
@@ -1480,6 +1494,27 @@ long icn_table_conv_fwd(int r_in, int stride, int corner_mode, int32_t* out, siz
         icn::build_conv_fwd(r_in, stride, corner_mode, v);
         if (out) std::memcpy(out, v.data(), std::min(cap, v.size()) * sizeof(int32_t));
         return (long)v.size();
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
+long icn_table_wgrad7(int r_in, int stride, int corner_mode, int32_t* rows, size_t cap_rows, uint16_t* pos, size_t cap_pos, int* meta) {
+    try {
+        std::vector<int32_t> fwd;
+        icn::build_conv_fwd(r_in, stride, corner_mode, fwd);
+        const int P = (int)(fwd.size() / icn::NTAPS);
+        icn::DmaTable h;
+        icn::build_dma_table(fwd, 1, P, h);
+        icn::Wg7Table w7;
+        if (!icn::build_wgrad7(h, P, stride == 1 ? 64 : 112, w7)) {
+            if (meta) meta[0] = meta[1] = 0;
+            return 0;
+        }
+        if (meta) { meta[0] = w7.U; meta[1] = w7.npatch; }
+        if (rows) std::memcpy(rows, w7.urow.data(), std::min(cap_rows, w7.urow.size()) * sizeof(int32_t));
+        if (pos) std::memcpy(pos, w7.upos.data(), std::min(cap_pos, w7.upos.size()) * sizeof(uint16_t));
+        return (long)w7.urow.size();
     } catch (const std::exception& e) {
         return fail(e.what());
     }

@@ -224,6 +224,45 @@ void build_dma_table(const std::vector<int32_t>& idx, int E, int P, DmaTable& ou
         }
 }
 
+bool build_wgrad7(const DmaTable& d, int P, int max_U, Wg7Table& out) {
+    out = Wg7Table{};
+    if (P <= 0 || P % WG7_PX != 0 || (size_t)NTAPS * P != d.code.size()) return false;
+    const int np = P / WG7_PX;
+    std::vector<std::vector<int32_t>> lists(np);
+    size_t longest = 0;
+    for (int q = 0; q < np; ++q) {
+        std::vector<int32_t>& l = lists[q];
+        for (int k = 0; k < WG7_PX; ++k)
+            for (int t = 0; t < NTAPS; ++t) {
+                const int32_t c = d.code[(size_t)t * P + q * WG7_PX + k];
+                if (c != IDX_ZERO) l.push_back(c);
+            }
+        // pixels ascending (neighbouring rows of the tensor end up in one DMA instruction), side slots (negative codes) last
+        std::sort(l.begin(), l.end(), [](int32_t a, int32_t b) { return (a < 0) != (b < 0) ? b < 0 : (a < 0 ? a > b : a < b); });
+        l.erase(std::unique(l.begin(), l.end()), l.end());
+        longest = std::max(longest, l.size());
+    }
+    // (one fixed list length: the kernel is instantiated for max_U rows, shorter unions are padded with rows of zeros)
+    const int U = max_U;
+    if ((int)longest + 1 > U || U % 16 != 0 || (size_t)(U - 1) * WG7_ROW_BYTES > 0xFFFFu) return false;
+    out.U = U;
+    out.npatch = np;
+    out.urow.assign((size_t)np * U, IDX_ZERO);
+    out.upos.assign((size_t)np * WG7_PX * 8, (uint16_t)((U - 1) * WG7_ROW_BYTES));
+    for (int q = 0; q < np; ++q) {
+        const std::vector<int32_t>& l = lists[q];
+        for (size_t u = 0; u < l.size(); ++u) out.urow[(size_t)q * U + u] = l[u];
+        for (int k = 0; k < WG7_PX; ++k)
+            for (int t = 0; t < NTAPS; ++t) {
+                const int32_t c = d.code[(size_t)t * P + q * WG7_PX + k];
+                if (c == IDX_ZERO) continue;
+                const size_t u = std::find(l.begin(), l.end(), c) - l.begin();
+                out.upos[((size_t)q * WG7_PX + k) * 8 + t] = (uint16_t)(u * WG7_ROW_BYTES);
+            }
+    }
+    return true;
+}
+
 void build_upsample(int r_in, int corner_mode, Ell& fwd, Ell& bwd) {
     check_args(r_in, 1, corner_mode);
     const int n = 1 << r_in, nf = 2 * n;

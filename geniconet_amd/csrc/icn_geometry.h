@@ -66,6 +66,24 @@ struct DmaTable {
 };
 void build_dma_table(const std::vector<int32_t>& idx, int E, int P, DmaTable& out);
 
+// Patch form of a forward DmaTable for the all-taps weight-gradient kernel (k_wgrad7): the output pixels of a sample are cut
+// into patches of WG7_PX consecutive pixels; a patch's 7 x WG7_PX gathered rows overlap heavily (the in-row taps of
+// neighbouring pixels are each other's centre rows), so the kernel stages the UNION of the patch's source rows once:
+//   urow [npatch][U]            DmaTable codes of the union rows (pixel / -2 - slot / IDX_ZERO), sorted; row U - 1 is always
+//                               IDX_ZERO (a row of zeros: what a tap that reads nothing points at)
+//   upos [npatch][WG7_PX][8]    byte offset (row index * row_bytes) of tap t's row of pixel k inside the staged union
+//                               ([k][7] is padding); row_bytes = 256 (64 channels per workgroup tile)
+// U = max_U (a multiple of 16; shorter unions are padded).  Returns false when P is not a multiple of WG7_PX or a patch's
+// union + 1 exceeds max_U (stride 2: ~100 rows) -- the caller then keeps the per-tap kernel.
+constexpr int WG7_PX = 16;
+constexpr int WG7_ROW_BYTES = 256;
+struct Wg7Table {
+    int U = 0, npatch = 0;
+    std::vector<int32_t> urow;
+    std::vector<uint16_t> upos;
+};
+bool build_wgrad7(const DmaTable& d, int P, int max_U, Wg7Table& out);
+
 // ELL sparse matrices of the r -> r+1 upsample and of its transpose.
 struct Ell {
     int rows = 0, width = 0;

@@ -1728,6 +1728,249 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_wgrad7 (round 4): ALL SEVEN TAPS of a 64 x 64 (ci, co) tile in one workgroup, the gathered x rows staged ONCE per patch.
+//   k_wgrad_dma gives every (tap, ci tile, co tile, row split) its own short workgroup: the seven taps of a split gather seven
+//   shifted copies of the same x rows (each row of x and dy travels L2 -> LDS 7 x the tiles' count), ~2300 workgroups of 18 steps
+//   each pay their own start-up and 64 KB slab, and 330 slabs per layer go through HBM to a reduction kernel.  Here:
+//   * a stage is one PATCH of 16 consecutive output pixels.  Its 7 x 16 gathered rows overlap (the in-row taps of neighbouring
+//     pixels are each other's centre rows): the host lists the UNION of the patch's source rows once (icn_geometry.h:
+//     build_wgrad7; <= 53 of 112 rows at stride 1) and, per (pixel, tap), the row's position in that list.  The union
+//     (U x 256 B), the 16 dy rows (4 KB) and the position table (256 B) are brought in by LDS-DMA, 3-stage ring as before.
+//   * the MFMA's A operand of tap t, pixel k is then read from LDS at row pos[k][t] -- an indirect ds_read_b32 per MFMA, its
+//     offset unpacked from the 16 bytes of positions a lane fetches per pixel -- and the B operand (dy) once per pixel for all
+//     seven taps: 56 MFMAs per wave and step on 7 x 16 accumulator registers.
+//   * the launch is ONE round of 512 equal workgroups (two per CU), each owning a (ci, co) tile and a contiguous range of
+//     patches: no dispatch tail, ~3 x fewer slabs, x / dy rows travel L2 -> LDS once per (co tile) / (ci tile) instead of 7 x.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int W7_PX = 16;                    // = WG7_PX (icn_geometry.h)
+constexpr int W7_ROWF = 64;                  // floats per staged row (the tile's 64 input channels) = WG7_ROW_BYTES / 4
+
+// NI: U = 16 * NI union rows per patch (NI DMA instructions per wave and stage); NST: ring stages (3: the DMA pointer two steps
+// ahead, counted waits; 2: one step ahead, the step's 56 MFMAs per wave cover the latency, a third less LDS)
+template <int NI, int NST>
+__global__ __launch_bounds__(256, 2) void k_wgrad7(
+    const float* __restrict__ x,        // (B, Ps, Cin)
+    const float* __restrict__ dy,       // (B, Pd, Cout0)
+    const float* __restrict__ dy2,      // (B, Pd, Cout - Cout0): output channels Cout0.. (pair sharing x), or null
+    const int32_t* __restrict__ urow,   // [Pd / 16][U] union-row codes (Wg7Table)
+    const uint16_t* __restrict__ upos,  // [Pd / 16][16][8] positions (byte offsets into the staged union)
+    const float* __restrict__ side,     // (B, n_slots, Cin) pole means of x, or null
+    float* __restrict__ partial,        // [S][7][Cin][Cout]
+    float* __restrict__ bias_partial,   // [S][Cout] or null
+    int M, int Ps, int Pd, int Cin, int Cout, int Cout0, int n_slots, int patches_per_split, int n_splits, unsigned x_bytes,
+    unsigned side_bytes, unsigned long long* __restrict__ trace) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int U = 16 * NI;
+    static_assert(U <= 128 && (NST == 2 || NST == 3), "at most two code DMAs (64 dwords each) per stage");
+    constexpr int CW = U > 64 ? 128 : 64;                           // code words per stage
+    unsigned long long tr_t0 = 0;
+    if (trace) tr_t0 = __builtin_amdgcn_s_memrealtime();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE_F = U * W7_ROWF + W7_PX * 64 + 64;          // floats per ring slot: X union | Y | positions
+    float* ring = reinterpret_cast<float*>(smem);                    // [NST][STAGE_F]
+    int32_t* Cs = reinterpret_cast<int32_t*>(ring + NST * STAGE_F);  // [2][CW] union-row codes of the stage under the code pointer
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    // blocks b and b + 8 share an XCD: the (ci, co) tiles of one row split sit side by side on one XCD (they read the same rows)
+    const int ntj = Cout / 64, tiles = (Cin / 64) * ntj;
+    const int xcd = blockIdx.x % 8, jb = blockIdx.x / 8;
+    const int split = (jb / tiles) * 8 + xcd, tile = jb % tiles;
+    if (split >= n_splits) return;
+    const int ci0 = (tile / ntj) * 64, co0 = (tile % ntj) * 64;
+    const int pps = Pd / W7_PX;                                       // patches per sample
+    const int p_begin = split * patches_per_split;
+    const int p_end = min(M / W7_PX, p_begin + patches_per_split);
+    const int nsteps = p_end > p_begin ? p_end - p_begin : 0;          // (0: a split past the last patch writes zeros)
+    const bool do_bias = bias_partial != nullptr && ci0 == 0;         // block-uniform
+
+    const bool ysec = co0 >= Cout0;
+    const int yC = ysec ? Cout - Cout0 : Cout0;
+    const int yc0 = ysec ? co0 - Cout0 : co0;
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+    const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ysec ? dy2 : dy), 0, (unsigned)M * (unsigned)yC * 4u, 0x00020000);
+    const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side ? side : x), 0, side ? side_bytes : 0u, 0x00020000);
+    const auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(urow), 0, pps * U * 4, 0x00020000);
+    const auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(upos), 0, pps * W7_PX * 16, 0x00020000);
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+
+    const int lrow = lane >> 4, lchunk = lane & 15;                   // DMA: row within the instruction's 4 rows, 16-byte chunk
+    // code pointer (3 stages ahead of compute) and DMA pointer (2 ahead): patch within its sample, sample
+    int c_q = p_begin % pps, c_b = p_begin / pps;
+    int d_q = c_q, d_step = 0, d_ring = 0, c_slot = 0;
+    unsigned aoff[NI];
+    int issued = 0, p_exact = 1;
+
+#define ICN_W7_FETCH_CODES() do { \
+        if (wave == 1 || (U > 64 && wave == 2)) { \
+            const int w0_ = __builtin_amdgcn_readfirstlane((wave - 1) * 64); \
+            int32_t* dst_ = Cs + __builtin_amdgcn_readfirstlane(c_slot * CW + w0_); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)dst_, 4, \
+                                                     w0_ + lane < U ? (unsigned)(c_q * U + w0_ + lane) * 4u : SIDE_FLAG, 0, 0, 0); \
+        } \
+        c_slot ^= 1; \
+    } while (0)
+    // codes of the stage under the code pointer (fetched one step ago into slot c_slot ^ 1, published by that step's barrier)
+    // -> byte offsets of this lane's rows; uses the pointer's sample BEFORE it is advanced
+#define ICN_W7_MAKE_OFFSETS() do { \
+        _Pragma("unroll") \
+        for (int i = 0; i < NI; ++i) { \
+            const int32_t c = Cs[(c_slot ^ 1) * CW + 4 * (wave + 4 * i) + lrow]; \
+            aoff[i] = c >= 0 ? ((unsigned)(c_b * Ps + c) * (unsigned)Cin + (unsigned)(ci0 + 4 * lchunk)) * 4u \
+                    : c == -1 ? NOTHING_OFFSET \
+                              : SIDE_FLAG | (((unsigned)(c_b * n_slots + (-2 - c)) * (unsigned)Cin + (unsigned)(ci0 + 4 * lchunk)) * 4u); \
+        } \
+    } while (0)
+#define ICN_W7_ADVANCE_CODE_PTR() do { if (++c_q == pps) { c_q = 0; ++c_b; } } while (0)
+    // DMA of stage d_step into ring slot d_ring: union rows (offsets from ICN_W7_MAKE_OFFSETS), dy rows, positions (wave 0)
+#define ICN_W7_ISSUE() do { \
+        issued = d_step < nsteps; \
+        p_exact = 1; \
+        if (issued) { \
+            const int slot_off_ = __builtin_amdgcn_readfirstlane(d_ring * STAGE_F); \
+            bool side_row = false; \
+            _Pragma("unroll") \
+            for (int i = 0; i < NI; ++i) side_row |= (int)aoff[i] < (int)NOTHING_OFFSET; \
+            if (__builtin_amdgcn_ballot_w64(side_row) == 0) { \
+                _Pragma("unroll") \
+                for (int i = 0; i < NI; ++i) { \
+                    float* dst_ = ring + __builtin_amdgcn_readfirstlane(slot_off_ + 4 * (wave + 4 * i) * W7_ROWF); \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst_, 16, aoff[i], 0, 0, 0); \
+                } \
+            } else { \
+                p_exact = 0; \
+                _Pragma("unroll") \
+                for (int i = 0; i < NI; ++i) { \
+                    float* dst_ = ring + __builtin_amdgcn_readfirstlane(slot_off_ + 4 * (wave + 4 * i) * W7_ROWF); \
+                    if ((int)aoff[i] >= (int)NOTHING_OFFSET) \
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst_, 16, aoff[i], 0, 0, 0); \
+                    else \
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_ptr_t)dst_, 16, aoff[i] & ~SIDE_FLAG, 0, 0, 0); \
+                } \
+            } \
+            { \
+                const int y_soff = __builtin_amdgcn_readfirstlane((p_begin + d_step) * W7_PX * yC * 4); \
+                float* dst_ = ring + __builtin_amdgcn_readfirstlane(slot_off_ + U * W7_ROWF + 4 * wave * 64); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)dst_, 16, \
+                                                         ((unsigned)(4 * wave + lrow) * (unsigned)yC + (unsigned)(yc0 + 4 * lchunk)) * 4u, y_soff, 0, 0); \
+            } \
+            if (wave == 0) { \
+                float* dst_ = ring + __builtin_amdgcn_readfirstlane(slot_off_ + U * W7_ROWF + W7_PX * 64); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_p, (lds_ptr_t)dst_, 4, (unsigned)lane * 4u, \
+                                                         __builtin_amdgcn_readfirstlane(d_q * (W7_PX * 16)), 0, 0); \
+            } \
+            d_ring = d_ring == NST - 1 ? 0 : d_ring + 1; \
+            d_step += 1; \
+            if (++d_q == pps) d_q = 0; \
+        } \
+    } while (0)
+    // end of a step: the previous stage has landed (and the codes fetched before this step's DMA); publish.  Wave 0 has one
+    // more DMA per stage in flight (the positions) than the others.
+#define ICN_W7_RETIRE_AND_PUBLISH() do { \
+        if (NST == 3 && issued && p_exact) { \
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI + 2) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI + 1) : "memory"); \
+        } else { \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier(); \
+    } while (0)
+#define ICN_W7_DRAIN_AND_PUBLISH() do { \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier(); \
+    } while (0)
+
+    // ring fill: stages 0 .. NST - 2; codes of stage NST - 1 in flight
+    ICN_W7_FETCH_CODES();                                 // stage 0
+    ICN_W7_DRAIN_AND_PUBLISH();
+#pragma unroll
+    for (int f = 0; f < NST - 1; ++f) {
+        ICN_W7_MAKE_OFFSETS();
+        ICN_W7_ADVANCE_CODE_PTR();
+        ICN_W7_FETCH_CODES();                             // stage f + 1
+        ICN_W7_ISSUE();                                   // stage f
+        ICN_W7_DRAIN_AND_PUBLISH();
+    }
+    int c_ring = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        ICN_W7_MAKE_OFFSETS();                            // stage step + NST - 1
+        ICN_W7_ADVANCE_CODE_PTR();
+        ICN_W7_FETCH_CODES();                             // stage step + NST (before the data DMA: retired with the previous stage)
+        ICN_W7_ISSUE();
+        const float* slot = ring + c_ring * STAGE_F;
+        const char* xa = reinterpret_cast<const char*>(slot) + (wr * 32 + l31) * 4;
+        const float* yb = slot + U * W7_ROWF + wc * 32 + l31;
+        const u32x4* pp = reinterpret_cast<const u32x4*>(slot + U * W7_ROWF + W7_PX * 64);
+        // positions of this lane's 8 pixels (k = 2 * k2 + h), then the operands of pixel pair k2 + 1 are fetched ahead of the
+        // seven MFMAs of pair k2 (register double buffer, as the conv kernel's fragments)
+        u32x4 pk[W7_PX / 2];
+#pragma unroll
+        for (int k2 = 0; k2 < W7_PX / 2; ++k2) pk[k2] = pp[2 * k2 + h];
+        float fa[2][7], fb[2];
+#define ICN_W7_OPERANDS(BUF, K2) do { \
+            fb[BUF] = yb[(2 * (K2) + h) * 64]; \
+            _Pragma("unroll") \
+            for (int t = 0; t < 7; ++t) { \
+                const unsigned off_ = (t & 1) ? pk[K2][t >> 1] >> 16 : pk[K2][t >> 1] & 0xFFFFu; \
+                fa[BUF][t] = *reinterpret_cast<const float*>(xa + off_); \
+            } \
+        } while (0)
+        ICN_W7_OPERANDS(0, 0);
+#pragma unroll
+        for (int k2 = 0; k2 < W7_PX / 2; ++k2) {
+            if (k2 + 1 < W7_PX / 2) ICN_W7_OPERANDS((k2 + 1) & 1, k2 + 1);
+            __builtin_amdgcn_sched_barrier(0);            // keep the next pair's LDS reads ahead of this pair's MFMAs
+#pragma unroll
+            for (int t = 0; t < 7; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k2 & 1][t], fb[k2 & 1], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef ICN_W7_OPERANDS
+        if (do_bias && tid < 64) {
+#pragma unroll
+            for (int k = 0; k < W7_PX; ++k) bsum += slot[U * W7_ROWF + k * 64 + tid];
+        }
+        ICN_W7_RETIRE_AND_PUBLISH();
+        c_ring = c_ring == NST - 1 ? 0 : c_ring + 1;
+    }
+#undef ICN_W7_FETCH_CODES
+#undef ICN_W7_MAKE_OFFSETS
+#undef ICN_W7_ADVANCE_CODE_PTR
+#undef ICN_W7_ISSUE
+#undef ICN_W7_RETIRE_AND_PUBLISH
+#undef ICN_W7_DRAIN_AND_PUBLISH
+
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        float* out = partial + ((size_t)split * 7 + t) * Cin * Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int co = co0 + wc * 32 + l31;
+            out[(size_t)ci * Cout + co] = acc[t][r];
+        }
+    }
+    if (do_bias && tid < 64) bias_partial[(size_t)split * Cout + co0 + tid] = bsum;
+    if (trace && tid == 0) {
+        unsigned long long* o = trace + (size_t)blockIdx.x * 8;
+        o[0] = tr_t0; o[1] = tr_t0; o[2] = tr_t0; o[3] = 0; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = 0;
+        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);
+    }
+#endif
+}
+
 // dw[co][ci][t] = sum_s partial[s][t][ci][co];   dbias[co] = sum_s bias_partial[s][co]
 // A block owns 64 consecutive elements of the [t][ci][co] slab layout (plus, past the weights, of the bias row); its
 // four waves each sum a quarter of the S slabs (256-byte coalesced reads, independent loads), the quarters are
@@ -1964,18 +2207,76 @@ static int wgrad_base_splits(int M, int Cin, int Cout, int Cout0) {     // MFMA 
     if (s < 1) s = 1;
     return (int)s;
 }
-int wgrad_splits(int M, int Cin, int Cout, int Cout0) {
+static int wgrad_splits_pertap(int M, int Cin, int Cout, int Cout0) {
     if (Cout0 <= 0 || Cout0 > Cout) Cout0 = Cout;
     if (wgrad_supported(Cin, Cout)) return wgrad_base_splits(M, Cin, Cout, Cout0);
     if (stem_supported(Cin, Cout)) return std::min(2048, (M + 255) / 256);
     return std::min(512, (M + 127) / 128);
 }
+int wgrad7_splits(int M, int Pd, int Cin, int Cout, int Cout0);
+// slabs of the workspace: enough for whichever kernel the launch picks
+int wgrad_splits(int M, int Cin, int Cout, int Cout0) {
+    if (Cout0 <= 0 || Cout0 > Cout) Cout0 = Cout;
+    return std::max(wgrad_splits_pertap(M, Cin, Cout, Cout0), wgrad7_splits(M, 16, Cin, Cout, Cout0));
+}
+
+// ---- k_wgrad7 launch plan: one round of 256 * 2 workgroups, a (ci, co) tile of 64 x 64 and a contiguous range of patches each
+struct W7Plan { int tiles, pps, splits; };
+static bool wgrad7_plan(int M, int Pd, int Cin, int Cout, int Cout0, W7Plan& p) {
+    if (Cin % 64 || Cout % 64 || Cout0 % 64 || Pd % W7_PX || M % W7_PX) return false;
+    const long tiles = (long)(Cin / 64) * (Cout / 64), np = M / W7_PX;
+    long S = std::max(1L, 512 / tiles);
+    long pps = (np + S - 1) / S;
+    if (pps < 8) pps = std::min<long>(8, np);              // short splits: the ring's fill and the slab would dominate
+    p.tiles = (int)tiles;
+    p.pps = (int)pps;
+    p.splits = (int)((np + pps - 1) / pps);
+    return tiles <= 4096 && pps >= 4;
+}
+static size_t wgrad7_lds(int U, int nst) { return (size_t)nst * (U * W7_ROWF + W7_PX * 64 + 64) * 4 + 2 * (U > 64 ? 128 : 64) * 4; }
+int wgrad7_splits(int M, int Pd, int Cin, int Cout, int Cout0) {
+    W7Plan p;
+    return wgrad7_plan(M, Pd, Cin, Cout, Cout0, p) ? p.splits : 0;
+}
 
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
     const bool pair = a.dy2 != nullptr || (a.y_taps && a.Cout0 > 0 && a.Cout0 < a.Cout);   // two weight tensors to fill
     const int Cout0 = pair ? a.Cout0 : a.Cout;
-    const int S = wgrad_splits(a.M, a.Cin, a.Cout, Cout0);
-    if (wgrad_supported(a.Cin, a.Cout)) {
+    int S = wgrad_splits_pertap(a.M, a.Cin, a.Cout, Cout0);
+    W7Plan w7{};
+    const size_t x_bytes7 = (size_t)(a.M / a.Pd) * a.Ps * a.Cin * 4, dy_bytes7 = (size_t)a.M * std::max(Cout0, a.Cout - Cout0) * 4;
+    const bool use7 = a.w7_rows != nullptr && a.w7_pos != nullptr && (a.w7_U == 64 || a.w7_U == 112) && !a.y_taps && !(dbg_flags() & (32 | 2048)) &&
+                      (a.n_slots == 0 || a.side != nullptr) && x_bytes7 < ((size_t)1 << 31) && dy_bytes7 < ((size_t)1 << 31) &&
+                      (size_t)(a.M / a.Pd) * a.n_slots * a.Cin * 4 < ((size_t)1 << 30) &&
+                      wgrad7_plan(a.M, a.Pd, a.Cin, a.Cout, Cout0, w7);
+    if (use7) {
+        S = w7.splits;
+        // ring depth (developer A/B: ICN_W7_NST=2|3): 3 stages / 2 workgroups per CU, or 2 stages (a third less LDS: 3 per CU)
+        static const int nst_env = getenv("ICN_W7_NST") ? atoi(getenv("ICN_W7_NST")) : 0;
+        const int nst = a.w7_U > 64 ? 2 : (nst_env == 2 || nst_env == 3 ? nst_env : 3);
+        const int occ = std::min(3, (int)((160 * 1024) / wgrad7_lds(a.w7_U, nst)));
+        (void)occ;
+        const dim3 grid((unsigned)w7.tiles * (unsigned)((S + 7) / 8 * 8));
+        const unsigned side_bytes7 = (unsigned)((size_t)(a.M / a.Pd) * a.n_slots * a.Cin * 4);
+        prof_mark_begin(PROF_WG7, a.algo_flops, s);
+#define ICN_W7(NI_, NST_)                                                                                                      \
+    do {                                                                                                                       \
+        static std::atomic<uint64_t> attr_devices{0};                                                                          \
+        if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad7<NI_, NST_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                             \
+            attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);                             \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((k_wgrad7<NI_, NST_>), grid, dim3(256), wgrad7_lds(16 * NI_, NST_), s, a.x, a.dy, a.dy2, a.w7_rows, a.w7_pos, \
+                           a.n_slots > 0 ? a.side : nullptr, a.partial, a.bias_partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout, Cout0,   \
+                           a.n_slots, w7.pps, S, (unsigned)x_bytes7, side_bytes7, g_trace_cap >= (size_t)grid.x * 8 ? g_trace : nullptr); \
+    } while (0)
+        if (a.w7_U > 64) ICN_W7(7, 2);
+        else if (nst == 2) ICN_W7(4, 2);
+        else ICN_W7(4, 3);
+#undef ICN_W7
+        prof_mark_end(s);
+    } else if (wgrad_supported(a.Cin, a.Cout)) {
         int rows = (a.M + S - 1) / S;
         rows = (rows + 31) / 32 * 32;
         const bool bi128 = a.Cin % 128 == 0, bj128 = wgrad_bj(a.Cout, Cout0) == 128;

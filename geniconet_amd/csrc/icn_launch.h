@@ -83,6 +83,9 @@ struct WgradArgs {
     int M, Ps, Pd, Cin, Cout, ns;
     double algo_flops;
     int y_taps;             // 7: dy is the tap-major aggregate g (M, 7, Cout) of icn_upconv_bwd and dcode one table [Pd]; else 0
+    const int32_t* w7_rows; // patch form of dcode for the all-taps kernel k_wgrad7 (icn_geometry.h: Wg7Table), or null
+    const uint16_t* w7_pos;
+    int w7_U;
 };
 
 bool gather_gemm_supported(int K, int N);
@@ -93,6 +96,8 @@ bool wgrad_supported(int Cin, int Cout);
 bool wgrad_pair_supported(int M, int Ps, int Pd, int Cin, int Cout0, int Cout1);
 // row splits (= partial slabs); Cout0 < Cout: pair whose co tiles must not straddle the two outputs
 int wgrad_splits(int M, int Cin, int Cout, int Cout0 = 0);
+// slabs the all-taps kernel k_wgrad7 writes for this shape (0: shape outside its plan); the workspace holds the larger count
+int wgrad7_splits(int M, int Pd, int Cin, int Cout, int Cout0);
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
 bool stem_supported(int Cin, int Cout);
 void launch_stem_fwd(const float* x, const float* w, const float* bias, float* y, const int32_t* idx, int M, int Ps, int Pd,
@@ -199,7 +204,8 @@ void launch_point_to_mesh(const float* pts, const float* vts, const int32_t* fac
 // developer routing flags (ICN_DEBUG / icn_set_debug_flags): 16 = convs on k_gather_gemm, 32 = wgrads on k_wgrad,
 // 128 = no stream-K, 256 = fault injection: every stream-K finisher reports its partners lost (tests of the failure path),
 // 512 = masked launches walk tiles b, b + G, ... instead of the balanced tile lists, 1024 = the sparse passes of the decoder-block
-// head on the row-per-thread kernels instead of the LDS-staged ones
+// head on the row-per-thread kernels instead of the LDS-staged ones, 2048 = weight gradients on the per-tap kernel k_wgrad_dma
+// instead of the all-taps kernel k_wgrad7
 int debug_flags();
 int set_debug_flags(int flags);
 
@@ -209,6 +215,7 @@ enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA
                 PROF_WG_128x64, PROF_WG_64x128, PROF_WG_64x64,
                 PROF_DMAS_128x128, PROF_DMAS_128x64, PROF_DMAS_64x128, PROF_DMAS_64x64,   // k_conv_dma<.., true>: class-major rows
                 PROF_DMAK_64x128, PROF_DMAK_64x64, PROF_DMAKS_64x128, PROF_DMAKS_64x64,    // k_conv_dma_sk<.., SEG>: stream-K form
+                PROF_WG7,                                                                   // k_wgrad7<4>: all-taps weight gradient
                 PROF_KINDS };
 extern const char* const PROF_NAMES[PROF_KINDS];
 void prof_mark_begin(int kind, double flops, hipStream_t s);   // no-ops unless profiling is on

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ICN_ABI_VERSION 5
+#define ICN_ABI_VERSION 6
 
 #define ICN_CORNER_ZEROS 0
 #define ICN_CORNER_AVERAGE 1
@@ -246,6 +246,14 @@ long icn_table_upconv(int r_in, int corner_mode, int32_t* ints, size_t cap_ints,
 /* ELL matrix dy (fine) -> g (coarse, 7 taps) of the aggregated backward of the same pair (icn_upconv_bwd): row s * 7 + t
  * lists the fine pixels and coefficients of g_t[s]; [7 * P_coarse][width], -1 padded. */
 long icn_table_upconv_bwd(int r_in, int corner_mode, int32_t* idx, float* coef, size_t cap, int* width);
+
+/* Patch form of the forward table for the all-taps weight-gradient kernel (ABI 6; csrc/icn_geometry.h Wg7Table):
+ * the output pixels of a sample in patches of 16 consecutive pixels; rows [npatch][U] = the UNION of a patch's gathered source
+ * rows as DmaTable codes (pixel, -1 nothing, -2 - k mean of pole k), row U - 1 always -1; pos [npatch][16][8] = byte offset
+ * (union row * 256) of tap t's row of pixel k in the staged union ([k][7] padding).  meta[2] = {U, npatch}, U = 64 at stride 1
+ * and 112 at stride 2 (the taps of neighbouring outputs share little there); returns the number of row codes, 0 when the table
+ * does not exist for this (r_in, stride): P_out % 16 != 0 or a union that does not fit. */
+long icn_table_wgrad7(int r_in, int stride, int corner_mode, int32_t* rows, size_t cap_rows, uint16_t* pos, size_t cap_pos, int* meta);
 
 /* Optional diagnostics: HIP-event timing of every MFMA kernel launch between start and stop, on the launch
  * stream.  `stop` synchronises the device and returns the number of entries written (one per kernel that ran).

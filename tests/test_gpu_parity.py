@@ -130,6 +130,53 @@ def test_conv_pair_falls_back_outside_its_limits():
         assert rel_l2(p_.detach().cpu().numpy(), h_.detach().cpu().numpy()) < 1e-6
 
 
+W7_CASES = [   # (r, stride, Cin, Cout0, Cout1 (0: single conv), B, corner mode)
+    (2, 1, 64, 64, 0, 3, 'average'), (3, 1, 128, 128, 0, 5, 'average'), (4, 1, 64, 128, 0, 2, 'zeros'), (3, 1, 256, 256, 0, 36, 'average'),
+    (3, 1, 128, 64, 64, 3, 'average'), (4, 1, 64, 128, 128, 7, 'average'),                       # pairs at stride 1
+    (3, 2, 64, 128, 0, 2, 'average'), (4, 2, 128, 256, 256, 3, 'average'), (5, 2, 64, 128, 128, 2, 'zeros'), (3, 2, 256, 256, 256, 36, 'average'),
+    (5, 1, 64, 64, 0, 1, 'average'), (2, 1, 192, 320, 0, 2, 'average'),
+]
+
+
+@pytest.mark.parametrize('case', W7_CASES, ids=lambda c: 'r%d_s%d_%dx%d+%d_b%d_%s' % c)
+def test_all_taps_weight_gradient_kernel_equals_the_per_tap_kernel(case):
+    """k_wgrad7 (a workgroup owns a 64 x 64 tile for all seven taps, the union of a 16-pixel patch's source rows
+    staged once, positions from host tables) against k_wgrad_dma (debug flag 2048) on the same inputs: weight and bias
+    gradients to 2e-6 (same products, other summation order), for single convolutions and pairs, both strides, both corner
+    modes, batches that do not divide into equal splits; the profiling hooks assert which kernel ran.  Both are held to the
+    oracle by the conv cases above."""
+    from geniconet_amd import _lib
+    from geniconet_amd.ico_conv import ico_conv, ico_conv_pair
+    r, stride, cin, c0, c1, B, mode = case
+    n = 2 ** r
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(B, cin, 5 * n, 2 * n, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    ws = [(torch.randn(c, cin, 7, device='cuda', generator=g) / (7 * cin) ** 0.5).requires_grad_() for c in (c0, c1) if c]
+    bs = [torch.randn(c, device='cuda', generator=g).requires_grad_() for c in (c0, c1) if c]
+
+    def grads():
+        if c1:
+            ys = ico_conv_pair(x, ws[0], bs[0], ws[1], bs[1], r, stride, mode)
+        else:
+            ys = (ico_conv(x, ws[0], bs[0], r, stride, mode),)
+        gen = torch.Generator(device='cuda').manual_seed(6)
+        gys = [torch.randn(y.shape, device='cuda', generator=gen) for y in ys]
+        _lib.profile_start(16)
+        out = torch.autograd.grad(ys, ws + bs, gys)
+        used = {e['kernel'].split('<')[0] for e in _lib.profile_stop()}
+        return out, used
+
+    new, used_new = grads()
+    old_flags = _lib.lib().icn_set_debug_flags(2048)
+    try:
+        old, used_old = grads()
+    finally:
+        _lib.lib().icn_set_debug_flags(old_flags)
+    assert 'k_wgrad7' in used_new and 'k_wgrad7' not in used_old and 'k_wgrad_dma' in used_old, (used_new, used_old)
+    for a, b in zip(new, old):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
+
+
 def test_tensors_beyond_2gib_take_the_fallback_kernels_and_agree_with_half_batches():
     """Maximum sizes: the LDS-DMA kernels address their operands through 32-bit buffer offsets, so a tensor of 2 GiB or
     more is routed to the register-staged kernels (per pass: what counts is the tensor that pass gathers from -- x for the
@@ -168,7 +215,7 @@ def test_tensors_beyond_2gib_take_the_fallback_kernels_and_agree_with_half_batch
     dw_sum, db_sum = torch.zeros_like(dw), torch.zeros_like(db)
     for lo in (0, h):
         (yh, dxh, dwh, dbh), half = kernels(run, x[lo:lo + h], gy[lo:lo + h])
-        assert half == {'k_conv_dma', 'k_wgrad_dma'}, half              # the production kernels
+        assert half == {'k_conv_dma', 'k_wgrad7'}, half                 # the production kernels
         assert close(y[lo:lo + h], yh) and close(dx[lo:lo + h], dxh)
         dw_sum += dwh
         db_sum += dbh

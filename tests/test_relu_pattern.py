@@ -69,7 +69,7 @@ def test_a_relu_flip_is_real_and_the_pattern_comparison_removes_it():
 def test_whole_network_gradients_at_I5_against_the_oracle_at_the_gpu_pattern(name, monkeypatch):
     """The r = 5 backward chain as the bench runs it (split-mode data gradients with virtual rows, stream-K, LDS-staged
     sparse passes r4 -> 5, weight gradients on the second stream), end to end against the float64 oracle network evaluated at
-    the GPU forward's ReLU pattern: forward 1e-4, every parameter gradient 1e-3 (half the contract's 2e-3), and every pattern
+    the GPU forward's ReLU pattern: forward 1e-4, every parameter gradient 5e-4 (a quarter of the contract's 2e-3; measured 2.1e-4), and every pattern
     difference a rounding event (< 1e-4 of the tensor's rms)."""
     from geniconet_amd import data, models
     from geniconet_amd.ico_conv import set_weight_gradient_stream
@@ -101,5 +101,5 @@ def test_whole_network_gradients_at_I5_against_the_oracle_at_the_gpu_pattern(nam
     n_flips = check_flips(pat, n_relu)
     errs = gradient_errors(dict(net.named_parameters()), g64)
     print('%s I5: %d ReLU flips %s, worst gradient %.2e %s' % ((name, n_flips, pat.flips) + worst(errs)))
-    assert worst(errs)[0] < 1e-3, sorted(((v, k) for k, v in errs.items()), reverse=True)[:5]
+    assert worst(errs)[0] < 5e-4, sorted(((v, k) for k, v in errs.items()), reverse=True)[:5]
     assert np.isfinite(float(loss.detach()))
