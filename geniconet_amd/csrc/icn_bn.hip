@@ -10,6 +10,16 @@
 
 #include "icn_launch.h"
 
+// (see icn_kernels.hip: wave priority of the kernels on the backward pass's critical chain)
+#ifndef ICN_CHAIN_PRIO
+#define ICN_CHAIN_PRIO 0
+#endif
+#if ICN_CHAIN_PRIO > 0
+#define ICN_CHAIN_SETPRIO() __builtin_amdgcn_s_setprio(ICN_CHAIN_PRIO)
+#else
+#define ICN_CHAIN_SETPRIO() ((void)0)
+#endif
+
 namespace icn {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -56,6 +66,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
                                                      const float* __restrict__ ba, const float* __restrict__ gb,
                                                      const float* __restrict__ bb, double* __restrict__ partial, int M, int C,
                                                      int rows_per_chunk) {
+    ICN_CHAIN_SETPRIO();
     constexpr int NS = MODE == 3 ? 4 : (MODE == 2 ? 3 : 2);
     __shared__ f64x4 red[NS][256];
     const int c4n = C / 4, stripes = 256 / c4n;
@@ -246,6 +257,7 @@ __global__ void k_bn_relu_fwd(const float* __restrict__ a, const float* __restri
                               const float* __restrict__ stat_b, const float* __restrict__ ga, const float* __restrict__ ba,
                               const float* __restrict__ gb, const float* __restrict__ bb, float* __restrict__ y, size_t total4,
                               int C) {
+    ICN_CHAIN_SETPRIO();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         f32x4 bv{}, mb{}, sb{}, bbv{};
@@ -262,6 +274,7 @@ __global__ void k_bn_relu_bwd(const float* __restrict__ dy, const float* __restr
                               const float* __restrict__ ba, const float* __restrict__ gb, const float* __restrict__ bb,
                               const float* __restrict__ sums, float* __restrict__ da, float* __restrict__ db, size_t total4, int C,
                               float inv_m) {
+    ICN_CHAIN_SETPRIO();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         const f32x4 d = ldv(dy + i * 4), av = ldv(a + i * 4);

@@ -30,6 +30,18 @@
 #include "icn_launch.h"
 #include "icn_streamk.h"
 
+// Wave priority of the kernels on the backward pass's critical chain (convolutions, BatchNorm passes): the weight gradients run
+// BESIDE them on a second stream at the default priority 0, so on a SIMD that hosts both the chain's waves issue
+// first and the weight gradients take the issue slots that are left.  ICN_CHAIN_PRIO = 0 compiles it out (A/B builds).
+#ifndef ICN_CHAIN_PRIO
+#define ICN_CHAIN_PRIO 0
+#endif
+#if ICN_CHAIN_PRIO > 0
+#define ICN_CHAIN_SETPRIO() __builtin_amdgcn_s_setprio(ICN_CHAIN_PRIO)
+#else
+#define ICN_CHAIN_SETPRIO() ((void)0)
+#endif
+
 namespace icn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -416,6 +428,7 @@ __device__ __forceinline__ void conv_dma_body(
     const int* __restrict__ sk_bnd,     // SK: range boundaries of the launch's two residue-class sizes, [2][G / 8 + 1] (sk_tables)
     const int* __restrict__ tlist) {    // !SK: per-workgroup tile lists, [G + 1] offsets then the tile ids (tile_lists), or null: b, b + G, ...
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource / LDS-DMA builtins only exist in the device pass
+    ICN_CHAIN_SETPRIO();
     // T taps in wt / dcode (7 hex taps, or the virtual taps of a composite table); a tile runs at most 7 of them (its tap
     // mask), and the LDS offset table is indexed by a tap's RANK inside that mask.
     // The plain instantiation (SEG = false) is the kernel of every ordinary convolution: 7 taps, rank == tap id, rows
@@ -2225,7 +2238,9 @@ struct W7Plan { int tiles, pps, splits; };
 static bool wgrad7_plan(int M, int Pd, int Cin, int Cout, int Cout0, W7Plan& p) {
     if (Cin % 64 || Cout % 64 || Cout0 % 64 || Pd % W7_PX || M % W7_PX) return false;
     const long tiles = (long)(Cin / 64) * (Cout / 64), np = M / W7_PX;
-    long S = std::max(1L, 512 / tiles);
+    // rounds of workgroups over the chip's 512 slots (developer sweep: ICN_W7_MULT)
+    static const double mult = getenv("ICN_W7_MULT") ? atof(getenv("ICN_W7_MULT")) : 1.0;
+    long S = std::max(1L, (long)(mult * 512 / tiles));
     long pps = (np + S - 1) / S;
     if (pps < 8) pps = std::min<long>(8, np);              // short splits: the ring's fill and the slab would dominate
     p.tiles = (int)tiles;
@@ -2233,6 +2248,14 @@ static bool wgrad7_plan(int M, int Pd, int Cin, int Cout, int Cout0, W7Plan& p) 
     p.splits = (int)((np + pps - 1) / pps);
     return tiles <= 4096 && pps >= 4;
 }
+// Which launches take k_wgrad7: class 1 = stride-1 tables (U = 64), class 2 = stride-2 tables (U = 112).  Default: class 1 only.
+// Measured at I5 / batch 36 (gpurun_out/r4_f_*, one box, alternating): every launch alone is ~10 % faster on k_wgrad7 (whole calls
+// 238 -> 208 us stride 1, 255 -> 231 us stride 2), and on ONE stream the step gains 0.145 ms; but with the weight gradients on the
+// second stream beside the backward chain the stride-2 form (67 KB of LDS, 28 union-row DMAs per stage: the taps of
+// neighbouring outputs share little) costs the chain more than it saves -- 8.44 ms per step with both classes, 8.37 with class 1
+// only, 8.37 with the per-tap kernel everywhere.  Debug flag 4096 (ICN_DEBUG / icn_set_debug_flags) sends class 2 to k_wgrad7 as
+// well (tests, A/B); flag 2048 sends everything to the per-tap kernel.
+static bool w7_class_enabled(int cls) { return cls == 1 || (dbg_flags() & 4096) != 0; }
 static size_t wgrad7_lds(int U, int nst) { return (size_t)nst * (U * W7_ROWF + W7_PX * 64 + 64) * 4 + 2 * (U > 64 ? 128 : 64) * 4; }
 int wgrad7_splits(int M, int Pd, int Cin, int Cout, int Cout0) {
     W7Plan p;
@@ -2248,7 +2271,7 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
     const bool use7 = a.w7_rows != nullptr && a.w7_pos != nullptr && (a.w7_U == 64 || a.w7_U == 112) && !a.y_taps && !(dbg_flags() & (32 | 2048)) &&
                       (a.n_slots == 0 || a.side != nullptr) && x_bytes7 < ((size_t)1 << 31) && dy_bytes7 < ((size_t)1 << 31) &&
                       (size_t)(a.M / a.Pd) * a.n_slots * a.Cin * 4 < ((size_t)1 << 30) &&
-                      wgrad7_plan(a.M, a.Pd, a.Cin, a.Cout, Cout0, w7);
+                      wgrad7_plan(a.M, a.Pd, a.Cin, a.Cout, Cout0, w7) && w7_class_enabled(a.w7_U > 64 ? 2 : 1);
     if (use7) {
         S = w7.splits;
         // ring depth (developer A/B: ICN_W7_NST=2|3): 3 stages / 2 workgroups per CU, or 2 stages (a third less LDS: 3 per CU)
