@@ -59,8 +59,14 @@ __device__ __forceinline__ f32x4 bn_pre4(f32x4 a, f32x4 mean_a, f32x4 scale_a, f
 //   MODE 2 (backward of relu(bn_a(a)+bn_b(b))):  k0 = sum g,        k1 = sum g * ahat,  k2 = sum g * bhat
 //          v = the pre-activation, RECOMPUTED from a (and b) with the forward's own expression (bn_pre4) instead of reading
 //          the saved output y: one tensor less to stream in each of the two backward passes.
+#ifndef ICN_BN_UN
+#define ICN_BN_UN 4
+#endif
+#ifndef ICN_BN_WAVES
+#define ICN_BN_WAVES 1
+#endif
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0, const float* __restrict__ p2,
+__global__ __launch_bounds__(256, ICN_BN_WAVES) void k_bn_partial(const float* __restrict__ p0, const float* __restrict__ p2,
                                                      const float* __restrict__ p3, const float* __restrict__ stat_a,
                                                      const float* __restrict__ stat_b, const float* __restrict__ ga,
                                                      const float* __restrict__ ba, const float* __restrict__ gb,
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
     // UN rows per iteration, each with its own accumulators (combined in a fixed order below): the loads of an iteration are
     // independent, so a wave keeps UN x (1..3) 16-byte loads in flight -- with 512 blocks on 256 CUs the kernel is bound by
     // loads in flight, not by HBM (2.9 TB/s with one row per iteration against the 5.9 TB/s of the apply passes).
-    constexpr int UN = 4;
+    constexpr int UN = ICN_BN_UN;
     f64x4 s[UN][NS];
 #pragma unroll
     for (int u = 0; u < UN; ++u)
@@ -127,7 +133,10 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ p0
         }
     }
 #pragma unroll
-    for (int k = 0; k < NS; ++k) s[0][k] = (s[0][k] + s[1][k]) + (s[2][k] + s[3][k]);
+    for (int k = 0; k < NS; ++k) {
+        if (UN == 4) s[0][k] = (s[0][k] + s[1][k]) + (s[2][k] + s[3][k]);
+        else if (UN == 2) s[0][k] = s[0][k] + s[1][k];
+    }
 #pragma unroll
     for (int k = 0; k < NS; ++k) red[k][threadIdx.x] = s[0][k];
     __syncthreads();

@@ -1,10 +1,15 @@
-"""The PRODUCTION communication path on the one GPU a test box has: an RCCL (backend 'nccl') process group of world size 1,
+"""The production communication path as far as ONE GPU can take it: an RCCL (backend 'nccl') process group of world size 1,
 DistributedDataParallel around the product model exactly as geniconet_amd/train.py builds it for N > 1 (init_sync,
-gradient_as_bucket_view, 5 MB buckets, torch's built-in C++ all-reduce comm hook, gradients written straight into the bucket
-views from the third backward on), device barriers, destroy_process_group.  World size 1 over RCCL runs
-everything N ranks would run except the wire: communicator creation, DDP's reducer over the pair / upconv / BN / head /
-loss autograd Functions with bucket-view gradients feeding icn_adam_step, and the bucket all-reduce kernels queued on
-RCCL's stream while the persistent, spin-waiting stream-K conv kernels own every CU.
+gradient_as_bucket_view, 10 MB buckets, torch's built-in C++ all-reduce comm hook, gradients written straight into the bucket
+views from the third backward on), device barriers, destroy_process_group.
+
+What this covers: communicator creation, DDP's reducer over the pair / upconv / BN / head / loss autograd Functions, the
+bucket-view leases feeding icn_adam_step, the 'bucketed' join bookkeeping of the weight gradients' side stream, and
+bit-identity with the plain trainer.  What it does NOT cover: any RCCL collective KERNEL -- with one rank the all-reduce
+degenerates to buffer copies (the tracer of this very run shows no `nccl*` kernel: profiles/r03_ddp_vs_plain.txt, +17
+copyBuffer / +20 fillBuffer per step), so a ring / tree kernel holding CUs beside the persistent conv kernels has never
+executed here.  `test_two_ranks_over_rccl_average_gradients_and_stay_in_lock_step` below is that test; it needs two GPUs and
+skips on the one-GPU boxes of this pool.
 
 Checked: gradients and the weights / BatchNorm statistics after 6 optimiser + scheduler steps are BIT-IDENTICAL to the
 trainer without DDP (a one-rank sum followed by a division by 1 must change nothing), at a small size and at the
@@ -115,3 +120,68 @@ def test_ddp_over_rccl_at_world_size_one_is_bit_identical_to_the_plain_trainer(t
         side, joins = c['side_ddp_step%d' % (c['nsteps'] - 1)]
         # (the first bucket to complete may hold nothing from the side stream yet -- no wait then --, every later one waits)
         assert c['buckets'] >= 2 and side >= 5 and c['buckets'] <= joins <= c['buckets'] + 1, c
+
+
+# ---- N = 2 over RCCL: runs the day a box has two GPUs ---------------------------------------------------------------------------
+def _worker2(rank, port, out_dir):
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(420, exit=True)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)                                   # one GPU per rank; the process group before any other GPU call
+    device = torch.device('cuda', rank)
+    dist.init_process_group('nccl', device_id=device, rank=rank, world_size=2)
+    from geniconet_amd import _lib, data, models
+    from geniconet_amd.train import Trainer
+    R, B = 4, 6                                                   # per-rank batch B, global batch 2 B
+    p = models.default_params('ico2ico', subdivisions=R)
+    p['ico2ico'].update(lr=1e-4, lr_base=1e-4, lr_max=1e-3)
+    tr = Trainer(p, device, seed=20 + rank)                       # differently seeded replicas: rank 0's weights must win
+    x, t = data.synthetic_batch(2 * B, R, seed=5, device=device)
+    x = x.contiguous(memory_format=torch.channels_last)
+    xs, ts = x[rank * B:(rank + 1) * B], t[rank * B:(rank + 1) * B]
+    rep = {'rank': rank, 'world': dist.get_world_size(), 'backend': dist.get_backend()}
+    rep['w0'] = {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
+    # one backward through DDP: every rank ends with the mean over ranks of the per-rank gradients
+    tr.optimizer.zero_grad()
+    tr.criterion(tr.net(xs), ts).backward()
+    rep['grad'] = {k: q.grad.detach().cpu().clone() for k, q in tr.model.named_parameters()}
+    # the same gradient without DDP: the plain model on this rank's shard (BatchNorm statistics are per rank by design)
+    tr.model.zero_grad()
+    tr.criterion(tr.model(xs), ts).backward()
+    rep['grad_local'] = {k: q.grad.detach().cpu().clone() for k, q in tr.model.named_parameters()}
+    for step in range(4):                                        # lock-step: Adam + CyclicLR replicated
+        tr.step(xs, ts)
+    dist.barrier(device_ids=[rank])
+    rep['w4'] = {k: v.detach().cpu() for k, v in tr.model.state_dict().items() if 'running' not in k and 'num_batches' not in k}
+    rep['status'] = _lib.device_status(device)
+    torch.save(rep, os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier(device_ids=[rank])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (RCCL refuses two ranks on one device)')
+def test_two_ranks_over_rccl_average_gradients_and_stay_in_lock_step(tmp_path):
+    """BASELINE configs[2] in miniature: 2 ranks, one GPU each, backend 'nccl' = RCCL, spawned fresh (process group before any
+    other GPU call, no re-exec).  Rank 0's initial weights reach both ranks; after one backward both ranks hold the MEAN of the
+    two per-rank gradients (each computed with its own BatchNorm statistics: DESIGN 6) -- compared with the per-rank
+    gradients measured without DDP, to fp32 rounding of one addition; after four optimiser steps the replicas' weights are
+    bit-identical.  This is the first test in which an RCCL collective kernel runs beside the persistent conv kernels and the
+    weight gradients' side stream ('bucketed' mode)."""
+    mp.spawn(_worker2, args=(_free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(str(tmp_path / ('rank%d.pt' % k))) for k in (0, 1))
+    assert r0['backend'] == r1['backend'] == 'nccl' and r0['world'] == 2
+    for k, v in r0['w0'].items():
+        assert torch.equal(v, r1['w0'][k]), k                      # broadcast from rank 0
+    for k in r0['grad']:
+        assert torch.equal(r0['grad'][k], r1['grad'][k]), k        # one all-reduced result on both ranks
+        want = 0.5 * (r0['grad_local'][k].double() + r1['grad_local'][k].double())
+        err = float((r0['grad'][k].double() - want).norm()) / max(float(want.norm()), 1e-12)
+        assert err < 1e-5, (k, err)
+    for k, v in r0['w4'].items():
+        assert torch.equal(v, r1['w4'][k]), k
+    assert r0['status'] == 0 and r1['status'] == 0

@@ -83,7 +83,10 @@ for k, cs in pmc.items():
         e['hbm_write_bytes_per_launch'] = cs['WRITE_SIZE'] * 1024
         e['hbm_bytes_per_launch'] = e['hbm_read_bytes_per_launch'] + e['hbm_write_bytes_per_launch']
     if 'GRBM_GUI_ACTIVE' in cs:
-        e['clock_ghz_estimate'] = round(cs['GRBM_GUI_ACTIVE'] / 8 / (e['avg_us_under_pmc'] * 1e-6) / 1e9, 3)
+        # GUI_ACTIVE cycles (summed over the 8 XCDs) / duration: a clock only for launches long enough that the cycles before the
+        # first and after the last wave do not matter -- for a 10 us kernel the quotient comes out at 3 - 6 "GHz"
+        e['clock_ghz_estimate'] = (round(cs['GRBM_GUI_ACTIVE'] / 8 / (e['avg_us_under_pmc'] * 1e-6) / 1e9, 3)
+                                   if e['avg_us_under_pmc'] >= 100 else None)
     if 'TCC_HIT_sum' in cs:
         e['l2_hit_rate'] = round(cs['TCC_HIT_sum'] / (cs['TCC_HIT_sum'] + cs['TCC_MISS_sum']), 4)
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in cs and 'GRBM_GUI_ACTIVE' in cs:
