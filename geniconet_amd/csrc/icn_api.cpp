@@ -227,7 +227,8 @@ ConvTables make_conv_tables(int r_in, int stride, int mode) {
         icn::DmaTable h;
         icn::build_dma_table(fwd, 1, t.Pout, h);
         icn::Wg7Table w7;
-        if (icn::build_wgrad7(h, t.Pout, stride == 1 ? 64 : 112, w7)) {
+        static const int u1 = getenv("ICN_W7_U") ? atoi(getenv("ICN_W7_U")) : 64;       // developer A/B: 56 = the 2-stage, 38 KB form
+        if (icn::build_wgrad7(h, t.Pout, stride == 1 ? u1 : 112, w7)) {
             t.w7_rows = upload(w7.urow);
             t.w7_pos = upload(w7.upos);
             t.w7_U = w7.U;
@@ -671,7 +672,7 @@ const char* const PROF_NAMES[PROF_KINDS] = {"k_conv_dma<128, 128, false>", "k_co
                                             "k_wgrad<64, 128>", "k_wgrad<64, 64>", "k_conv_dma<128, 128, true>",
                                             "k_conv_dma<128, 64, true>", "k_conv_dma<64, 128, true>", "k_conv_dma<64, 64, true>",
                                             "k_conv_dma_sk<64, 128, false>", "k_conv_dma_sk<64, 64, false>", "k_conv_dma_sk<64, 128, true>",
-                                            "k_conv_dma_sk<64, 64, true>", "k_wgrad7<4>"};
+                                            "k_conv_dma_sk<64, 64, true>", "k_wgrad7"};
 void prof_mark_begin(int kind, double flops, hipStream_t s) {
     if (!g_prof_on) return;
     g_prof_mu.lock();

@@ -62,6 +62,9 @@ __device__ __forceinline__ f32x4 bn_pre4(f32x4 a, f32x4 mean_a, f32x4 scale_a, f
 #ifndef ICN_BN_UN
 #define ICN_BN_UN 4
 #endif
+#ifndef ICN_BN_UN_BWD
+#define ICN_BN_UN_BWD 2
+#endif
 #ifndef ICN_BN_WAVES
 #define ICN_BN_WAVES 1
 #endif
@@ -81,7 +84,12 @@ __global__ __launch_bounds__(256, ICN_BN_WAVES) void k_bn_partial(const float* _
     // UN rows per iteration, each with its own accumulators (combined in a fixed order below): the loads of an iteration are
     // independent, so a wave keeps UN x (1..3) 16-byte loads in flight -- with 512 blocks on 256 CUs the kernel is bound by
     // loads in flight, not by HBM (2.9 TB/s with one row per iteration against the 5.9 TB/s of the apply passes).
-    constexpr int UN = ICN_BN_UN;
+    // Backward modes: 2 rows per iteration.  They run beside the weight-gradient kernels of the second stream, whose
+    // two waves per SIMD leave 176 registers: with 4 rows the backward forms need 128 / 196 and find no slot until a weight-gradient
+    // workgroup retires; with 2 rows (78 / 122) one wave per SIMD fits at once.  Measured (gpurun_out/r4_i_*, 4 alternations):
+    // 8.236 against 8.288 ms per step overlapped; alone on the chip the 2-row form is the slower one (8.606 against 8.559 with
+    // every pass on 2 rows), which is why the forward modes, which never have company, keep 4.
+    constexpr int UN = (MODE == 1 || MODE == 2) ? ICN_BN_UN_BWD : ICN_BN_UN;
     f64x4 s[UN][NS];
 #pragma unroll
     for (int u = 0; u < UN; ++u)
@@ -261,18 +269,39 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double* __restric
 }
 
 // y = relu(bn_a(a) [+ bn_b(b)])
+// APPLY_UNR elements per thread and iteration, every load of an iteration issued before the first use: a wave then keeps
+// APPLY_UNR x (1..3) 16-byte loads in flight, so the pass stays near HBM speed when only one or two waves per SIMD find room
+// beside the weight-gradient kernels of the second stream, not only on an empty chip (7 - 8 waves per SIMD).
+#ifndef ICN_BN_APPLY_UNR
+#define ICN_BN_APPLY_UNR 1
+#endif
+constexpr int APPLY_UNR = ICN_BN_APPLY_UNR;
+
 template <int DUAL>
 __global__ void k_bn_relu_fwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ stat_a,
                               const float* __restrict__ stat_b, const float* __restrict__ ga, const float* __restrict__ ba,
                               const float* __restrict__ gb, const float* __restrict__ bb, float* __restrict__ y, size_t total4,
                               int C) {
     ICN_CHAIN_SETPRIO();
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
-        f32x4 bv{}, mb{}, sb{}, bbv{};
-        if (DUAL) { bv = ldv(b + i * 4); mb = ldv(stat_b + c); sb = ldv(stat_b + C + c) * ldv(gb + c); bbv = ldv(bb + c); }
-        const f32x4 v = bn_pre4<DUAL>(ldv(a + i * 4), ldv(stat_a + c), ldv(stat_a + C + c) * ldv(ga + c), ldv(ba + c), bv, mb, sb, bbv);
-        stv(y + i * 4, relu4(v));
+    const size_t T = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total4; i0 += APPLY_UNR * T) {
+        f32x4 av[APPLY_UNR], bv[APPLY_UNR];
+#pragma unroll
+        for (int u = 0; u < APPLY_UNR; ++u) {
+            const size_t i = i0 + u * T < total4 ? i0 + u * T : i0;      // (clamped: loaded, not stored)
+            av[u] = ldv(a + i * 4);
+            if (DUAL) bv[u] = ldv(b + i * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < APPLY_UNR; ++u) {
+            const size_t i = i0 + u * T;
+            if (i >= total4) break;
+            const int c = (int)((i * 4) % C);
+            f32x4 bu{}, mb{}, sb{}, bbv{};
+            if (DUAL) { bu = bv[u]; mb = ldv(stat_b + c); sb = ldv(stat_b + C + c) * ldv(gb + c); bbv = ldv(bb + c); }
+            const f32x4 v = bn_pre4<DUAL>(av[u], ldv(stat_a + c), ldv(stat_a + C + c) * ldv(ga + c), ldv(ba + c), bu, mb, sb, bbv);
+            stv(y + i * 4, relu4(v));
+        }
     }
 }
 
@@ -284,24 +313,38 @@ __global__ void k_bn_relu_bwd(const float* __restrict__ dy, const float* __restr
                               const float* __restrict__ sums, float* __restrict__ da, float* __restrict__ db, size_t total4, int C,
                               float inv_m) {
     ICN_CHAIN_SETPRIO();
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
-        const f32x4 d = ldv(dy + i * 4), av = ldv(a + i * 4);
-        const f32x4 mean_a = ldv(stat_a + c), inv_a = ldv(stat_a + C + c), gam_a = ldv(ga + c);
-        f32x4 bv{}, mean_b{}, inv_b{}, gam_b{}, be_b{};
-        if (DUAL) { bv = ldv(b + i * 4); mean_b = ldv(stat_b + c); inv_b = ldv(stat_b + C + c); gam_b = ldv(gb + c); be_b = ldv(bb + c); }
-        const f32x4 v = bn_pre4<DUAL>(av, mean_a, inv_a * gam_a, ldv(ba + c), bv, mean_b, inv_b * gam_b, be_b);
-        f32x4 g;
+    const size_t T = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total4; i0 += APPLY_UNR * T) {
+        f32x4 dv[APPLY_UNR], avv[APPLY_UNR], bvv[APPLY_UNR];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = v[j] > 0.f ? d[j] : 0.f;
-        const f32x4 sg = ldv(sums + c) * inv_m;
-        {
-            const f32x4 xh = (av - mean_a) * inv_a;
-            stv(da + i * 4, gam_a * inv_a * (g - sg - xh * (ldv(sums + C + c) * inv_m)));
+        for (int u = 0; u < APPLY_UNR; ++u) {
+            const size_t i = i0 + u * T < total4 ? i0 + u * T : i0;      // (clamped: loaded, not stored)
+            dv[u] = ldv(dy + i * 4);
+            avv[u] = ldv(a + i * 4);
+            if (DUAL) bvv[u] = ldv(b + i * 4);
         }
-        if (DUAL) {
-            const f32x4 xh = (bv - mean_b) * inv_b;
-            stv(db + i * 4, gam_b * inv_b * (g - sg - xh * (ldv(sums + 2 * C + c) * inv_m)));
+#pragma unroll
+        for (int u = 0; u < APPLY_UNR; ++u) {
+            const size_t i = i0 + u * T;
+            if (i >= total4) break;
+            const int c = (int)((i * 4) % C);
+            const f32x4 d = dv[u], av = avv[u];
+            const f32x4 mean_a = ldv(stat_a + c), inv_a = ldv(stat_a + C + c), gam_a = ldv(ga + c);
+            f32x4 bv{}, mean_b{}, inv_b{}, gam_b{}, be_b{};
+            if (DUAL) { bv = bvv[u]; mean_b = ldv(stat_b + c); inv_b = ldv(stat_b + C + c); gam_b = ldv(gb + c); be_b = ldv(bb + c); }
+            const f32x4 v = bn_pre4<DUAL>(av, mean_a, inv_a * gam_a, ldv(ba + c), bv, mean_b, inv_b * gam_b, be_b);
+            f32x4 g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = v[j] > 0.f ? d[j] : 0.f;
+            const f32x4 sg = ldv(sums + c) * inv_m;
+            {
+                const f32x4 xh = (av - mean_a) * inv_a;
+                stv(da + i * 4, gam_a * inv_a * (g - sg - xh * (ldv(sums + C + c) * inv_m)));
+            }
+            if (DUAL) {
+                const f32x4 xh = (bv - mean_b) * inv_b;
+                stv(db + i * 4, gam_b * inv_b * (g - sg - xh * (ldv(sums + 2 * C + c) * inv_m)));
+            }
         }
     }
 }
@@ -309,7 +352,7 @@ __global__ void k_bn_relu_bwd(const float* __restrict__ dy, const float* __restr
 bool bn_supported(int C) { return C >= 4 && C <= 1024 && C % 4 == 0 && 256 % (C / 4) == 0; }
 int bn_chunks(int M) { return std::min(BN_MAX_CHUNKS, (M + 63) / 64); }
 
-static int stream_blocks(size_t total4) { return (int)std::min((size_t)8192, (total4 + 255) / 256); }
+static int stream_blocks(size_t total4) { return (int)std::min((size_t)8192, (total4 + 256 * APPLY_UNR - 1) / (256 * APPLY_UNR)); }
 
 void launch_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
                      float* ws, hipStream_t s) {

@@ -244,7 +244,7 @@ bool build_wgrad7(const DmaTable& d, int P, int max_U, Wg7Table& out) {
     }
     // (one fixed list length: the kernel is instantiated for max_U rows, shorter unions are padded with rows of zeros)
     const int U = max_U;
-    if ((int)longest + 1 > U || U % 16 != 0 || (size_t)(U - 1) * WG7_ROW_BYTES > 0xFFFFu) return false;
+    if ((int)longest + 1 > U || U % 4 != 0 || (size_t)(U - 1) * WG7_ROW_BYTES > 0xFFFFu) return false;
     out.U = U;
     out.npatch = np;
     out.urow.assign((size_t)np * U, IDX_ZERO);

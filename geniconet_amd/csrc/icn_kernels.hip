@@ -1759,9 +1759,10 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
 constexpr int W7_PX = 16;                    // = WG7_PX (icn_geometry.h)
 constexpr int W7_ROWF = 64;                  // floats per staged row (the tile's 64 input channels) = WG7_ROW_BYTES / 4
 
-// NI: U = 16 * NI union rows per patch (NI DMA instructions per wave and stage); NST: ring stages (3: the DMA pointer two steps
-// ahead, counted waits; 2: one step ahead, the step's 56 MFMAs per wave cover the latency, a third less LDS)
-template <int NI, int NST>
+// U: union rows per patch, a multiple of 4 (a DMA instruction brings 4 rows; ceil(U / 16) instructions per wave and stage);
+// NST: ring stages (3: the DMA pointer two steps ahead, counted waits; 2: one step ahead -- the step's 56 MFMAs per wave cover
+// the latency -- and a third less LDS)
+template <int U, int NST>
 __global__ __launch_bounds__(256, 2) void k_wgrad7(
     const float* __restrict__ x,        // (B, Ps, Cin)
     const float* __restrict__ dy,       // (B, Pd, Cout0)
@@ -1774,8 +1775,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad7(
     int M, int Ps, int Pd, int Cin, int Cout, int Cout0, int n_slots, int patches_per_split, int n_splits, unsigned x_bytes,
     unsigned side_bytes, unsigned long long* __restrict__ trace) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int U = 16 * NI;
-    static_assert(U <= 128 && (NST == 2 || NST == 3), "at most two code DMAs (64 dwords each) per stage");
+    constexpr int NI = (U + 15) / 16;
+    static_assert(U % 4 == 0 && U <= 128 && (NST == 2 || NST == 3), "at most two code DMAs (64 dwords each) per stage");
+    static_assert(U % 16 == 0 || NST == 2, "uneven DMA counts per wave need the uncounted wait of the 2-stage ring");
     constexpr int CW = U > 64 ? 128 : 64;                           // code words per stage
     unsigned long long tr_t0 = 0;
     if (trace) tr_t0 = __builtin_amdgcn_s_memrealtime();
@@ -1837,7 +1839,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad7(
 #define ICN_W7_MAKE_OFFSETS() do { \
         _Pragma("unroll") \
         for (int i = 0; i < NI; ++i) { \
-            const int32_t c = Cs[(c_slot ^ 1) * CW + 4 * (wave + 4 * i) + lrow]; \
+            const int32_t c = (U % 16 == 0 || 4 * (wave + 4 * i) < U) ? Cs[(c_slot ^ 1) * CW + 4 * (wave + 4 * i) + lrow] : -1; \
             aoff[i] = c >= 0 ? ((unsigned)(c_b * Ps + c) * (unsigned)Cin + (unsigned)(ci0 + 4 * lchunk)) * 4u \
                     : c == -1 ? NOTHING_OFFSET \
                               : SIDE_FLAG | (((unsigned)(c_b * n_slots + (-2 - c)) * (unsigned)Cin + (unsigned)(ci0 + 4 * lchunk)) * 4u); \
@@ -1856,6 +1858,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad7(
             if (__builtin_amdgcn_ballot_w64(side_row) == 0) { \
                 _Pragma("unroll") \
                 for (int i = 0; i < NI; ++i) { \
+                    if (U % 16 != 0 && 4 * (wave + 4 * i) >= U) continue; \
                     float* dst_ = ring + __builtin_amdgcn_readfirstlane(slot_off_ + 4 * (wave + 4 * i) * W7_ROWF); \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst_, 16, aoff[i], 0, 0, 0); \
                 } \
@@ -1863,6 +1866,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad7(
                 p_exact = 0; \
                 _Pragma("unroll") \
                 for (int i = 0; i < NI; ++i) { \
+                    if (U % 16 != 0 && 4 * (wave + 4 * i) >= U) continue; \
                     float* dst_ = ring + __builtin_amdgcn_readfirstlane(slot_off_ + 4 * (wave + 4 * i) * W7_ROWF); \
                     if ((int)aoff[i] >= (int)NOTHING_OFFSET) \
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)dst_, 16, aoff[i], 0, 0, 0); \
@@ -2268,7 +2272,7 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
     int S = wgrad_splits_pertap(a.M, a.Cin, a.Cout, Cout0);
     W7Plan w7{};
     const size_t x_bytes7 = (size_t)(a.M / a.Pd) * a.Ps * a.Cin * 4, dy_bytes7 = (size_t)a.M * std::max(Cout0, a.Cout - Cout0) * 4;
-    const bool use7 = a.w7_rows != nullptr && a.w7_pos != nullptr && (a.w7_U == 64 || a.w7_U == 112) && !a.y_taps && !(dbg_flags() & (32 | 2048)) &&
+    const bool use7 = a.w7_rows != nullptr && a.w7_pos != nullptr && (a.w7_U == 56 || a.w7_U == 64 || a.w7_U == 112) && !a.y_taps && !(dbg_flags() & (32 | 2048)) &&
                       (a.n_slots == 0 || a.side != nullptr) && x_bytes7 < ((size_t)1 << 31) && dy_bytes7 < ((size_t)1 << 31) &&
                       (size_t)(a.M / a.Pd) * a.n_slots * a.Cin * 4 < ((size_t)1 << 30) &&
                       wgrad7_plan(a.M, a.Pd, a.Cin, a.Cout, Cout0, w7) && w7_class_enabled(a.w7_U > 64 ? 2 : 1);
@@ -2276,27 +2280,28 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         S = w7.splits;
         // ring depth (developer A/B: ICN_W7_NST=2|3): 3 stages / 2 workgroups per CU, or 2 stages (a third less LDS: 3 per CU)
         static const int nst_env = getenv("ICN_W7_NST") ? atoi(getenv("ICN_W7_NST")) : 0;
-        const int nst = a.w7_U > 64 ? 2 : (nst_env == 2 || nst_env == 3 ? nst_env : 3);
+        const int nst = (a.w7_U > 64 || a.w7_U % 16) ? 2 : (nst_env == 2 || nst_env == 3 ? nst_env : 3);
         const int occ = std::min(3, (int)((160 * 1024) / wgrad7_lds(a.w7_U, nst)));
         (void)occ;
         const dim3 grid((unsigned)w7.tiles * (unsigned)((S + 7) / 8 * 8));
         const unsigned side_bytes7 = (unsigned)((size_t)(a.M / a.Pd) * a.n_slots * a.Cin * 4);
         prof_mark_begin(PROF_WG7, a.algo_flops, s);
-#define ICN_W7(NI_, NST_)                                                                                                      \
+#define ICN_W7(U_, NST_)                                                                                                       \
     do {                                                                                                                       \
         static std::atomic<uint64_t> attr_devices{0};                                                                          \
         if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad7<NI_, NST_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad7<U_, NST_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       160 * 1024);                                                                             \
             attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);                             \
         }                                                                                                                      \
-        hipLaunchKernelGGL((k_wgrad7<NI_, NST_>), grid, dim3(256), wgrad7_lds(16 * NI_, NST_), s, a.x, a.dy, a.dy2, a.w7_rows, a.w7_pos, \
+        hipLaunchKernelGGL((k_wgrad7<U_, NST_>), grid, dim3(256), wgrad7_lds(U_, NST_), s, a.x, a.dy, a.dy2, a.w7_rows, a.w7_pos, \
                            a.n_slots > 0 ? a.side : nullptr, a.partial, a.bias_partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout, Cout0,   \
                            a.n_slots, w7.pps, S, (unsigned)x_bytes7, side_bytes7, g_trace_cap >= (size_t)grid.x * 8 ? g_trace : nullptr); \
     } while (0)
-        if (a.w7_U > 64) ICN_W7(7, 2);
-        else if (nst == 2) ICN_W7(4, 2);
-        else ICN_W7(4, 3);
+        if (a.w7_U == 112) ICN_W7(112, 2);
+        else if (a.w7_U == 56) ICN_W7(56, 2);
+        else if (nst == 2) ICN_W7(64, 2);
+        else ICN_W7(64, 3);
 #undef ICN_W7
         prof_mark_end(s);
     } else if (wgrad_supported(a.Cin, a.Cout)) {
@@ -2312,7 +2317,10 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         const bool dma = !(dbg_flags() & 32) && a.dcode != nullptr && (a.n_slots == 0 || a.side != nullptr) &&
                          x_bytes < ((size_t)1 << 31) && dy_bytes < ((size_t)1 << 31) && side_bytes < ((size_t)1 << 30);
         if ((pair || a.y_taps) && !dma) throw std::invalid_argument("icn: pair weight gradient outside the LDS-DMA kernel's limits");
-        const size_t lds_dma = wgrad_lds(BI, BJ, true);
+        // developer A/B (ICN_WG_OCC=2): at most two workgroups per CU, by asking for more than a third of the LDS -- leaves the
+        // chain's HBM-bound passes registers to run beside it on the second stream (three workgroups of 168 registers fill a SIMD)
+        static const int occ_cap = getenv("ICN_WG_OCC") ? atoi(getenv("ICN_WG_OCC")) : 0;
+        const size_t lds_dma = std::max(wgrad_lds(BI, BJ, true), occ_cap == 2 ? (size_t)(160 * 1024 / 3 + 1024) : (size_t)0);
 #define ICN_WG(I, J)                                                                                                       \
     do {                                                                                                                   \
         if (dma)                                                                                                           \
