@@ -27,7 +27,10 @@ __device__ __forceinline__ f32x4 ldv(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ void stv(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
 
-constexpr int BN_MAX_CHUNKS = 512;
+#ifndef ICN_BN_MAX_CHUNKS
+#define ICN_BN_MAX_CHUNKS 512
+#endif
+constexpr int BN_MAX_CHUNKS = ICN_BN_MAX_CHUNKS;
 
 // Sums of the BatchNorm passes are accumulated in DOUBLE from the first add (round 3), as the CPU reference does (torch's
 // acc_type<float> on the CPU is double; its device kernels sum in fp32).  A batch statistic enters every element of its channel,
