@@ -69,6 +69,13 @@ def set_weight_gradient_stream(mode, bucket_of=None):
     if mode not in _MODES:
         raise ValueError('mode must be one of %s' % (_MODES,))
     prev = (_wgrad_mode[0], _buckets.get('map'))
+    # A mode switch is a boundary between backward passes (the Trainer switches before and after every backward()): whatever a pass
+    # left behind -- it may have ended in an exception, in which case the engine never ran the end-of-pass callback -- is settled
+    # here, so that the next pass starts with a joined side stream and empty per-pass bookkeeping.
+    if _pending[0]:
+        _join_now()
+    _seen.clear()
+    _callback_queued[0] = False
     if mode == 'bucketed':
         if not bucket_of:
             raise ValueError("mode 'bucketed' needs the parameter -> bucket map")

@@ -70,6 +70,7 @@ def test_modes_other_than_bucketed_ignore_the_hooks_and_the_switch_checks_its_ar
     p = torch.nn.Parameter(torch.zeros(1))
     for mode in ('off', 'deferred', 'eager'):
         ic.set_weight_gradient_stream(mode)
+        del recorder[:]                                       # (the switch itself settles what the previous mode left pending)
         ic._pending[0] = True
         ic.parameter_gradient_ready(p)
         assert recorder == []
@@ -115,3 +116,16 @@ def test_a_weight_gradient_stays_on_the_current_stream_when_somebody_could_read_
     assert not _gradbuf.served_from_view(q, again) and not ic._readers_can_wait(q, again)
     ic._backward_pass_over()
     assert ic._seen == {} and not ic._callback_queued[0]
+
+
+def test_a_mode_switch_settles_what_an_aborted_pass_left_behind(recorder):
+    """A backward pass that raised never runs the engine's end-of-pass callback: the side stream would stay un-joined, the
+    callback flag set and the per-pass parameter set stale.  set_weight_gradient_stream (called by the Trainer around every
+    backward) joins and clears."""
+    ic.set_weight_gradient_stream('deferred')
+    q = torch.nn.Parameter(torch.zeros(2))
+    ic._pending[0] = True
+    ic._seen[id(q)] = True
+    ic._callback_queued[0] = True
+    ic.set_weight_gradient_stream('off')
+    assert recorder == ['join'] and ic._seen == {} and not ic._callback_queued[0] and not ic._pending[0]
