@@ -134,7 +134,7 @@ W7_CASES = [   # (r, stride, Cin, Cout0, Cout1 (0: single conv), B, corner mode)
     (2, 1, 64, 64, 0, 3, 'average'), (3, 1, 128, 128, 0, 5, 'average'), (4, 1, 64, 128, 0, 2, 'zeros'), (3, 1, 256, 256, 0, 36, 'average'),
     (3, 1, 128, 64, 64, 3, 'average'), (4, 1, 64, 128, 128, 7, 'average'),                       # pairs at stride 1
     (3, 2, 64, 128, 0, 2, 'average'), (4, 2, 128, 256, 256, 3, 'average'), (5, 2, 64, 128, 128, 2, 'zeros'), (3, 2, 256, 256, 256, 36, 'average'),
-    (5, 1, 64, 64, 0, 1, 'average'), (2, 1, 192, 320, 0, 2, 'average'),
+    (5, 1, 64, 64, 0, 1, 'average'), (2, 1, 192, 320, 0, 2, 'average'), (6, 1, 64, 64, 0, 1, 'zeros'), (3, 1, 256, 512, 512, 5, 'average'),
 ]
 
 

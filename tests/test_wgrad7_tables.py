@@ -20,7 +20,7 @@ def _dma_code(fwd):
 
 
 @pytest.mark.parametrize('mode', ['average', 'zeros'])
-@pytest.mark.parametrize('r,stride', [(2, 1), (3, 1), (4, 1), (5, 1), (3, 2), (4, 2), (5, 2), (6, 2)])
+@pytest.mark.parametrize('r,stride', [(2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (3, 2), (4, 2), (5, 2), (6, 2)])
 def test_union_rows_and_positions_reproduce_the_forward_table(r, stride, mode):
     tab = _lib.table_wgrad7(r, stride, mode)
     assert tab is not None
