@@ -1777,7 +1777,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad7(
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NI = (U + 15) / 16;
     static_assert(U % 4 == 0 && U <= 128 && (NST == 2 || NST == 3), "at most two code DMAs (64 dwords each) per stage");
-    static_assert(U % 16 == 0 || NST == 2, "uneven DMA counts per wave need the uncounted wait of the 2-stage ring");
+    // U % 16 != 0 (U = 56): the last DMA instruction exists in the first (U % 16) / 4 waves only; the counted waits follow
     constexpr int CW = U > 64 ? 128 : 64;                           // code words per stage
     unsigned long long tr_t0 = 0;
     if (trace) tr_t0 = __builtin_amdgcn_s_memrealtime();
@@ -1894,8 +1894,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad7(
     // more DMA per stage in flight (the positions) than the others.
 #define ICN_W7_RETIRE_AND_PUBLISH() do { \
         if (NST == 3 && issued && p_exact) { \
+            constexpr int FULLW = U % 16 == 0 ? 4 : (U % 16) / 4;      /* waves that issue all NI union-row DMAs */ \
             if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI + 2) : "memory"); \
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI + 1) : "memory"); \
+            else if (wave < FULLW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI + 1) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory"); \
         } else { \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         } \
@@ -2280,7 +2282,7 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         S = w7.splits;
         // ring depth (developer A/B: ICN_W7_NST=2|3): 3 stages / 2 workgroups per CU, or 2 stages (a third less LDS: 3 per CU)
         static const int nst_env = getenv("ICN_W7_NST") ? atoi(getenv("ICN_W7_NST")) : 0;
-        const int nst = (a.w7_U > 64 || a.w7_U % 16) ? 2 : (nst_env == 2 || nst_env == 3 ? nst_env : 3);
+        const int nst = a.w7_U > 64 ? 2 : (nst_env == 2 || nst_env == 3 ? nst_env : 3);
         const int occ = std::min(3, (int)((160 * 1024) / wgrad7_lds(a.w7_U, nst)));
         (void)occ;
         const dim3 grid((unsigned)w7.tiles * (unsigned)((S + 7) / 8 * 8));
@@ -2299,7 +2301,8 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
                            a.n_slots, w7.pps, S, (unsigned)x_bytes7, side_bytes7, g_trace_cap >= (size_t)grid.x * 8 ? g_trace : nullptr); \
     } while (0)
         if (a.w7_U == 112) ICN_W7(112, 2);
-        else if (a.w7_U == 56) ICN_W7(56, 2);
+        else if (a.w7_U == 56 && nst == 2) ICN_W7(56, 2);
+        else if (a.w7_U == 56) ICN_W7(56, 3);
         else if (nst == 2) ICN_W7(64, 2);
         else ICN_W7(64, 3);
 #undef ICN_W7
@@ -2659,7 +2662,8 @@ __global__ __launch_bounds__(256, 3) void k_upconv_gather_lds(const float* __res
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* ctab = reinterpret_cast<f32x4*>(smem);         // [ncls][20][2]
-    float* rows_s = reinterpret_cast<float*>(ctab + UPCONV_PX_CLASSES * 20 * 2);   // [umax][32]
+    float* rows_s = reinterpret_cast<float*>(ctab + ncls * 20 * 2);   // [umax][32]  (table sized by the classes in use: 19 of 32 -> 41 KB
+                                                                      //  per workgroup, which fits beside two k_wgrad7 workgroups: DESIGN 4.2b)
     for (int i = threadIdx.x; i < ncls * 20 * 2; i += 256) ctab[i] = ld4(cls_coef + 4 * i);
     const int C = C0 + C1, nchunk = C / PATCH_CH, n_it = umax / 32;
     const int nbg = (B + bgroup - 1) / bgroup, ncg = (nchunk + cgroup - 1) / cgroup, items = npatch * nbg * ncg;
@@ -2718,7 +2722,7 @@ void launch_upconv_gather_lds(const float* dy0, const float* dy1, float* g, cons
     patch_groups(t.npatch, B, (C0 + C1) / PATCH_CH, bgroup, cgroup);
     const int items = t.npatch * ((B + bgroup - 1) / bgroup) * (((C0 + C1) / PATCH_CH + cgroup - 1) / cgroup);
     const int grid = (items + 7) / 8 * 8;
-    const size_t lds = (size_t)UPCONV_PX_CLASSES * 20 * 2 * 16 + (size_t)(t.umax + 1) * PATCH_CH * 4;   // + the zero row
+    const size_t lds = (size_t)ncls * 20 * 2 * 16 + (size_t)(t.umax + 1) * PATCH_CH * 4;   // + the zero row
     static std::atomic<uint64_t> attr_devices{0};
     if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_upconv_gather_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
