@@ -142,17 +142,19 @@ def _readers_can_wait(q, g):
     return not (q._backward_hooks or getattr(q, '_post_accumulate_grad_hooks', None))
 
 
-def _wgrad_stream(dev, dests, *tensors):
+def _wgrad_stream(dev, dests, *tensors, allow=True):
     """The side stream for a weight-gradient launch issued from inside a backward pass, ordered after everything the current
     stream has been given so far; `dests` = [(parameter, tensor its gradient is about to be written to)], `tensors` (allocated
     on the current stream) are kept alive for the side stream.  None -- the launch stays on the current stream -- in mode 'off'
-    and whenever one of the destinations could be read on the current stream before the join (_readers_can_wait); when an
-    earlier gradient of one of these parameters is still on the side stream, the current stream waits for it first."""
+    and whenever one of the destinations could be read on the current stream before the join (_readers_can_wait), or the caller
+    does not want it there (`allow`); when an earlier gradient of one of these parameters is still on the side stream, the
+    current stream waits for it first -- which is why callers that keep a launch on the current stream for their own reasons
+    must still come through here."""
     if _wgrad_mode[0] == 'off':
         return None
     dests = [(q, g) for q, g in dests if g is not None]
-    ok = _wgrad_mode[0] == 'eager' or (all(_readers_can_wait(q, g) for q, g in dests)
-                                        and len({id(q) for q, _ in dests}) == len(dests))        # (one tensor as both weights)
+    ok = allow and (_wgrad_mode[0] == 'eager' or (all(_readers_can_wait(q, g) for q, g in dests)
+                                                  and len({id(q) for q, _ in dests}) == len(dests)))   # (one tensor as both weights)
     if _wgrad_mode[0] != 'eager' and not _callback_queued[0]:
         torch.autograd.Variable._execution_engine.queue_callback(_backward_pass_over)     # once per pass: join + forget `_seen`
         _callback_queued[0] = True
@@ -162,7 +164,8 @@ def _wgrad_stream(dev, dests, *tensors):
     if not ok:
         if again and _pending[0]:
             _join_now()
-        wgrad_stream_counts['kept'] += 1
+        if allow:                                    # (not the caller's own choice: a reader could not have waited)
+            wgrad_stream_counts['kept'] += 1
         return None
     side = _side_streams.get(dev.index)
     if side is None:
@@ -247,8 +250,8 @@ class _IcoConvFn(torch.autograd.Function):
                 #  stays on the current stream, which has nothing else left to do, instead of queueing behind the side stream's
                 #  backlog: +1.2 %, 4346-4370 against 4298-4314 meshes/s; keeping the last one or two OTHER weight gradients on
                 #  the current stream as well loses 1 - 1.5 %)
-                side = (_wgrad_stream(gyp.device, [(ctx.params[0], dw), (ctx.params[1], db)], xp, gyp, ws)
-                        if ctx.needs_input_grad[0] else None)
+                side = _wgrad_stream(gyp.device, [(ctx.params[0], dw), (ctx.params[1], db)], xp, gyp, ws,
+                                     allow=bool(ctx.needs_input_grad[0]))
                 rc = L.icn_conv_bwd_weight(xp.data_ptr(), gyp.data_ptr(), dw.data_ptr(),
                                            db.data_ptr() if db is not None else None, B, Cin, Cout, r, stride, mode,
                                            ws.data_ptr(), ws_bytes, side.cuda_stream if side is not None else _stream())

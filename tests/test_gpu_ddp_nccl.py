@@ -43,8 +43,23 @@ def _worker(rank, port, out_path):
     torch.cuda.set_device(0)
     device = torch.device('cuda', 0)
     dist.init_process_group('nccl', device_id=device, rank=0, world_size=1)     # RCCL communicator, as bench.py creates it
+    import importlib
     from geniconet_amd import _lib, data, models
     from geniconet_amd.train import Trainer
+    # race detector (round 4): every weight-gradient launch on the side stream is preceded there by a ~1 ms spin kernel, so the side
+    # stream lags the backward chain and a bucket whose all-reduce (here: its copies) is launched without the wait for the side
+    # stream reads gradients that have not been written -- the bit-identity below then fails instead of passing by luck
+    ic = importlib.import_module('geniconet_amd.ico_conv')
+    real_side, lagged = ic._wgrad_stream, [0]
+
+    def lagging(dev, dests, *tensors, **kw):
+        side = real_side(dev, dests, *tensors, **kw)
+        if side is not None:
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(2_000_000)
+            lagged[0] += 1
+        return side
+    ic._wgrad_stream = lagging
     report = {'backend': dist.get_backend(), 'cases': []}
     for name, R, B in (('ico2ico', 3, 3), ('ico2ico_vae', 3, 2), ('ico2ico', 5, 36)):
         p = models.default_params(name, subdivisions=R)
@@ -90,6 +105,7 @@ def _worker(rank, port, out_path):
                 case['weight_mismatch'].append(k)
         case['finite'] = bool(torch.isfinite(loss))
         case['status'] = _lib.device_status(device)
+        case['lagged'] = lagged[0]
         report['cases'].append(case)
         del plain, ddp
     dist.barrier(device_ids=[0])
@@ -107,7 +123,7 @@ def test_ddp_over_rccl_at_world_size_one_is_bit_identical_to_the_plain_trainer(t
     for c in rep['cases']:
         assert c['grad_mismatch'] == [], (c['name'], c['R'], c['grad_mismatch'][:5])
         assert c['weight_mismatch'] == [], (c['name'], c['R'], c['weight_mismatch'][:5])
-        assert c['finite'] and c['status'] == 0, c
+        assert c['finite'] and c['status'] == 0 and c['lagged'] >= 30, c       # (the side stream really lagged)
         # in the last step every gradient the package's backward kernels produce went straight into a bucket view (all
         # parameters but the 4 of the VAE latent heads' torch-native BatchNorms), none into a new tensor
         served, new = c['leases_step%d' % (c['nsteps'] - 1)]

@@ -449,6 +449,75 @@ def test_second_stream_guards_readers_it_cannot_see():
     assert all(torch.equal(a, b) for a, b in zip(res['off'][:3], res['deferred'][:3]))
 
 
+def test_a_lagging_side_stream_is_waited_for(monkeypatch):
+    """A race detector for the second stream: every weight-gradient launch that goes to the side stream is preceded there by a
+    ~1 ms spin kernel, so the side stream lags the backward chain by tens of milliseconds and ANY reader that does not wait
+    for it -- the optimiser after a missing end-of-pass join, AccumulateGrad on an existing .grad, the engine adding the two
+    gradients of a shared weight -- reads memory the weight gradient has not written yet.  With the joins and the
+    per-launch guard in place the results stay bit-identical to one stream: three trainer steps, a gradient-accumulation
+    pass, a module applied twice."""
+    import importlib
+    from geniconet_amd import data, models
+    from geniconet_amd.ico_conv import IcoConvS2S, set_weight_gradient_stream
+    from geniconet_amd.train import Trainer, build_criterion
+    ico_conv = importlib.import_module('geniconet_amd.ico_conv')        # (the package attribute of that name is the function)
+    real = ico_conv._wgrad_stream
+    lag = {'n': 0}
+
+    def lagging(dev, dests, *tensors, **kw):
+        side = real(dev, dests, *tensors, **kw)
+        if side is not None:
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(2_000_000)                  # ~1 ms at 2.1 - 2.4 GHz
+            lag['n'] += 1
+        return side
+    monkeypatch.setattr(ico_conv, '_wgrad_stream', lagging)
+    dev = torch.device('cuda', 0)
+    R, B = 3, 3
+    p = models.default_params('ico2ico', subdivisions=R)
+    p['ico2ico'].update(lr=1e-4, lr_base=1e-4, lr_max=1e-3)
+    two, one = Trainer(p, dev, seed=31), Trainer(p, dev, seed=32)
+    one.model.load_state_dict(two.model.state_dict())
+    one.overlap_weight_gradients = False
+    x, t = data.synthetic_batch(B, R, seed=71, device=dev)
+    x = x.contiguous(memory_format=torch.channels_last)
+    for _ in range(3):
+        two.step(x, t)
+        one.step(x, t)
+    assert lag['n'] >= 15                                     # the lag was really injected (>= 5 launches per step)
+    s2, s1 = two.model.state_dict(), one.model.state_dict()
+    assert [k for k in s1 if not torch.equal(s1[k], s2[k])] == []
+    # accumulation: a second backward on top of existing gradients, under 'deferred' and under 'off'
+    crit = build_criterion(p, dev)
+    grads = {}
+    for mode, tr in (('deferred', two), ('off', one)):
+        tr.model.zero_grad()
+        for _ in range(2):
+            prev = set_weight_gradient_stream(mode)
+            try:
+                crit(tr.model(x), t).backward()
+            finally:
+                set_weight_gradient_stream(*prev)
+        torch.cuda.synchronize()
+        grads[mode] = {k: q.grad.clone() for k, q in tr.model.named_parameters()}
+    assert [k for k in grads['off'] if not torch.equal(grads['off'][k], grads['deferred'][k])] == []
+    # a module applied twice
+    torch.manual_seed(9)
+    conv = IcoConvS2S(64, 64, 1, True, 3, 'average').cuda()
+    xs = torch.randn(4, 64, 40, 16, device='cuda').contiguous(memory_format=torch.channels_last)
+    res = {}
+    for mode in ('off', 'deferred'):
+        conv.zero_grad()
+        prev = set_weight_gradient_stream(mode)
+        try:
+            conv(torch.relu(conv(xs))).square().mean().backward()
+        finally:
+            set_weight_gradient_stream(*prev)
+        torch.cuda.synchronize()
+        res[mode] = (conv.weight.grad.clone(), conv.bias.grad.clone())
+    assert all(torch.equal(a, b) for a, b in zip(res['off'], res['deferred']))
+
+
 def test_validation_after_fused_training_steps_uses_the_current_running_statistics():
     """the fused training path updates running_mean / running_var through raw pointers (no version bump), so
     the eval-mode cache of [mean | 1/std] must be dropped by the training step itself.  The loop of run.py:479-487 -- step,
