@@ -516,6 +516,20 @@ def test_a_lagging_side_stream_is_waited_for(monkeypatch):
         torch.cuda.synchronize()
         res[mode] = (conv.weight.grad.clone(), conv.bias.grad.clone())
     assert all(torch.equal(a, b) for a, b in zip(res['off'], res['deferred']))
+    # torch.autograd.grad (nothing is accumulated into .grad): the end-of-pass callback joins before the results are handed out
+    from geniconet_amd.ico_conv import ico_conv as conv_fn
+    xg = xs.clone().requires_grad_()
+    w = (torch.randn(64, 64, 7, device='cuda') / 21).requires_grad_()
+    b = torch.randn(64, device='cuda', requires_grad=True)
+    got = {}
+    for mode in ('off', 'deferred'):
+        prev = set_weight_gradient_stream(mode)
+        try:
+            got[mode] = torch.autograd.grad(conv_fn(xg, w, b, 3, 1, 'average').square().sum(), (xg, w, b))
+        finally:
+            set_weight_gradient_stream(*prev)
+        got[mode] = [g.clone() for g in got[mode]]
+    assert all(torch.equal(a, b_) for a, b_ in zip(got['off'], got['deferred']))
 
 
 def test_validation_after_fused_training_steps_uses_the_current_running_statistics():
