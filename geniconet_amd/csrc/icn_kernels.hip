@@ -866,6 +866,10 @@ _Pragma("unroll") \
             const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc(sk_part, 0, (int)(gridDim.x * (unsigned)(BM * BN * 4)), 0x00020000);
             const int me = blockIdx.x;                     // this block's slot / flag
             if (c_s1 < sk_S) {                             // a piece that does not reach the tile's end: park it
+                if (sk_spin_limit > 0 && (sk_spin_limit & (1 << 28))) {       // tests (debug flag 8192): a SLOW partner -- the finisher
+#pragma unroll 1
+                    for (int i = 0; i < 16; ++i) __builtin_amdgcn_s_sleep(127);   // really waits (~50 us) instead of finding the piece parked
+                }
                 const unsigned base = (unsigned)me * (unsigned)(BM * BN * 4) + tid * 16u;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -1244,7 +1248,7 @@ static void launch_conv_dma_sk_t(const GatherGemmArgs& a, int occ, hipStream_t s
     hipLaunchKernelGGL((k_conv_dma_sk<BM, BN, SEG>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,
                        a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.M, a.Ps, a.Pd, a.K,
                        a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs, CONV_SK_MIN_PIECE,
-                       a.sk_part, a.sk_flag, device_status_word(), (dbg_flags() & 256) ? -1 : (1 << 22),
+                       a.sk_part, a.sk_flag, device_status_word(), (dbg_flags() & 256) ? -1 : ((1 << 22) | ((dbg_flags() & 8192) ? (1 << 28) : 0)),
                        g_trace_cap >= (size_t)grid * 8 ? g_trace : nullptr, sk_boundary_tables(ntiles, grid, conv_sk_steps(a), occ));
     prof_mark_end(s);
 }

@@ -205,7 +205,8 @@ void launch_point_to_mesh(const float* pts, const float* vts, const int32_t* fac
 // 128 = no stream-K, 256 = fault injection: every stream-K finisher reports its partners lost (tests of the failure path),
 // 512 = masked launches walk tiles b, b + G, ... instead of the balanced tile lists, 1024 = the sparse passes of the decoder-block
 // head on the row-per-thread kernels instead of the LDS-staged ones, 2048 = weight gradients on the per-tap kernel k_wgrad_dma
-// instead of the all-taps kernel k_wgrad7, 4096 = stride-2 weight gradients on k_wgrad7 too (default: stride 1 only)
+// instead of the all-taps kernel k_wgrad7, 4096 = stride-2 weight gradients on k_wgrad7 too (default: stride 1 only),
+// 8192 = every stream-K workgroup sleeps ~50 us before it parks its piece (tests: the finishers really wait for their partners)
 int debug_flags();
 int set_debug_flags(int flags);
 

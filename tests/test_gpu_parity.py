@@ -279,6 +279,15 @@ def test_stream_k_equals_whole_tile_schedule(r, cin, cout, B, pair):
         again, _ = run(0)                                    # fixed summation order: bit-identical when repeated
         for a, b in zip(got, again):
             assert torch.equal(a, b), trial
+        # slow partners (debug flag 8192: every workgroup sleeps ~50 us before it parks its piece): normally a finisher finds its
+        # partners' pieces long parked, here it really spins on their flags -- the hand-off (system-scope slot stores complete
+        # before the flag is raised, slot loads issued after the flag was seen) must give the same bits
+        slow, k_slow = run(8192)
+        assert any(k.startswith('k_conv_dma_sk') for k in k_slow)
+        for a, b in zip(got, slow):
+            assert torch.equal(a, b), trial
+    from geniconet_amd import _lib as lib_
+    assert lib_.device_status() == 0                         # nobody timed out waiting
 
 
 @pytest.mark.parametrize('r,cin,cout,B', [(2, 256, 256, 36), (3, 256, 128, 36), (4, 128, 64, 9)])
