@@ -13,7 +13,7 @@ import pytest
 from geniconet_amd import _lib, geometry
 from oracle import ico_ref
 
-LEVELS = [0, 1, 2, 3, 4]
+LEVELS = [0, 1, 2, 3, 4, 5, 6]      # 5 = the BASELINE configs, 6 = the I6 config (config 5)
 
 
 def directed_edges(f):
@@ -78,7 +78,7 @@ def test_taps_are_the_true_one_ring_in_face_order(r, source):
         assert dup == (1 if len(ring[p]) == 5 else 0)
 
 
-@pytest.mark.parametrize('r', [1, 2, 3, 4])
+@pytest.mark.parametrize('r', [1, 2, 3, 4, 5, 6])
 def test_levels_nest(r):
     """Coarse pixel (i,j) of level r-1 is fine pixel (2i, 2j+1); every other fine vertex is the midpoint of exactly
     one coarse edge; the stride-2 table is the stride-1 table sampled at those sites (App. A.4)."""
@@ -103,7 +103,7 @@ def test_levels_nest(r):
     assert Pc == s2.shape[1]
 
 
-@pytest.mark.parametrize('r', [0, 1, 2, 3])
+@pytest.mark.parametrize('r', [0, 1, 2, 3, 4, 5, 6])
 def test_grid_positions(r):
     v, f = geometry.get_icosahedral_grid(r)
     assert v.shape == (geometry.num_vertices(r), 3)

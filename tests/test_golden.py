@@ -25,6 +25,53 @@ def T(a, dev='cpu', grad=False):
 
 def test_fixtures_present():
     assert len(CONV) == 5 and len(UP) == 3 and os.path.exists(os.path.join(GOLDEN, 'ico2ico_I5_b4.npz'))
+    assert os.path.exists(os.path.join(GOLDEN, 'ico2ico_I6_b1.npz'))
+
+
+def _i6_compare(g, y, loss, named_grads, tol_y, tol_g):
+    """Output sample / norm, loss and every parameter gradient (norm + strided sample) against tests/golden/ico2ico_I6_b1.npz."""
+    yf = np.asarray(y, np.float64).reshape(-1)
+    assert rel_l2(yf[::int(g['y_stride'])], g['y_sample']) < tol_y
+    assert abs(np.linalg.norm(yf) - float(g['y_norm'])) < tol_y * float(g['y_norm'])
+    assert abs(loss - float(g['loss'])) < 1e-4 * float(g['loss'])
+    grads = dict(named_grads)
+    assert list(g['grad_names']) == list(grads)
+    floor = 1e-3 * float(g['grad_norms'].max())
+    worst = (0.0, None)
+    for i, k in enumerate(g['grad_names']):
+        a = np.asarray(grads[str(k)], np.float64).reshape(-1)
+        want = g['grad_samples'][g['grad_offsets'][i]:g['grad_offsets'][i + 1]]
+        step = max(1, -(-a.size // 2048))
+        scale = max(float(g['grad_norms'][i]), floor)
+        # the sample is 1 / step of the tensor: its error is held against the same share of the tensor's norm
+        e = max(abs(np.linalg.norm(a) - float(g['grad_norms'][i])) / scale,
+                np.linalg.norm(a[::step] - want) / (scale / np.sqrt(step)) if scale > 0 else 0.0)
+        worst = max(worst, (e, str(k)))
+    assert worst[0] < tol_g, worst
+    return worst
+
+
+def _i6_inputs(g):
+    tgt = g['target']
+    return tgt, tgt[:, :3, :-2].reshape(1, 3, 320, 128).copy()
+
+
+def test_oracle_reproduces_the_I6_golden():
+    """BASELINE config 5 (ico2ico at subdivision 6; the reference hard-wires 5, models.py:108-148): the fp32 oracle against the
+    float64 fixture -- forward 1e-5, every parameter gradient 2e-3 (the fixture's mesh was chosen for err32 = 4e-4)."""
+    g = np.load(os.path.join(GOLDEN, 'ico2ico_I6_b1.npz'))
+    assert float(g['err32']) < 1e-3
+    tgt, x = _i6_inputs(g)
+    torch.manual_seed(int(g['model_seed']))
+    model = models_ref.ico2ico(R=6).train()
+    y = model(T(x))
+    terms = loss_ref.p2p_terms(y.detach().numpy(), tgt, 6)
+    np.testing.assert_allclose(terms, g['loss_terms'], rtol=1e-4)
+    v = torch.cat([y.reshape(1, 3, -1), y.reshape(1, 3, 5, 64, 128)[:, :, :, 0, 0].mean(-1, keepdim=True),
+                   y.reshape(1, 3, 5, 64, 128)[:, :, :, -1, -1].mean(-1, keepdim=True)], 2)
+    loss = ((v - T(tgt[:, :3])) ** 2).mean()
+    loss.backward()
+    _i6_compare(g, y.detach().numpy(), float(loss.detach()), [(k, q.grad.numpy()) for k, q in model.named_parameters()], 1e-5, 2e-3)
 
 
 @pytest.mark.parametrize('path', CONV, ids=os.path.basename)
@@ -104,3 +151,28 @@ def test_hip_reproduces_model_golden():
     crit(y, T(tgt, 'cuda'))
     mse, cos, lap, _, _ = crit.get_last_losses()
     np.testing.assert_allclose([mse, cos, lap], g['loss_terms'], rtol=2e-3)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_the_I6_golden():
+    """BASELINE config 5 on the GPU against the committed float64 oracle fixture: one mesh at subdivision 6 through the
+    product network (training-mode BatchNorm) and the HIP loss -- forward 1e-4, loss terms, and every parameter gradient's
+    norm + strided sample to 2e-3 (plain bound: the fixture's mesh is the one of six where the oracle's own fp32 evaluation is
+    within 4e-4 of float64; the tight gradient check at the GPU's ReLU pattern is tests/test_relu_pattern.py)."""
+    from geniconet_amd import losses, models
+    g = np.load(os.path.join(GOLDEN, 'ico2ico_I6_b1.npz'))
+    tgt, x = _i6_inputs(g)
+    torch.manual_seed(int(g['model_seed']))
+    ref = models_ref.ico2ico(R=6)                                 # re-creates the golden's weights
+    net = models.ico2ico(models.default_params('ico2ico', subdivisions=6))
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.cuda().train()
+    y = net(T(x, 'cuda'))
+    crit = losses.P2P_Loss(6, 1., 0., 0.).cuda()
+    loss = crit(y, T(tgt, 'cuda'))
+    loss.backward()
+    mse, cos, lap, _, _ = crit.get_last_losses()
+    np.testing.assert_allclose([mse, cos, lap], g['loss_terms'], rtol=2e-3)
+    w = _i6_compare(g, y.detach().cpu().numpy(), float(loss.detach()), [(k, q.grad.cpu().numpy()) for k, q in net.named_parameters()],
+                    TOL, 2e-3)
+    print('I6 golden on the GPU: worst gradient %.2e (%s)' % w)

@@ -43,6 +43,7 @@ MFMA_CASES = [
     (4, 1, 128, 64, 2, 'average'), (2, 2, 256, 256, 3, 'average'), (3, 1, 256, 128, 2, 'zeros'),
     (4, 2, 64, 128, 1, 'zeros'), (2, 1, 96, 192, 2, 'average'), (1, 1, 64, 64, 1, 'average'),
     (5, 1, 128, 128, 1, 'average'),
+    (6, 1, 64, 64, 1, 'average'),          # level 6 (BASELINE config 5; the reference hard-wires 5, models.py:108-148): up3.conv01
 ]
 # odd-but-legal shapes: K = 32 / 64 (short tiles; stride-2 dgrad with Cout = 64 must take the register-staged kernel),
 # N = 192 / 320, single sample, coarsest levels, 'zeros' corners with multi-entry transposed taps
@@ -54,6 +55,7 @@ EDGE_CASES = [
 SCALAR_CASES = [
     (2, 1, 3, 64, 2, 'average'), (1, 1, 5, 7, 2, 'average'), (2, 2, 3, 8, 2, 'zeros'), (0, 1, 4, 4, 2, 'average'),
     (3, 1, 3, 64, 2, 'zeros'), (2, 1, 64, 3, 2, 'average'), (1, 2, 33, 65, 1, 'average'),
+    (6, 1, 3, 64, 1, 'average'),           # the I6 network's stem
 ]
 
 
@@ -72,6 +74,8 @@ PAIR_CASES = [
     (4, 1, 128, 64, 2, 'average', True), (3, 1, 64, 128, 2, 'average', True), (3, 2, 64, 128, 2, 'average', True),
     (4, 2, 128, 256, 1, 'average', True), (2, 2, 256, 256, 3, 'average', False), (5, 1, 64, 64, 1, 'average', True),
     (2, 1, 256, 256, 2, 'zeros', True), (4, 2, 64, 64, 2, 'zeros', False), (1, 1, 128, 128, 2, 'average', True),
+    (6, 2, 64, 128, 1, 'average', True),   # the I6 network's first residual block: 64 -> 2 x 128, level 6 -> 5
+    (5, 2, 128, 256, 1, 'average', True),  # ... and its second: 128 -> 2 x 256, level 5 -> 4
 ]
 
 
@@ -466,7 +470,8 @@ def test_argument_errors_on_gpu():
         ico_upsample(x.double(), 2, 'average')
 
 
-@pytest.mark.parametrize('r,C,B,mode', [(0, 4, 2, 'average'), (2, 64, 3, 'average'), (3, 5, 2, 'zeros'), (4, 128, 2, 'average'), (1, 7, 1, 'zeros')])
+@pytest.mark.parametrize('r,C,B,mode', [(0, 4, 2, 'average'), (2, 64, 3, 'average'), (3, 5, 2, 'zeros'), (4, 128, 2, 'average'), (1, 7, 1, 'zeros'),
+                                        (5, 64, 1, 'average'), (5, 8, 2, 'zeros')])        # level 5 -> 6 (I6 config)
 def test_upsample_forward_backward(r, C, B, mode):
     from geniconet_amd.ico_conv import ico_upsample
     g = torch.Generator().manual_seed(3)
@@ -850,7 +855,9 @@ def test_device_resident_dataset_feeds_the_hip_path(tmp_path):
 # a row segment
 UPCONV_CASES = [(0, 64, 64, 2, 'average', True), (1, 64, 128, 3, 'average', True), (2, 256, 256, 2, 'average', True),
                 (3, 128, 64, 2, 'average', True), (2, 64, 64, 5, 'zeros', True), (3, 64, 128, 1, 'zeros', False),
-                (4, 128, 64, 1, 'average', True), (2, 128, 192, 3, 'average', False)]
+                (4, 128, 64, 1, 'average', True), (2, 128, 192, 3, 'average', False),
+                (4, 256, 128, 1, 'average', True),      # the I6 network's decoder heads: level 4 -> 5 ...
+                (5, 128, 64, 1, 'average', True)]       # ... and the I6 network's last decoder head, level 5 -> 6, all gradients
 
 
 @pytest.mark.parametrize('case', UPCONV_CASES, ids=lambda c: 'r%d_%dx2x%d_b%d_%s_bias%d' % c)

@@ -2,6 +2,7 @@
 oracle/ico_ref.py): two independent derivations of SURVEY App. A must agree entry for entry."""
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 from geniconet_amd import _lib
 from oracle import ico_ref
@@ -11,7 +12,25 @@ def corner_pixel(n, k, c):
     return (c * n) * 2 * n if k == 0 else ((c + 1) * n - 1) * 2 * n + 2 * n - 1
 
 
-@pytest.mark.parametrize('r', [0, 1, 2, 3, 4, 5])
+def corner_pixels(n, k):
+    return np.array([corner_pixel(n, k, c) for c in range(5)])
+
+
+def code_matrix(codes, rows, n_src, shape):
+    """Sparse matrix of a list of (row, code) pairs: code >= 0 a pixel (weight 1), -2 - k the mean of the 5 corner pixels of
+    pole k (5 x 0.2), -1 nothing.  n_src is the chart size n of the level the codes point into.  Duplicates add up."""
+    codes, rows = np.asarray(codes).ravel(), np.asarray(rows).ravel()
+    px = codes >= 0
+    R, C, V = [rows[px]], [codes[px]], [np.ones(int(px.sum()))]
+    for k in (0, 1):
+        m = codes == -2 - k
+        R.append(np.repeat(rows[m], 5))
+        C.append(np.tile(corner_pixels(n_src, k), int(m.sum())))
+        V.append(np.full(5 * int(m.sum()), 0.2))
+    return sp.coo_matrix((np.concatenate(V), (np.concatenate(R), np.concatenate(C))), shape=shape).tocsr()
+
+
+@pytest.mark.parametrize('r', [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('stride', [1, 2])
 def test_conv_forward_table(r, stride):
     if stride == 2 and r == 0:
@@ -24,12 +43,12 @@ def test_conv_forward_table(r, stride):
     assert (zer == np.where(ref >= P, -1, ref)).all()
 
 
-@pytest.mark.parametrize('r', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('r', [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('stride', [1, 2])
 @pytest.mark.parametrize('mode', ['average', 'zeros'])
 def test_conv_backward_table_is_the_transpose(r, stride, mode):
-    """Dense check: G_t (P_out x P_in, pole mean folded in) built from the forward table, transposed, equals the
-    matrix the backward table describes."""
+    """G_t (P_out x P_in, pole mean folded in) built from the forward table, transposed, equals the matrix the backward
+    table describes -- as sparse matrices, so that the levels production runs (r = 5, and 6 for the I6 config) are covered."""
     if stride == 2 and r == 0:
         pytest.skip('stride 2 needs r >= 1')
     n = 2 ** r
@@ -38,60 +57,37 @@ def test_conv_backward_table_is_the_transpose(r, stride, mode):
     fwd, bwd = _lib.table_conv_fwd(r, stride, mode), _lib.table_conv_bwd(r, stride, mode)
     assert bwd.shape[0] == 7 and bwd.shape[2] == Pin
     for t in range(7):
-        G = np.zeros((Pout, Pin))
-        for p in range(Pout):
-            q = fwd[t, p]
-            if q >= 0:
-                G[p, q] += 1
-            elif q <= -2:
-                for c in range(5):
-                    G[p, corner_pixel(n, -2 - q, c)] += 0.2
-        H = np.zeros((Pin, Pout))
-        for e in range(bwd.shape[1]):
-            for q in range(Pin):
-                p = bwd[t, e, q]
-                if p >= 0:
-                    H[q, p] += 1
-                elif p <= -2:
-                    for c in range(5):
-                        H[q, corner_pixel(no, -2 - p, c)] += 0.2
-        np.testing.assert_allclose(H, G.T, atol=1e-12)
+        G = code_matrix(fwd[t], np.arange(Pout), n, (Pout, Pin))
+        H = code_matrix(bwd[t], np.tile(np.arange(Pin), bwd.shape[1]), no, (Pin, Pout))
+        d = (H - G.T).tocoo()
+        assert d.nnz == 0 or np.abs(d.data).max() < 1e-12, (t, np.abs(d.data).max())
 
 
-@pytest.mark.parametrize('r', [0, 1, 2, 3])
+@pytest.mark.parametrize('r', [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize('mode', ['average', 'zeros'])
 def test_upsample_tables(r, mode):
+    """r -> r + 1; r = 5 is the last upsample of the I6 network (5 -> 6)."""
     n = 2 ** r
     Pc, Pf = 10 * n * n, 40 * n * n
     pairs = ico_ref.upsample_table(r)
-    U = np.zeros((Pf, Pc))
-    for q in range(Pf):
-        for v in pairs[:, q]:
-            w = 0.5
-            if v >= Pc:
-                if mode == 'average':
-                    for c in range(5):
-                        U[q, corner_pixel(n, v - Pc, c)] += w * 0.2
-            else:
-                U[q, v] += w
+    codes = np.where(pairs >= Pc, (-2 - (pairs - Pc)) if mode == 'average' else -1, pairs)
+    U = 0.5 * code_matrix(codes, np.tile(np.arange(Pf), 2), n, (Pf, Pc))
 
-    def dense(idx, coef, shape):
-        M = np.zeros(shape)
-        for row in range(idx.shape[0]):
-            packed = True
-            for e in range(idx.shape[1]):
-                if idx[row, e] >= 0:
-                    assert packed, 'rows must be left-packed'
-                    M[row, idx[row, e]] += coef[row, e]
-                else:
-                    packed = False
-        return M
-    np.testing.assert_allclose(dense(*_lib.table_upsample(r, mode, False), (Pf, Pc)), U, atol=1e-7)
-    np.testing.assert_allclose(dense(*_lib.table_upsample(r, mode, True), (Pc, Pf)), U.T, atol=1e-7)
+    def ell(idx, coef, shape):
+        used = idx >= 0
+        assert (used[:, :-1] >= used[:, 1:]).all(), 'rows must be left-packed'
+        rows = np.repeat(np.arange(idx.shape[0]), idx.shape[1]).reshape(idx.shape)
+        return sp.coo_matrix((coef[used].astype(np.float64), (rows[used], idx[used])), shape=shape).tocsr()
+
+    def close(a, b):
+        d = (a - b).tocoo()
+        return d.nnz == 0 or np.abs(d.data).max() < 1e-7
+    assert close(ell(*_lib.table_upsample(r, mode, False), (Pf, Pc)), U)
+    assert close(ell(*_lib.table_upsample(r, mode, True), (Pc, Pf)), U.T)
     assert (np.sort(_lib.table_upsample_pairs(r), 0) == np.sort(pairs, 0)).all()
 
 
-@pytest.mark.parametrize('r', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('r', [0, 1, 2, 3, 4, 5, 6])
 def test_faces_table(r):
     assert (_lib.table_faces(r) == ico_ref.faces_from_lattice(r)).all()
 

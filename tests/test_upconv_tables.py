@@ -3,6 +3,7 @@ evaluated in numpy (float64) from the table alone and compared with the oracle's
 (oracle/ico_ref.py ico_upsample -> ico_conv; reference models.py:58-60).  CPU only: this pins the table before any kernel."""
 import numpy as np
 import pytest
+import scipy.sparse as sp
 import torch
 
 from conftest import rel_l2
@@ -11,7 +12,8 @@ from oracle import ico_ref
 
 
 def eval_composite(tab, x, w, bias):
-    """x (B, Cin, Pc), w (Cout, Cin, 7), bias (Cout) -> y (B, Cout, Pf) using only the table."""
+    """x (B, Cin, Pc), w (Cout, Cin, 7), bias (Cout) -> y (B, Cout, Pf) using only the table (vectorised per segment and
+    virtual tap, so that the levels production runs -- coarse r = 4, and 5 for the I6 config -- finish in seconds)."""
     B, Cin, _ = x.shape
     weff = np.einsum('vt,oit->voi', tab['alpha'].astype(np.float64), w)                # (NV, Cout, Cin)
     side = np.zeros((B, Cin, max(len(tab['slot_idx']), 1)))
@@ -23,20 +25,20 @@ def eval_composite(tab, x, w, bias):
     macs = 0
     for cnt, off, mask in tab['seg']:
         taps = [v for v in range(tab['code'].shape[0]) if (int(mask) >> v) & 1]
-        for pos in range(off, off + cnt):
-            p = tab['pix'][pos]
-            for v in taps:
-                c = tab['code'][v, pos]
-                macs += 1
-                if c >= 0:
-                    y[:, :, p] += x[:, :, c] @ weff[v].T
-                elif c <= -2:
-                    y[:, :, p] += side[:, :, -2 - c] @ weff[v].T
+        pix = tab['pix'][off:off + cnt]
+        for v in taps:
+            c = tab['code'][v, off:off + cnt]
+            macs += int(cnt)
+            src = np.zeros((B, Cin, int(cnt)))
+            px, sd = c >= 0, c <= -2
+            src[:, :, px] = x[:, :, c[px]]
+            src[:, :, sd] = side[:, :, -2 - c[sd]]
+            y[:, :, pix] += np.einsum('oi,bip->bop', weff[v], src)
     return y, macs
 
 
 @pytest.mark.parametrize('mode', ['average', 'zeros'])
-@pytest.mark.parametrize('r', [0, 1, 2, 3])
+@pytest.mark.parametrize('r', [0, 1, 2, 3, 4, 5])
 def test_composite_table_equals_upsample_then_conv(r, mode):
     tab = _lib.table_upconv(r, mode)
     n = 2 ** r
@@ -74,7 +76,7 @@ def test_virtual_taps_are_the_documented_ones():
 
 
 @pytest.mark.parametrize('mode', ['average', 'zeros'])
-@pytest.mark.parametrize('r', [0, 1, 2, 3])
+@pytest.mark.parametrize('r', [0, 1, 2, 3, 4, 5])
 def test_aggregated_backward_table_gives_both_gradients(r, mode):
     """icn_table_upconv_bwd: g_t[s] = sum_p U[nbr_t(p), s] dy[p] turns the backward of conv(upsample(x)) into dense
     coarse-level contractions, dx[s] = sum_t W_t^T g_t[s] and dW_t = sum_s x[s]^T g_t[s] (and dbias = sum_s g_0[s] for
@@ -92,12 +94,10 @@ def test_aggregated_backward_table_gives_both_gradients(r, mode):
     dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
     y.backward(dy)
     dyf = dy.reshape(B, Cout, Pf).numpy()
-    gt = np.zeros((B, Cout, Pc, 7))
-    for row in range(7 * Pc):
-        s, t = divmod(row, 7)
-        for p, c in zip(idx[row], coef[row]):
-            if p >= 0:
-                gt[:, :, s, t] += float(c) * dyf[:, :, p]
+    used = idx >= 0
+    rows = np.repeat(np.arange(7 * Pc), idx.shape[1]).reshape(idx.shape)
+    A = sp.coo_matrix((coef[used].astype(np.float64), (rows[used], idx[used])), shape=(7 * Pc, Pf)).tocsr()
+    gt = (A @ dyf.reshape(B * Cout, Pf).T).T.reshape(B, Cout, Pc, 7)                   # row s * 7 + t
     wn, xn = w.detach().numpy(), x.detach().reshape(B, Cin, Pc).numpy()
     dx = np.einsum('oit,bost->bis', wn, gt)
     dw = np.einsum('bis,bost->oit', xn, gt)
