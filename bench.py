@@ -3,6 +3,7 @@
   python bench.py --gpus 1 --steps 50 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...        (no WORLD_SIZE in the environment: starts the N ranks itself, see launch_ranks)
 
 A step = one pass of the hot path over one batch: forward -> P2P loss -> zero_grad -> backward -> Adam -> CyclicLR
 (reference run.py:244-254) on 36 synthetic I5 meshes per GPU already resident in HBM.  Weak scaling: per-GPU
@@ -13,7 +14,10 @@ Rank 0 prints ONE JSON line, with
                  gradients on a second stream beside the other launches; a launch that shares the chip has no
                  roofline of its own, so the events are taken in the survey steps, which run on one stream, and the timed
                  region carries none (ICN_WGRAD_STREAM=off: one stream throughout, events over the timed region);
-  cpu_baseline : the CPU restatement of the same step (oracle/) timed on this host's cores (N=1 only).
+  cpu_baseline : the CPU restatement of the same step (oracle/) timed on this host's cores (N=1 only);
+  also         : (N=1 only) BASELINE configs 4 and 5 -- ico2ico_vae at I5 / batch 36, ico2ico at I6 / batch 8 -- timed in the same
+                 process after the headline (model freed in between), same --steps / --warmup; the headline's fields, timed region
+                 and metric are not affected.
 """
 import argparse
 import faulthandler
@@ -22,14 +26,10 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from geniconet_amd import _lib, data, models  # noqa: E402
-from geniconet_amd.train import Trainer, force_ddp_requested  # noqa: E402
+# torch and the package are imported by run(), not here: the launcher path of `python bench.py --gpus N` (launch_ranks) must
+# start its children before anything in this process could touch the GPU, and needs the standard library only.
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
 # algorithmic work per mesh per TRAINING step (SURVEY.md 8d / BASELINE.md): 3 x forward conv FLOPs
@@ -74,7 +74,9 @@ def cpu_baseline(cfg, budget_s=12.0):
     GPU/CPU ratio); `with_anomaly`: the same steps inside torch.autograd.detect_anomaly(), as the reference trains
     (run.py:237).  Bounded sample: the batch is sized from a 2-mesh calibration step so that 3 timed steps take about
     budget_s in each mode."""
-    from geniconet_amd.train import build_criterion
+    import torch
+    from geniconet_amd import data, models
+    from geniconet_amd.train import Trainer, build_criterion
     from oracle import models_ref
     cores = min(usable_cores(), int(os.environ.get('ICN_CPU_THREADS', 64)))
     torch.set_num_threads(cores)
@@ -112,51 +114,60 @@ def cpu_baseline(cfg, budget_s=12.0):
                       % (steps, batch, cfg['R'], int(budget_s), cores)}
 
 
-def main():
-    faulthandler.enable()      # a native crash leaves every rank's Python stack on stderr
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--config', choices=sorted(CONFIGS), default='ae')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process becomes a launcher.  It starts N fresh
+    interpreters of this same file -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT (a free port) set, one
+    rank per GPU -- exactly what `python -m torch.distributed.run --nproc-per-node N` would start, waits for them, and exits
+    with the first non-zero code (the others are then stopped by PID).  The launcher never imports torch and never touches the
+    GPU: the children are new processes, not re-execs of one that initialised HIP.  stdout / stderr are inherited, so rank 0's
+    one JSON line is this command's one JSON line."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), ICN_BENCH_LAUNCHER='self')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs on this pool's hosts
+        env.setdefault('OMP_NUM_THREADS', '1')                   # as torch.distributed.run sets it
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc, live = 0, list(procs)
+    try:
+        while live and rc == 0:
+            time.sleep(0.2)
+            for q in list(live):
+                code = q.poll()
+                if code is not None:
+                    live.remove(q)
+                    if code != 0 and rc == 0:
+                        rc = code if code > 0 else 128 - code
+                        sys.stderr.write('bench.py: rank %d (pid %d) exited with %d; stopping the other ranks\n' % (procs.index(q), q.pid, code))
+    except KeyboardInterrupt:
+        rc = 130
+    for q in live:                                               # exact PIDs this launcher started, nothing by pattern
+        q.send_signal(signal.SIGTERM)
+    deadline = time.time() + 10
+    for q in live:
+        try:
+            q.wait(max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            q.kill()
+            q.wait()
+    return rc
 
-    rank = int(os.environ.get('RANK', 0))
-    local = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py: no GPU visible; the HIP path has no CPU fallback')
-    # Rehearsal switch for a 1-GPU box (never set by the driver): all ranks share device 0 and talk over gloo, which
-    # exercises the same DDP wiring (bucketing, hooks on the custom autograd ops) without RCCL.
-    rehearsal = os.environ.get('ICN_BENCH_REHEARSAL', '') == '1'
-    if rehearsal:
-        local = 0
-        if world > 6:
-            raise SystemExit('bench.py: the one-GPU rehearsal is limited to 6 ranks (process cap of a GPU box)')
-        faulthandler.dump_traceback_later(int(os.environ.get('ICN_BENCH_WATCHDOG', 300)), exit=True)
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
-    # ICN_FORCE_DDP=1 at N = 1 (never set by the driver): the production communication path on a one-GPU box -- an RCCL process
-    # group of one rank, DistributedDataParallel around the model exactly as for N > 1, device barriers.  Everything N ranks
-    # would run except the wire.
-    forced = world == 1 and force_ddp_requested() and not rehearsal
-    if forced:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29517')
-        dist.init_process_group('nccl', device_id=device, rank=0, world_size=1)
-    group = world > 1 or forced
-    if world > 1:
-        if rehearsal:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=device)      # RCCL over xGMI
 
-    _lib.lib()
+def measure(cfg, args, ctx, headline):
+    """W warm-up steps, (survey steps), then EXACTLY K timed steps of configuration `cfg` between barrier + synchronize on both
+    sides; MAX over ranks.  Returns the fields of the bench line that depend on the measurement.  headline=False (the `also`
+    entries) skips the two extra overlapped steps that only feed avg_launch_us_overlapped."""
+    import torch
+    import torch.distributed as dist
+    from geniconet_amd import _lib, data, models
+    from geniconet_amd.train import Trainer
+    device, rank, world, group, rehearsal, local = (ctx[k] for k in ('device', 'rank', 'world', 'group', 'rehearsal', 'local'))
     p = models.default_params(cfg['model'], subdivisions=cfg['R'])
     tr = Trainer(p, device, seed=0)
     x, t = data.synthetic_batch(cfg['batch'], cfg['R'], seed=1234 + rank, device=device)
@@ -208,94 +219,209 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_stop() if dominant and not overlapped else []
-    if dominant and overlapped:
+    if dominant and overlapped and headline:
         _lib.profile_start(200, only=dominant)
         for _ in range(2):
             tr.step(x, t)
         torch.cuda.synchronize()
         prof = _lib.profile_stop()
-    el = torch.tensor([elapsed], device='cpu' if rehearsal else device, dtype=torch.float64)   # gloo: host tensors only
+    per_rank = [elapsed]
     if group:
+        el = torch.tensor([elapsed], device='cpu' if rehearsal else device, dtype=torch.float64)   # gloo: host tensors only
+        gathered = [torch.zeros_like(el) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, el)
+        per_rank = [float(g) for g in gathered]
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el)
+        elapsed = float(el)
     final_loss = float(loss)
     _lib.raise_on_device_status(device)      # a kernel-side failure (lost stream-K partner) must not yield a bench line
+    ddp = tr.net is not tr.model                                      # DistributedDataParallel around the model
+    del tr, x, t, loss
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
 
+    key = (cfg['model'], cfg['R'])
+    value = cfg['batch'] * world * args.steps / elapsed
+    roofline = None
+    if survey:
+        dom_name = dominant
+        iso = next(e for e in survey if e['kernel'] == dom_name)
+        timed = next((e for e in prof if e['kernel'] == dom_name), None)
+        timed_ms = timed['total_ms'] / timed['launches'] if timed else None
+        # overlapped run: the kernel's own rate comes from the survey steps (one stream); else from the timed region
+        src = iso if (overlapped or not timed) else timed
+        per_launch_ms = src['total_ms'] / src['launches']
+        achieved = src['total_flops'] / (src['total_ms'] * 1e-3) / 1e12
+        traffic, traffic_source = committed_traffic(dom_name)
+        mfma_ms = sum(e['total_ms'] for e in survey)
+        roofline = {
+            'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+            'kernel': dom_name, 'launches_per_step': iso['launches'] / n_survey,
+            'avg_launch_us': round(per_launch_ms * 1e3, 2),
+            'measured': ('one stream: HIP events around the %d launches of this kernel in the %d survey steps, which run the weight '
+                         'gradients on the main stream.  In the timed region the weight gradients run on a second stream beside the '
+                         'other launches and no launch carries events; avg_launch_us_overlapped is what this kernel\'s launches take '
+                         'there (2 extra untimed steps): a launch sharing the chip is not a roofline quantity, the step-level '
+                         'figures below are' % (iso['launches'], n_survey)) if overlapped
+                        else 'HIP events around every launch of this kernel in the timed region',
+            'avg_launch_us_overlapped': round(timed_ms * 1e3, 2) if (overlapped and timed) else None,
+            'weight_gradients_on_second_stream': overlapped,
+            'algorithmic_gflop_per_launch': round(iso['total_flops'] / iso['launches'] / 1e9, 3),
+            # per-kernel figures count the FLOPs a launch executes (= algorithmic for ordinary convolutions; the composite
+            # upsample+conv launches of the decoder execute 0.68 x / 0.25 x of the operators they replace), so frac <= 1
+            'flops_counted': 'executed',
+            # the other MFMA kernels: from the survey steps (events around every launch)
+            'all_mfma_kernels': [{'kernel': e['kernel'], 'launches_per_step': e['launches'] / n_survey,
+                                  'avg_launch_us': round(e['total_ms'] / e['launches'] * 1e3, 2),
+                                  'tflops': round(e['total_flops'] / (e['total_ms'] * 1e-3) / 1e12, 2)} for e in survey],
+            'mfma_kernels_ms_per_step': round(mfma_ms / n_survey, 3),
+            'step_tflops': round(value * TRAIN_GFLOP_PER_MESH[key] / 1e3, 2),
+            'step_frac_of_mfma_peak': round(value * TRAIN_GFLOP_PER_MESH[key] / 1e3 / PEAK_FP32_MFMA_TFLOPS / world, 4),
+            # step_tflops is ALGORITHMIC (3 x forward conv FLOPs of the reference's operator graph);
+            # the MFMA launches of this implementation execute fewer (composite decoder blocks):
+            'step_executed_tflops': round(sum(e['total_flops'] for e in survey) / n_survey / (elapsed / args.steps) / 1e12, 2),
+            'step_executed_gflop': round(sum(e['total_flops'] for e in survey) / n_survey / 1e9, 1),
+            # the HBM side of the same step (SURVEY 8d asks for both fractions; the binding one is MFMA)
+            'achieved_hbm': round(value * TRAIN_MB_PER_MESH[key] / 1e3 / world, 1),
+            'peak_hbm': PEAK_HBM_GBPS, 'unit_hbm': 'GB/s',
+            'frac_hbm': round(value * TRAIN_MB_PER_MESH[key] / 1e3 / world / PEAK_HBM_GBPS, 4),
+        }
+    return {'value': round(value, 2), 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'final_loss': final_loss,
+            'roofline': roofline, 'ddp': ddp,
+            'rank_ms_per_step': {'min': round(min(per_rank) / args.steps * 1e3, 3), 'max': round(max(per_rank) / args.steps * 1e3, 3)}}
+
+
+def committed_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the latest committed PMC passes (tools/profile_round.sh: separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this same command, FETCH doubled per the gfx950 note) -- but only when that profile was taken on THESE
+    kernel sources: tools/profile_summary.py records the sha256 of geniconet_amd/csrc/ in the summary, and a summary of other
+    sources yields traffic = None with the reason (a kernel change without a re-profile must not report stale bytes)."""
+    import glob
+    from geniconet_amd import _lib
+    try:
+        latest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel.json')))[-1]
+        summary = json.load(open(latest))
+    except (IndexError, OSError, ValueError):
+        return None, 'no committed profiles/r*_pmc_per_kernel.json'
+    rel = os.path.relpath(latest, ROOT)
+    have, want = summary.get('_kernel_sources_sha256'), _lib.source_sha256()
+    if have != want:
+        return None, ('not reported: %s was measured on kernel sources %s, this tree has %s -- re-run tools/profile_round.sh'
+                      % (rel, (have or 'unrecorded')[:16], want[:16]))
+    traffic = summary.get('icn::' + kernel, {}).get('hbm_bytes_per_launch')
+    if traffic is None:
+        return None, 'kernel not in ' + rel
+    return traffic, ('not measured by this run: looked up in the committed ' + rel + ' (separate rocprofv3 --pmc FETCH_SIZE / '
+                     'WRITE_SIZE passes of this command on kernel sources ' + want[:16] + ')')
+
+
+def run(args):
+    import torch
+    import torch.distributed as dist
+    from geniconet_amd import _lib
+    from geniconet_amd import train as icn_train
+    cfg = CONFIGS[args.config]
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d in the environment (start it as `python bench.py --gpus N` with no '
+                         'WORLD_SIZE set, or with torch.distributed.run --nproc-per-node N)' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py: no GPU visible; the HIP path has no CPU fallback')
+    # Rehearsal switch for a 1-GPU box (never set by the driver): all ranks share device 0 and talk over gloo, which
+    # exercises the same DDP wiring (bucketing, hooks on the custom autograd ops) without RCCL.
+    rehearsal = os.environ.get('ICN_BENCH_REHEARSAL', '') == '1'
+    visible = torch.cuda.device_count()
+    if rehearsal:
+        local = 0
+        if world > 6:
+            raise SystemExit('bench.py: the one-GPU rehearsal is limited to 6 ranks (process cap of a GPU box)')
+        faulthandler.dump_traceback_later(int(os.environ.get('ICN_BENCH_WATCHDOG', 300)), exit=True)
+    elif local >= visible:
+        raise SystemExit('bench.py: rank %d wants GPU %d but only %d device(s) are visible' % (rank, local, visible))
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    # ICN_FORCE_DDP=1 at N = 1 (never set by the driver): the production communication path on a one-GPU box -- an RCCL process
+    # group of one rank, DistributedDataParallel around the model exactly as for N > 1, device barriers.  Everything N ranks
+    # would run except the wire.
+    forced = world == 1 and icn_train.force_ddp_requested() and not rehearsal
+    if forced:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group('nccl', device_id=device, rank=0, world_size=1)
+    group = world > 1 or forced
+    if world > 1:
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)      # RCCL over xGMI
+    _lib.lib()
+    ctx = dict(device=device, rank=rank, world=world, group=group, rehearsal=rehearsal, local=local)
+    head = measure(cfg, args, ctx, headline=True)
+
+    out = None
     if rank == 0:
-        meshes = cfg['batch'] * world * args.steps
-        value = meshes / elapsed
-        roofline = None
-        if prof:
-            dom = max(prof, key=lambda e: e['total_ms'])
-            # HBM bytes per launch of that kernel from the latest committed PMC passes (tools/profile_round.sh:
-            # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH doubled per the gfx950 note)
-            traffic, traffic_source = None, None
-            try:
-                import glob
-                latest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel.json')))[-1]
-                traffic = json.load(open(latest)).get('icn::' + dom['kernel'], {}).get('hbm_bytes_per_launch')
-                if traffic is not None:
-                    traffic_source = ('not measured by this run: looked up in the committed ' + os.path.relpath(latest, ROOT)
-                                      + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)')
-            except (IndexError, OSError, ValueError):
-                pass
-            timed_ms = dom['total_ms'] / dom['launches']
-            timed_tf = dom['total_flops'] / (dom['total_ms'] * 1e-3) / 1e12
-            iso = next(e for e in survey if e['kernel'] == dom['kernel'])
-            # overlapped run: the kernel's own rate comes from the survey steps (one stream); else from the timed region
-            per_launch_ms = iso['total_ms'] / iso['launches'] if overlapped else timed_ms
-            achieved = iso['total_flops'] / (iso['total_ms'] * 1e-3) / 1e12 if overlapped else timed_tf
-            mfma_ms = sum(e['total_ms'] for e in survey)
-            roofline = {
-                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
-                'kernel': dom['kernel'], 'launches_per_step': iso['launches'] / n_survey,
-                'avg_launch_us': round(per_launch_ms * 1e3, 2),
-                'measured': ('one stream: HIP events around the %d launches of this kernel in the %d survey steps, which run the weight '
-                             'gradients on the main stream.  In the timed region the weight gradients run on a second stream beside the '
-                             'other launches and no launch carries events; avg_launch_us_overlapped is what this kernel\'s launches take '
-                             'there (2 extra untimed steps): a launch sharing the chip is not a roofline quantity, the step-level '
-                             'figures below are' % (iso['launches'], n_survey)) if overlapped
-                            else 'HIP events around every launch of this kernel in the timed region',
-                'avg_launch_us_overlapped': round(timed_ms * 1e3, 2) if overlapped else None,
-                'weight_gradients_on_second_stream': overlapped,
-                'algorithmic_gflop_per_launch': round(dom['total_flops'] / dom['launches'] / 1e9, 3),
-                # per-kernel figures count the FLOPs a launch executes (= algorithmic for ordinary convolutions; the composite
-                # upsample+conv launches of the decoder execute 0.68 x / 0.25 x of the operators they replace), so frac <= 1
-                'flops_counted': 'executed',
-                # the other MFMA kernels: from the survey steps (events around every launch)
-                'all_mfma_kernels': [{'kernel': e['kernel'], 'launches_per_step': e['launches'] / n_survey,
-                                      'avg_launch_us': round(e['total_ms'] / e['launches'] * 1e3, 2),
-                                      'tflops': round(e['total_flops'] / (e['total_ms'] * 1e-3) / 1e12, 2)} for e in survey],
-                'mfma_kernels_ms_per_step': round(mfma_ms / n_survey, 3),
-                'step_tflops': round(value * TRAIN_GFLOP_PER_MESH[(cfg['model'], cfg['R'])] / 1e3, 2),
-                'step_frac_of_mfma_peak': round(value * TRAIN_GFLOP_PER_MESH[(cfg['model'], cfg['R'])] / 1e3
-                                                / PEAK_FP32_MFMA_TFLOPS / world, 4),
-                # step_tflops is ALGORITHMIC (3 x forward conv FLOPs of the reference's operator graph);
-                # the MFMA launches of this implementation execute fewer (composite decoder blocks):
-                'step_executed_tflops': round(sum(e['total_flops'] for e in survey) / n_survey / (elapsed / args.steps) / 1e12, 2),
-                'step_executed_gflop': round(sum(e['total_flops'] for e in survey) / n_survey / 1e9, 1),
-                # the HBM side of the same step (SURVEY 8d asks for both fractions; the binding one is MFMA)
-                'achieved_hbm': round(value * TRAIN_MB_PER_MESH[(cfg['model'], cfg['R'])] / 1e3 / world, 1),
-                'peak_hbm': PEAK_HBM_GBPS, 'unit_hbm': 'GB/s',
-                'frac_hbm': round(value * TRAIN_MB_PER_MESH[(cfg['model'], cfg['R'])] / 1e3 / world / PEAK_HBM_GBPS, 4),
-            }
         out = {
             'metric': 'meshes/sec training throughput, ico2ico I5 batch=36' if args.config == 'ae'
                       else 'meshes/sec training throughput, %s' % cfg['workload'],
-            'value': round(value, 2), 'unit': 'meshes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'value': head['value'], 'unit': 'meshes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'per_gpu_batch': cfg['batch'], 'global_batch': cfg['batch'] * world,
                        'subdivisions': cfg['R'], 'parallelism': 'dp%d' % world + (' (DDP over RCCL forced at world size 1)' if forced else ''),
-                       'final_loss': final_loss},
-            'roofline': roofline,
+                       'final_loss': head['final_loss']},
+            'roofline': head['roofline'],
+            # what the ranks saw (lets a reader verify that N ranks really met over the backend named)
+            'distributed': {'n_ranks_seen': dist.get_world_size() if group else 1,
+                            'backend': dist.get_backend() if group else None,
+                            'visible_devices': visible, 'ddp': head['ddp'],
+                            'bucket_mb': icn_train.GRAD_BUCKET_MB if head['ddp'] else None,
+                            'rank_ms_per_step': head['rank_ms_per_step'],
+                            'launcher': os.environ.get('ICN_BENCH_LAUNCHER') or ('torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ
+                                                                                  else 'none')},
         }
+    # BASELINE configs 4 and 5 behind the headline, same process, same --steps / --warmup (N = 1; the scaling runs stay short)
+    if world == 1 and not forced and args.config == 'ae' and not args.no_also:
+        also = []
+        for name in ('vae', 'i6'):
+            c = CONFIGS[name]
+            m = measure(c, args, ctx, headline=False)
+            r = m['roofline'] or {}
+            also.append({'workload': c['workload'], 'value': m['value'], 'unit': 'meshes/s', 'ms_per_step': m['ms_per_step'],
+                         'roofline': {'kernel': r.get('kernel'), 'frac': r.get('frac'), 'achieved': r.get('achieved'),
+                                      'avg_launch_us': r.get('avg_launch_us')},
+                         'step_executed_tflops': r.get('step_executed_tflops'), 'step_tflops': r.get('step_tflops'),
+                         'final_loss': m['final_loss']})
+        out['also'] = also
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if group:
         dist.destroy_process_group()
+
+
+def main():
+    faulthandler.enable()      # a native crash leaves every rank's Python stack on stderr
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='ae')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
+    ap.add_argument('--no-also', action='store_true', help='skip the vae / i6 configurations behind the headline (N = 1)')
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    run(args)
 
 
 if __name__ == '__main__':

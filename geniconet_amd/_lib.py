@@ -115,6 +115,20 @@ def lib():
     return _lib
 
 
+def source_sha256():
+    """sha256 over the kernel / library sources under csrc/ and include/icn.h (names + contents, sorted): identifies the code a
+    profile was measured on (tools/profile_summary.py stores it, bench.py refuses a profile of other sources)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.hip')) + glob.glob(os.path.join(_HERE, 'csrc', '*.h'))
+                   + glob.glob(os.path.join(_HERE, 'csrc', '*.cpp')) + [os.path.join(os.path.dirname(_HERE), 'include', 'icn.h')])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b'\0')
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError('%s failed: %s' % (what, lib().icn_last_error().decode()))

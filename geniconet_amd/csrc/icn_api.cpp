@@ -209,6 +209,21 @@ std::map<std::tuple<int, int, int>, UpconvBwdDev> g_upconv_bwd;
 std::map<std::tuple<int, int, int, int>, ConvTables> g_conv;   // (device, r, stride, mode)
 std::map<std::tuple<int, int, int>, UpTables> g_up;            // (device, r, mode)
 
+// Union rows per 16-pixel stage of k_wgrad7: 64 at stride 1 (ICN_W7_U=56 selects the 38 KB two-stage form for A/B
+// runs), 112 at stride 2.  ONE definition for the table the kernel is launched with (make_conv_tables) and the table the tests and
+// the host selfcheck look at (icn_table_wgrad7); a value launch_wgrad has no instantiation for is an error, not a silent fall
+// back to the per-tap kernel.
+static int wgrad7_union_rows(int stride) {
+    if (stride != 1) return 112;
+    static const int u1 = [] {
+        const char* e = getenv("ICN_W7_U");
+        return e ? atoi(e) : 64;
+    }();
+    if (u1 != 56 && u1 != 64)
+        throw std::invalid_argument("icn: ICN_W7_U must be 56 or 64 (the instantiations of k_wgrad7 at stride 1), got " + std::to_string(u1));
+    return u1;
+}
+
 ConvTables make_conv_tables(int r_in, int stride, int mode) {
     ConvTables t;
     t.n_in = 1 << r_in;
@@ -227,8 +242,7 @@ ConvTables make_conv_tables(int r_in, int stride, int mode) {
         icn::DmaTable h;
         icn::build_dma_table(fwd, 1, t.Pout, h);
         icn::Wg7Table w7;
-        static const int u1 = getenv("ICN_W7_U") ? atoi(getenv("ICN_W7_U")) : 64;       // developer A/B: 56 = the 2-stage, 38 KB form
-        if (icn::build_wgrad7(h, t.Pout, stride == 1 ? u1 : 112, w7)) {
+        if (icn::build_wgrad7(h, t.Pout, wgrad7_union_rows(stride), w7)) {
             t.w7_rows = upload(w7.urow);
             t.w7_pos = upload(w7.upos);
             t.w7_U = w7.U;
@@ -1508,7 +1522,7 @@ long icn_table_wgrad7(int r_in, int stride, int corner_mode, int32_t* rows, size
         icn::DmaTable h;
         icn::build_dma_table(fwd, 1, P, h);
         icn::Wg7Table w7;
-        if (!icn::build_wgrad7(h, P, stride == 1 ? 64 : 112, w7)) {
+        if (!icn::build_wgrad7(h, P, wgrad7_union_rows(stride), w7)) {      // the very table make_conv_tables uploads
             if (meta) meta[0] = meta[1] = 0;
             return 0;
         }

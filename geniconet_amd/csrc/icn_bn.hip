@@ -31,6 +31,9 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f),
 #define ICN_BN_MAX_CHUNKS 512
 #endif
 constexpr int BN_MAX_CHUNKS = ICN_BN_MAX_CHUNKS;
+// (the finalize kernels walk the chunks 16 at a time -- chunk_sums: slice = threadIdx.x / 16 -- and any count works; the workspace
+//  is sized by bn_chunks(), which is capped by this constant, so it only has to be positive)
+static_assert(BN_MAX_CHUNKS >= 1 && BN_MAX_CHUNKS <= 65536, "ICN_BN_MAX_CHUNKS");
 
 // Sums of the BatchNorm passes are accumulated in DOUBLE from the first add (round 3), as the CPU reference does (torch's
 // acc_type<float> on the CPU is double; its device kernels sum in fp32).  A batch statistic enters every element of its channel,
@@ -71,6 +74,7 @@ __device__ __forceinline__ f32x4 bn_pre4(f32x4 a, f32x4 mean_a, f32x4 scale_a, f
 #ifndef ICN_BN_WAVES
 #define ICN_BN_WAVES 1
 #endif
+static_assert(ICN_BN_WAVES >= 1 && ICN_BN_WAVES <= 8, "ICN_BN_WAVES: minimum workgroups per CU of k_bn_partial's launch bounds");
 template <int MODE>
 __global__ __launch_bounds__(256, ICN_BN_WAVES) void k_bn_partial(const float* __restrict__ p0, const float* __restrict__ p2,
                                                      const float* __restrict__ p3, const float* __restrict__ stat_a,
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(256, ICN_BN_WAVES) void k_bn_partial(const float* _
     // 8.236 against 8.288 ms per step overlapped; alone on the chip the 2-row form is the slower one (8.606 against 8.559 with
     // every pass on 2 rows), which is why the forward modes, which never have company, keep 4.
     constexpr int UN = (MODE == 1 || MODE == 2) ? ICN_BN_UN_BWD : ICN_BN_UN;
+    static_assert(UN == 1 || UN == 2 || UN == 4, "ICN_BN_UN / ICN_BN_UN_BWD: the accumulator combine below is written for 1, 2 or 4 rows per iteration");
     f64x4 s[UN][NS];
 #pragma unroll
     for (int u = 0; u < UN; ++u)
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double* __restric
 #define ICN_BN_APPLY_UNR 1
 #endif
 constexpr int APPLY_UNR = ICN_BN_APPLY_UNR;
+static_assert(APPLY_UNR >= 1 && APPLY_UNR <= 8, "ICN_BN_APPLY_UNR: elements per thread and iteration of the apply passes");
 
 template <int DUAL>
 __global__ void k_bn_relu_fwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ stat_a,

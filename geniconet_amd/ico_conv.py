@@ -57,8 +57,12 @@ if _wgrad_mode[0] not in _MODES:
     raise ValueError('ICN_WGRAD_STREAM must be one of %s' % (_MODES,))
 _side_streams = {}
 _pending = [False]                                  # something went to the side stream since the current stream last waited for it
-_seen = {}                                          # id(parameter) -> one of its gradients of THIS backward pass is on the side stream
-_callback_queued = [False]                          # the end-of-pass callback has been queued for this backward pass
+# Per-pass bookkeeping is keyed on the PASS (the autograd engine's graph-task id), never on a global flag: a pass that ends in an
+# exception runs no end-of-pass callback, and whatever it leaves behind must not be mistaken for the next pass's state.
+_seen = {}                                          # id(parameter) -> (pass id, one of its gradients of that pass is on the side stream)
+_queued = set()                                     # passes whose end-of-pass callback has been queued
+_known = set()                                      # passes seen (and not yet over): the bucket countdown is armed at a pass's first event
+_last_pass = [None]                                 # the pass the previous event belonged to
 _buckets = {'of': {}, 'size': {}, 'left': {}}       # id(param) -> bucket key; bucket key -> parameters in it / still to come
 wgrad_stream_counts = {'side': 0, 'joins': 0, 'kept': 0}   # launches put on the side stream / waits issued / launches kept on
                                                           # the current stream because a reader could not wait (tests, diagnostics)
@@ -74,8 +78,7 @@ def set_weight_gradient_stream(mode, bucket_of=None):
     # here, so that the next pass starts with a joined side stream and empty per-pass bookkeeping.
     if _pending[0]:
         _join_now()
-    _seen.clear()
-    _callback_queued[0] = False
+    _forget_passes()
     if mode == 'bucketed':
         if not bucket_of:
             raise ValueError("mode 'bucketed' needs the parameter -> bucket map")
@@ -91,6 +94,41 @@ def set_weight_gradient_stream(mode, bucket_of=None):
     return prev
 
 
+def _current_pass():
+    """Id of the backward pass the engine is running on this thread (-1 outside one)."""
+    return torch._C._current_graph_task_id()
+
+
+def _forget_passes():
+    _seen.clear()
+    _queued.clear()
+    _known.clear()
+    _last_pass[0] = None
+
+
+def _enter_pass():
+    """Called by everything that acts inside a backward pass; returns the pass id.  An event of another pass than the previous
+    event's is a pass boundary nobody announced: either the previous pass ended in an exception (OOM, KeyboardInterrupt; its
+    end-of-pass callback never ran, the side stream may be un-joined) or passes are nested.  Either way the current stream waits
+    for whatever is still on the side stream -- after that every earlier gradient is complete and only this pass's own launches
+    need the bookkeeping, which is looked up by pass id, so a stale pass's entries are simply never matched.  The bucket
+    countdown is (re)armed at a pass's first event."""
+    tid = _current_pass()
+    if tid != _last_pass[0]:
+        if _pending[0]:
+            _join_now()
+        _last_pass[0] = tid
+    if tid not in _known:
+        if len(_known) > 16 or len(_seen) > 8192:      # leftovers of passes that raised: ids and ints only, drop them
+            keep = {k: v for k, v in _seen.items() if v[0] == tid}
+            _forget_passes()
+            _seen.update(keep)
+            _last_pass[0] = tid
+        _known.add(tid)
+        _buckets['left'] = dict(_buckets['size'])
+    return tid
+
+
 def _join_now():
     for dev_index, side in _side_streams.items():
         torch.cuda.current_stream(dev_index).wait_stream(side)
@@ -98,14 +136,25 @@ def _join_now():
     wgrad_stream_counts['joins'] += 1
 
 
-def _backward_pass_over():
-    """Autograd-engine callback at the end of a backward pass (queued by the pass's first weight-gradient launch in a
-    side-stream mode): the current stream waits for the side stream, the per-pass bookkeeping is forgotten."""
+def _backward_pass_over(tid=None):
+    """Autograd-engine callback at the end of backward pass `tid` (queued by the pass's first weight-gradient launch in a
+    side-stream mode): the current stream waits for the side stream, the pass's bookkeeping is forgotten."""
     if _pending[0]:
         _join_now()
-    _seen.clear()
-    _callback_queued[0] = False
+    if tid is None:
+        _forget_passes()
+    else:
+        for k in [k for k, v in _seen.items() if v[0] == tid]:
+            del _seen[k]
+        _queued.discard(tid)
+        _known.discard(tid)
+        if _last_pass[0] == tid:
+            _last_pass[0] = None
     _buckets['left'] = dict(_buckets['size'])
+
+
+def _queue_end_of_pass(tid):
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: _backward_pass_over(tid))
 
 
 def parameter_gradient_ready(param):
@@ -113,6 +162,7 @@ def parameter_gradient_ready(param):
     accumulated, after which the reducer may launch the all-reduce of the parameter's bucket."""
     if _wgrad_mode[0] != 'bucketed':
         return
+    _enter_pass()
     pending = _pending[0]                                        # something is on the side stream that nobody has waited for
     k = _buckets['of'].get(id(param))
     if k is None:                                                # not in the map: take no chances
@@ -135,7 +185,7 @@ def _readers_can_wait(q, g):
         countdown hooks are the ones registered);
       * 'bucketed': `g` is not the parameter's bucket view (the lease fell back to a new tensor), so the reducer copies it
         into the bucket -- on the current stream, and only the bucket's LAST gradient is preceded by a join."""
-    if not isinstance(q, torch.Tensor) or not q.is_leaf or q.grad is not None or id(q) in _seen:
+    if not isinstance(q, torch.Tensor) or not q.is_leaf or q.grad is not None or _seen.get(id(q), (None,))[0] == _current_pass():
         return False
     if _wgrad_mode[0] == 'bucketed':
         return _gradbuf.served_from_view(q, g)
@@ -152,15 +202,17 @@ def _wgrad_stream(dev, dests, *tensors, allow=True):
     must still come through here."""
     if _wgrad_mode[0] == 'off':
         return None
+    tid = _enter_pass()
     dests = [(q, g) for q, g in dests if g is not None]
     ok = allow and (_wgrad_mode[0] == 'eager' or (all(_readers_can_wait(q, g) for q, g in dests)
                                                   and len({id(q) for q, _ in dests}) == len(dests)))   # (one tensor as both weights)
-    if _wgrad_mode[0] != 'eager' and not _callback_queued[0]:
-        torch.autograd.Variable._execution_engine.queue_callback(_backward_pass_over)     # once per pass: join + forget `_seen`
-        _callback_queued[0] = True
-    again = any(_seen.get(id(q), False) for q, _ in dests)
+    if _wgrad_mode[0] != 'eager' and tid not in _queued:
+        _queue_end_of_pass(tid)                                                       # once per pass: join + forget
+        _queued.add(tid)
+    mine = {id(q): _seen[id(q)][1] for q, _ in dests if _seen.get(id(q), (None,))[0] == tid}   # earlier gradients of THIS pass
+    again = any(mine.values())
     for q, _ in dests:
-        _seen[id(q)] = _seen.get(id(q), False) or ok
+        _seen[id(q)] = (tid, mine.get(id(q), False) or ok)
     if not ok:
         if again and _pending[0]:
             _join_now()

@@ -257,9 +257,18 @@ def save_checkpoint(trainer, log_dir, epoch, val_loss=None, misc=None, model_nam
     if os.path.exists(path):
         return None
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    torch.save({'model_state_dict': trainer.model.state_dict(), 'optimizer_state_dict': trainer.optimizer.state_dict(),
-                'epoch': epoch if isinstance(epoch, int) else int(str(epoch)[1:]), 'loss': val_loss, 'misc': misc}, path)
-    trainer.check_status()                    # (the tensors were just copied to the host: everything before is complete)
+    # Check BEFORE anything reaches the disk: a kernel-side failure (a lost stream-K partner turns its tile into NaNs)
+    # must raise here, not after a poisoned file has been written that a later --resume would load.  And the file appears under
+    # its name only when it is complete.
+    trainer.check_status(synchronize=True)
+    tmp = path + '.tmp%d' % os.getpid()
+    try:
+        torch.save({'model_state_dict': trainer.model.state_dict(), 'optimizer_state_dict': trainer.optimizer.state_dict(),
+                    'epoch': epoch if isinstance(epoch, int) else int(str(epoch)[1:]), 'loss': val_loss, 'misc': misc}, tmp)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return path
 
 

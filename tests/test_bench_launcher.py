@@ -1,0 +1,40 @@
+"""bench.py's own launcher (`python bench.py --gpus N` with no WORLD_SIZE in the environment): host-side behaviour that needs no
+GPU.  The N-rank run itself is tests/test_gpu_dp_rehearsal.py::test_bench_self_launch_rehearsal (one-GPU box, gloo)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['PYTHONPATH'] = ROOT
+    return env
+
+
+def test_the_launcher_path_never_imports_torch():
+    """The parent of a self-launched run must not be able to initialise the GPU: importing bench.py pulls in neither torch
+    nor the package (children are fresh interpreters, never re-execs of a process that touched HIP)."""
+    code = "import sys, bench; assert 'torch' not in sys.modules and 'geniconet_amd' not in sys.modules, sorted(sys.modules)"
+    subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=_env(), check=True, timeout=120)
+
+
+def test_a_failing_rank_fails_the_launcher():
+    """No GPU in this container: every rank exits with 'no GPU visible'; the launcher must forward a non-zero code (and not
+    print a bench line).  With a GPU present this test has nothing to show and passes trivially on rc == 0."""
+    import torch
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                        '--no-cpu-baseline'], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    if torch.cuda.is_available():
+        return
+    assert r.returncode != 0
+    assert 'no GPU visible' in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+def test_a_world_size_mismatch_is_refused():
+    env = dict(_env(), WORLD_SIZE='3', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=3' in r.stderr

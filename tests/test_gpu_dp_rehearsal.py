@@ -82,3 +82,28 @@ def test_two_ranks_on_one_gpu_average_gradients_through_the_hip_operators(tmp_pa
             continue                                      # BatchNorm statistics are per rank by design
         assert torch.equal(a['w_end'][k], b['w_end'][k]), k
     assert all(abs(v) < 1e9 for v in a['losses'] + b['losses'])
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launch_rehearsal():
+    """`python3 bench.py --gpus 2` with NO WORLD_SIZE in the environment -- the form the driver uses for N = 1 -- must start its two
+    ranks itself (fresh interpreters; the launcher never touches the GPU), meet over the backend, and print ONE JSON line that
+    says how many ranks met.  On this one-GPU box the ranks share cuda:0 over gloo (ICN_BENCH_REHEARSAL=1); on an 8-GPU node the
+    same entry runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(ICN_BENCH_REHEARSAL='1', PYTHONFAULTHANDLER='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['value'] > 0 and out['scaling'] == 'weak'
+    d = out['distributed']
+    assert d['n_ranks_seen'] == 2 and d['backend'] == 'gloo' and d['launcher'] == 'self' and d['ddp'] is True
+    assert d['bucket_mb'] > 0 and d['visible_devices'] >= 1
+    assert 0 < d['rank_ms_per_step']['min'] <= d['rank_ms_per_step']['max'] <= out['ms_per_step'] + 1e-3
+    assert out['config']['global_batch'] == 72 and 'cpu_baseline' not in out and 'also' not in out
+    assert out['roofline'] is not None and out['roofline']['kernel'].startswith('k_')

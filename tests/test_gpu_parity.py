@@ -426,6 +426,33 @@ def test_a_lost_stream_k_partner_is_loud():
     assert torch.equal(y_again, y_ok) and _lib.device_status() == 0
 
 
+def test_no_checkpoint_is_written_after_a_kernel_reported_a_failure(tmp_path):
+    """save_checkpoint checks the device status BEFORE it writes.  A lost stream-K partner (injected as above, the
+    launch still in flight when save_checkpoint is called) raises and leaves NO file that a later --resume could load (run.py:342-372
+    picks the newest file of the directory); after the failure has been reported the same call writes normally."""
+    import os
+    from geniconet_amd import _lib, models
+    from geniconet_amd.ico_conv import ico_conv
+    from geniconet_amd.train import Trainer, save_checkpoint
+    p = models.default_params('ico2ico', subdivisions=2)
+    tr = Trainer(p, 'cuda', seed=0)
+    r, cin, cout, B = SK_CASES[0][:4]
+    n = 2 ** r
+    x = torch.randn(B, cin, 5 * n, 2 * n, device='cuda')
+    w = torch.randn(cout, cin, 7, device='cuda') / (7 * cin) ** 0.5
+    old = _lib.lib().icn_set_debug_flags(256)
+    try:
+        ico_conv(x, w, None, r, 1, 'average')                 # not synchronised: save_checkpoint has to do that itself
+    finally:
+        _lib.lib().icn_set_debug_flags(old)
+    with pytest.raises(RuntimeError, match='stream-K'):
+        save_checkpoint(tr, str(tmp_path), 1, val_loss=0.0)
+    saved = os.path.join(str(tmp_path), 'savedModel')
+    assert not os.path.isdir(saved) or os.listdir(saved) == []
+    path = save_checkpoint(tr, str(tmp_path), 1, val_loss=0.0)
+    assert path and os.listdir(saved) == [os.path.basename(path)]
+
+
 def test_conv_without_bias_and_noncontiguous_input():
     from geniconet_amd.ico_conv import ico_conv
     for k, (got, want) in conv_both(2, 1, 64, 64, 2, 'average', seed=5, bias=False).items():

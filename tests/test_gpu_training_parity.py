@@ -449,17 +449,11 @@ def test_second_stream_guards_readers_it_cannot_see():
     assert all(torch.equal(a, b) for a, b in zip(res['off'][:3], res['deferred'][:3]))
 
 
-def test_a_lagging_side_stream_is_waited_for(monkeypatch):
-    """A race detector for the second stream: every weight-gradient launch that goes to the side stream is preceded there by a
-    ~1 ms spin kernel, so the side stream lags the backward chain by tens of milliseconds and ANY reader that does not wait
-    for it -- the optimiser after a missing end-of-pass join, AccumulateGrad on an existing .grad, the engine adding the two
-    gradients of a shared weight -- reads memory the weight gradient has not written yet.  With the joins and the
-    per-launch guard in place the results stay bit-identical to one stream: three trainer steps, a gradient-accumulation
-    pass, a module applied twice."""
+def lagging_side_stream(monkeypatch):
+    """The race detector: every weight-gradient launch that goes to the side stream is preceded THERE by a ~1 ms spin kernel, so
+    the side stream lags the backward chain by tens of milliseconds and any reader that does not wait for it reads memory the
+    weight gradient has not written yet.  Returns the counter of injected lags ({'n': ...})."""
     import importlib
-    from geniconet_amd import data, models
-    from geniconet_amd.ico_conv import IcoConvS2S, set_weight_gradient_stream
-    from geniconet_amd.train import Trainer, build_criterion
     ico_conv = importlib.import_module('geniconet_amd.ico_conv')        # (the package attribute of that name is the function)
     real = ico_conv._wgrad_stream
     lag = {'n': 0}
@@ -472,6 +466,64 @@ def test_a_lagging_side_stream_is_waited_for(monkeypatch):
             lag['n'] += 1
         return side
     monkeypatch.setattr(ico_conv, '_wgrad_stream', lagging)
+    return lag
+
+
+def test_a_backward_pass_that_raises_does_not_leave_the_next_one_unjoined(monkeypatch):
+    """the mode set globally ('deferred', as ICN_WGRAD_STREAM=deferred does -- no Trainer, no try / finally around
+    backward()), a backward pass that raises half-way (a tensor hook on an encoder activation), and then an ordinary pass with a
+    LAGGING side stream followed by a read of the gradients on the current stream, which is what optimizer.step() does.  The
+    aborted pass left weight gradients in flight and its end-of-pass callback never ran; the next pass must still join before
+    anybody reads: gradients bit-identical to mode 'off'."""
+    from geniconet_amd import data, models
+    from geniconet_amd.ico_conv import set_weight_gradient_stream, wgrad_stream_counts
+    from geniconet_amd.train import build_criterion
+    R, B = 3, 3
+    p = models.default_params('ico2ico', subdivisions=R)
+    crit = build_criterion(p, 'cuda')
+    x, t = data.synthetic_batch(B, R, seed=91, device='cuda')
+    x = x.contiguous(memory_format=torch.channels_last)
+
+    class Boom(RuntimeError):
+        pass
+
+    def run(mode, lagged):
+        torch.manual_seed(17)
+        net = models.ico2ico(p).cuda().to(memory_format=torch.channels_last).train()
+        prev = set_weight_gradient_stream(mode)               # set once, globally: nobody switches around the passes below
+        try:
+            def boom(g):
+                raise Boom('injected')
+            h = net.enc.register_forward_hook(lambda m, a, o: o.register_hook(boom) and None)
+            with pytest.raises(Boom):                         # the decoder's weight gradients are issued, then the pass dies
+                crit(net(x), t).backward()
+            h.remove()
+            net.zero_grad()
+            before = dict(wgrad_stream_counts)
+            crit(net(x), t).backward()                        # the next pass
+            grads = {k: q.grad.clone() for k, q in net.named_parameters()}      # a read on the current stream, like optimizer.step
+            torch.cuda.synchronize()
+            return grads, {c: wgrad_stream_counts[c] - before[c] for c in before}
+        finally:
+            set_weight_gradient_stream(*prev)
+    want, _ = run('off', False)
+    lag = lagging_side_stream(monkeypatch)
+    got, counts = run('deferred', True)
+    assert lag['n'] >= 8 and counts['side'] >= 5 and counts['joins'] >= 1, (lag, counts)
+    assert [k for k in want if not torch.equal(want[k], got[k])] == []
+
+
+def test_a_lagging_side_stream_is_waited_for(monkeypatch):
+    """A race detector for the second stream: every weight-gradient launch that goes to the side stream is preceded there by a
+    ~1 ms spin kernel, so the side stream lags the backward chain by tens of milliseconds and ANY reader that does not wait
+    for it -- the optimiser after a missing end-of-pass join, AccumulateGrad on an existing .grad, the engine adding the two
+    gradients of a shared weight -- reads memory the weight gradient has not written yet.  With the joins and the
+    per-launch guard in place the results stay bit-identical to one stream: three trainer steps, a gradient-accumulation
+    pass, a module applied twice."""
+    from geniconet_amd import data, models
+    from geniconet_amd.ico_conv import IcoConvS2S, set_weight_gradient_stream
+    from geniconet_amd.train import Trainer, build_criterion
+    lag = lagging_side_stream(monkeypatch)
     dev = torch.device('cuda', 0)
     R, B = 3, 3
     p = models.default_params('ico2ico', subdivisions=R)
@@ -687,11 +739,14 @@ def test_hip_loss_laplacian_conventions(mode):
 
 
 # ---- (e) full-size steps: size-independent checks -------------------------------------------------------------------------------
+@pytest.mark.parametrize('lag', ['plain', 'lagging_side_stream'])
 @pytest.mark.parametrize('cfg', [('ico2ico', 5, 36), ('ico2ico', 6, 8), ('ico2ico_vae', 5, 36)], ids=lambda c: '%s_I%d_b%d' % c)
-def test_full_size_training_step_is_finite_and_deterministic(cfg):
-    """BASELINE configs 1, 3 and 4 at their real sizes: two training steps through Trainer.step give a finite loss, finite
+def test_full_size_training_step_is_finite_and_deterministic(cfg, lag, monkeypatch):
+    """BASELINE configs 2, 4 and 5 at their real sizes: two training steps through Trainer.step give a finite loss, finite
     weights, running statistics inside the data's range, and -- every reduction on the path being fixed-order (wgrad slabs,
-    BatchNorm / loss / head two-level sums, no atomics) -- bit-identical results when repeated from the same state."""
+    BatchNorm / loss / head two-level sums, no atomics) -- bit-identical results when repeated from the same state.
+    'lagging_side_stream': the repetition runs with the race detector on (every side-stream launch behind a ~1 ms spin kernel),
+    so the full-size steps, too, are bit-identical with a second stream that lags the chain by tens of milliseconds."""
     from geniconet_amd import data, models
     from geniconet_amd.train import Trainer
     name, R, B = cfg
@@ -699,12 +754,17 @@ def test_full_size_training_step_is_finite_and_deterministic(cfg):
     x, t = data.synthetic_batch(B, R, seed=1234, device='cuda')
     x = x.contiguous(memory_format=torch.channels_last)
     runs = []
-    for _ in range(2):
+    injected = None
+    for rep in range(2):
+        if rep == 1 and lag == 'lagging_side_stream':
+            injected = lagging_side_stream(monkeypatch)
         tr = Trainer(p, 'cuda', seed=0)
+        assert tr.overlap_weight_gradients
         torch.manual_seed(99)                                         # the VAE's noise
         losses_ = [tr.step(x, t) for _ in range(2)]
         runs.append(([float(v) for v in losses_], {k: v.clone() for k, v in tr.model.state_dict().items()}))
         del tr
+    assert injected is None or injected['n'] >= 20, injected
     (la, sa), (lb, sb) = runs
     assert all(np.isfinite(la)) and la == lb, (la, lb)
     for k, v in sa.items():

@@ -51,3 +51,21 @@ def test_no_table_where_the_output_grid_is_not_made_of_whole_patches():
     assert _lib.table_wgrad7(0, 1, 'average') is None
     assert _lib.table_wgrad7(1, 1, 'average') is None
     assert _lib.table_wgrad7(2, 2, 'average') is None
+
+
+def test_the_union_row_knob_is_one_definition_and_rejects_what_has_no_kernel():
+    """ICN_W7_U (developer A/B knob, read once per process) selects the stride-1 table the kernel is launched with AND
+    the one icn_table_wgrad7 shows; a value k_wgrad7 has no instantiation for is an error, not a silent fall-back."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from geniconet_amd import _lib\n"
+            "t = _lib.table_wgrad7(4, 1, 'average'); print('U', t[0].shape[1], _lib.table_wgrad7(4, 2, 'average')[0].shape[1])\n" % root)
+    for u, want in (('56', 'U 56 112'), ('64', 'U 64 112'), ('48', None), ('112', None)):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, ICN_W7_U=u), capture_output=True, text=True, timeout=300)
+        if want:
+            assert r.returncode == 0 and want in r.stdout, (u, r.stdout, r.stderr[-500:])
+        else:
+            assert r.returncode != 0 and 'ICN_W7_U must be 56 or 64' in r.stderr, (u, r.stderr[-500:])

@@ -96,8 +96,10 @@ def test_a_weight_gradient_stays_on_the_current_stream_when_somebody_could_read_
     q.grad = torch.zeros(4)                                   # accumulation / zero_grad(set_to_none=False)
     assert not ic._readers_can_wait(q, g)
     q.grad = None
-    ic._seen[id(q)] = True                                    # already received a gradient in this pass
+    ic._seen[id(q)] = (ic._current_pass(), True)             # already received a gradient in this pass
     assert not ic._readers_can_wait(q, g)
+    ic._seen[id(q)] = (12345, True)                          # ... in ANOTHER pass (one that raised and left this behind): ignored
+    assert ic._readers_can_wait(q, g)
     ic._seen.clear()
     assert not ic._readers_can_wait(q * 2, g)                 # non-leaf: the gradient flows on
     h = q.register_hook(lambda grad: None)                    # somebody looks at it
@@ -115,17 +117,65 @@ def test_a_weight_gradient_stays_on_the_current_stream_when_somebody_could_read_
     again = _gradbuf.lease(q, (4,), torch.device('cpu'))      # second lease in one pass: a new tensor
     assert not _gradbuf.served_from_view(q, again) and not ic._readers_can_wait(q, again)
     ic._backward_pass_over()
-    assert ic._seen == {} and not ic._callback_queued[0]
+    assert ic._seen == {} and not ic._queued and not ic._known
 
 
 def test_a_mode_switch_settles_what_an_aborted_pass_left_behind(recorder):
     """A backward pass that raised never runs the engine's end-of-pass callback: the side stream would stay un-joined, the
-    callback flag set and the per-pass parameter set stale.  set_weight_gradient_stream (called by the Trainer around every
-    backward) joins and clears."""
+    callback marked as queued and the per-pass parameter set stale.  set_weight_gradient_stream (called by the Trainer around
+    every backward) joins and clears."""
     ic.set_weight_gradient_stream('deferred')
     q = torch.nn.Parameter(torch.zeros(2))
     ic._pending[0] = True
-    ic._seen[id(q)] = True
-    ic._callback_queued[0] = True
+    ic._seen[id(q)] = (7, True)
+    ic._queued.add(7)
+    ic._known.add(7)
     ic.set_weight_gradient_stream('off')
-    assert recorder == ['join'] and ic._seen == {} and not ic._callback_queued[0] and not ic._pending[0]
+    assert recorder == ['join'] and ic._seen == {} and not ic._queued and not ic._known and not ic._pending[0]
+
+
+class _FakeStream:
+    index = 0
+
+    def wait_stream(self, other):
+        pass
+
+
+class _FakeGrad:
+    def record_stream(self, s):
+        pass
+
+
+def test_an_aborted_pass_without_a_mode_switch_cannot_leave_the_next_pass_unjoined(recorder, monkeypatch):
+    """the mode set once and globally (ICN_WGRAD_STREAM=deferred, or set_weight_gradient_stream without the Trainer's
+    try / finally), and a backward() that raises half-way.  With one global 'callback queued' flag the next pass queued no
+    callback, so nothing joined before optimizer.step().  The bookkeeping is keyed on the engine's pass id instead: the next
+    pass (1) first waits for what the aborted one left on the side stream, (2) ignores its parameter set, (3) queues its own
+    end-of-pass callback, whose join covers its own side launches."""
+    side = _FakeStream()
+    monkeypatch.setattr(ic, '_side_streams', {0: side})
+    monkeypatch.setattr(ic.torch.cuda, 'current_stream', lambda dev=None: _FakeStream())
+    queued = []
+    monkeypatch.setattr(ic, '_queue_end_of_pass', lambda tid: queued.append(tid))
+    now = {'tid': 41}
+    monkeypatch.setattr(ic, '_current_pass', lambda: now['tid'])
+    ic.set_weight_gradient_stream('deferred')
+    dev = torch.device('cuda', 0)
+    a, b = torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2))
+    assert ic._wgrad_stream(dev, [(a, _FakeGrad())]) is side                 # pass 41: a's gradient goes to the side stream ...
+    assert queued == [41] and ic._pending[0] and recorder == []
+    now['tid'] = 42                                                         # ... the pass raises: no callback, nothing joined
+    assert ic._wgrad_stream(dev, [(b, _FakeGrad())]) is side                 # pass 42, first side launch:
+    assert recorder == ['join']                                             # (1) the leftover is waited for first
+    assert queued == [41, 42]                                               # (3) this pass queues its own callback
+    assert ic._wgrad_stream(dev, [(a, _FakeGrad())]) is side                 # (2) a is "unseen" in pass 42 although pass 41 listed it
+    assert ic._wgrad_stream(dev, [(a, _FakeGrad())]) is None                 # ... and its second gradient of THIS pass stays put,
+    assert recorder == ['join', 'join']                                     #     after a wait for the first (still in flight)
+    assert ic._pending[0] is False
+    assert ic._wgrad_stream(dev, [(b, _FakeGrad())], allow=False) is None    # b again, kept by the caller's own choice (nothing in flight)
+    ic._pending[0] = True
+    ic._backward_pass_over(42)                                              # end of pass 42
+    assert recorder == ['join'] * 3 and not ic._pending[0]
+    assert all(v[0] != 42 for v in ic._seen.values()) and 42 not in ic._queued and 42 not in ic._known
+    ic._backward_pass_over(41)                                              # (a late callback of a pass would find nothing to do)
+    assert ic._seen == {} and recorder == ['join'] * 3

@@ -92,6 +92,12 @@ for k, cs in pmc.items():
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in cs and 'GRBM_GUI_ACTIVE' in cs:
         e['mfma_pipe_busy_frac'] = round(cs['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (cs['GRBM_GUI_ACTIVE'] / 8), 4)
     out[k] = e
+# the kernel sources these counters were measured on (bench.py reports roofline.traffic only when the tree it runs from has the
+# same hash: a kernel change without a re-profile must not report stale bytes)
+sys.path.insert(0, root)
+from geniconet_amd import _lib  # noqa: E402
+sha_file = os.path.join(src, 'sources_sha256.txt')         # written on the box by profile_round.sh next to the raw counters
+out['_kernel_sources_sha256'] = open(sha_file).read().strip() if os.path.exists(sha_file) else _lib.source_sha256()
 json.dump(out, open(os.path.join(dst, rnd + '_pmc_per_kernel.json'), 'w'), indent=1, sort_keys=True)
 json.dump(bench, open(os.path.join(dst, rnd + '_bench_under_rocprof.json'), 'w'), indent=1)
 print('stats from', os.path.relpath(stats[0], root))
