@@ -434,7 +434,7 @@ def test_no_checkpoint_is_written_after_a_kernel_reported_a_failure(tmp_path):
     from geniconet_amd import _lib, models
     from geniconet_amd.ico_conv import ico_conv
     from geniconet_amd.train import Trainer, save_checkpoint
-    p = models.default_params('ico2ico', subdivisions=2)
+    p = models.default_params('ico2ico', subdivisions=3)
     tr = Trainer(p, 'cuda', seed=0)
     r, cin, cout, B = SK_CASES[0][:4]
     n = 2 ** r
