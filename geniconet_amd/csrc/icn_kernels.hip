@@ -42,6 +42,19 @@
 #define ICN_CHAIN_SETPRIO() ((void)0)
 #endif
 
+// Pricing switches for the persistent conv GEMM (tools/build_exp.sh, tools/price_conv_features.py; DESIGN 4.1 "what production pays
+// over the ladder").  A build with -DICN_EXP=<bits> leaves one production-only feature of conv_dma_body out at a time; RESULTS ARE
+// THEN WRONG -- only the launch time is read, exactly as profiles/r03_kstep_decomposition.txt did for the K-step.  0 (the default)
+// is the product, and compiles to the same instructions as before the switches existed.
+//   1 no tile epilogue (accumulators are dropped)          2 no per-tile metadata DMA + convert (every tile reuses the first tile's tables)
+//   4 no side-row vote / second resource in the stage issue (also in the weight-gradient kernels)     8 no bias in the epilogue
+//   16 epilogue arithmetic and store instructions kept, every offset out of range (no memory side)   64 / 256 epilogue stores with the
+//   non-temporal (nt) / system-scope write-through (sc0 sc1) cache policy
+#ifndef ICN_EXP
+#define ICN_EXP 0
+#endif
+#define ICN_EXP_STORE_POLICY ((ICN_EXP & 64) ? 2 : (ICN_EXP & 256) ? 17 : 0)
+
 namespace icn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -721,7 +734,7 @@ __device__ __forceinline__ void conv_dma_body(
             bool side_row = false; \
 _Pragma("unroll") \
             for (int i = 0; i < RA; ++i) side_row |= (int)pbase[i] < (int)NOTHING_OFFSET; \
-            if (__builtin_amdgcn_ballot_w64(side_row) == 0) { \
+            if ((ICN_EXP & 4) || __builtin_amdgcn_ballot_w64(side_row) == 0) { \
 _Pragma("unroll") \
                 for (int i = 0; i < RA; ++i) { \
                     float* lds_dst = As + __builtin_amdgcn_readfirstlane(i_ring * BM * BK + 8 * (wave + 4 * i) * BK); \
@@ -842,7 +855,7 @@ _Pragma("unroll") \
         const int S = c_s1 - c_s0;                        // K-steps of this segment (without SK: of the whole tile)
         if (SK && trace && tr_split == 0 && (c_s0 > 0 || c_s1 < sk_S)) tr_split = __builtin_amdgcn_s_memrealtime();
         for (int step = 0; step < S; ++step) {
-            const bool meta = step == 0 && has_next;      // wave-uniform
+            const bool meta = !(ICN_EXP & 2) && step == 0 && has_next;      // wave-uniform
             frag0(c_ring);
             if (meta) ICN_META_ISSUE();                   // next tile's tables: consumed >= 2 K-steps from now
             ICN_ISSUE_STAGE();                            // stage s+2
@@ -951,7 +964,7 @@ _Pragma("unroll") \
         // `if (m < M) dst[(size_t)drow * stride + col] = ...` it replaces compiled to ~40 VALU instructions per element and cost
         // 4-5 us per tile (icn_debug_trace: 7-9 % of a launch of 28-step tiles, a third of one of 4-8-step tiles), which was
         // not the stores: leaving them out changed nothing, leaving the loop out took the launch from 215 to 205 us.
-        if (sk_store) {
+        if (sk_store && !(ICN_EXP & 1)) {
             unsigned dr[TM][16];                              // destination rows of this lane's elements (permuted launches)
             if (perm) {
 #pragma unroll
@@ -963,7 +976,7 @@ _Pragma("unroll") \
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int cl = wc * (BN / 2) + j * 32 + l31, col = n0 + cl;
-                const float bv = bias ? bias_s[eslot * BN + cl] : 0.f;
+                const float bv = (bias && !(ICN_EXP & 8)) ? bias_s[eslot * BN + cl] : 0.f;
                 // pair forward: 32-column groups at or beyond N0 belong to the second output tensor (wave-uniform)
                 const bool second = __builtin_amdgcn_readfirstlane(n0 + wc * (BN / 2) + j * 32 >= N0 ? 1 : 0) != 0;
                 const unsigned rs = (unsigned)(second ? N - N0 : N0) * 4u;                  // row stride of the tensor, bytes
@@ -976,16 +989,28 @@ _Pragma("unroll") \
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r] + bv), rd,
-                                                                  base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rs, 0, 0);
+                                                                  (ICN_EXP & 16) ? 0xFFFFFF00u : base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rs,
+                                                                  0, ICN_EXP_STORE_POLICY);
                 } else {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r] + bv), rd,
-                                                                  dr[i][r] == INVALID_ROW ? 0xFFFFFF00u : dr[i][r] * rs + cb, 0, 0);
+                                                                  ((ICN_EXP & 16) || dr[i][r] == INVALID_ROW) ? 0xFFFFFF00u : dr[i][r] * rs + cb,
+                                                                  0, ICN_EXP_STORE_POLICY);
                 }
             }
+        }
+        if ((ICN_EXP & 1) && sk_store) {                      // pricing build: the accumulators must stay live without an epilogue
+            float keep_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 4) keep_ += acc[i][j][r];
+            if (keep_ == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, keep_), rsrc_d, 0, 0, 0);
         }
         if (trace) { tr_epi += __builtin_amdgcn_s_memrealtime() - tr_e0; ++tr_nseg; }
         if (!has_next) break;
@@ -994,8 +1019,10 @@ _Pragma("unroll") \
         m0 = nm0;
         n0 = nn0;
         mask_c = mask_n;
-        slot ^= 1;
-        eslot = eslot == 2 ? 0 : eslot + 1;
+        if (!(ICN_EXP & 2)) {
+            slot ^= 1;
+            eslot = eslot == 2 ? 0 : eslot + 1;
+        }
         i_own = 1;                                        // the DMA pointer is already inside this tile
         next_tile = tile + gridDim.x;
         if (!SK && tlist) {
@@ -1637,7 +1664,7 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
             bool side_row = false; \
             _Pragma("unroll") \
             for (int i = 0; i < NA; ++i) side_row |= (int)aoff[i] < (int)NOTHING_OFFSET; \
-            if (__builtin_amdgcn_ballot_w64(side_row) == 0) { \
+            if ((ICN_EXP & 4) || __builtin_amdgcn_ballot_w64(side_row) == 0) { \
                 _Pragma("unroll") \
                 for (int i = 0; i < NA; ++i) { \
                     float* dst_ = Xs + __builtin_amdgcn_readfirstlane(d_ring * WG_RS * BI + (wave + 4 * i) * RPA * BI); \
@@ -1859,7 +1886,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad7(
             bool side_row = false; \
             _Pragma("unroll") \
             for (int i = 0; i < NI; ++i) side_row |= (int)aoff[i] < (int)NOTHING_OFFSET; \
-            if (__builtin_amdgcn_ballot_w64(side_row) == 0) { \
+            if ((ICN_EXP & 4) || __builtin_amdgcn_ballot_w64(side_row) == 0) { \
                 _Pragma("unroll") \
                 for (int i = 0; i < NI; ++i) { \
                     if (U % 16 != 0 && 4 * (wave + 4 * i) >= U) continue; \

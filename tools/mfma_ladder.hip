@@ -121,10 +121,10 @@ __global__ __launch_bounds__(256) void k_ladder(const float* src, unsigned src_b
 // Waves per block: the production kernels run 4 waves (2 x 2) per block; NW = 8 arranges them WR x WC over the tile, each wave a
 // (BM / WR) x (BN / WC) sub-tile of 32 x 32 MFMA tiles -- same LDS per block, twice the waves per SIMD to cover a block's barrier.
 // Level-4 traffic only (the conv's real gather), 3-stage ring.
-template <int BM, int BN, int WR, int WC>
+template <int BM, int BN, int WR, int WC, int NST = 3>
 __global__ __launch_bounds__(64 * WR * WC) void k_ladder_w(const float* src, unsigned src_bytes, float* out, int steps, int rows_total) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NW = WR * WC, NST = 3;
+    constexpr int NW = WR * WC;
     constexpr int TM = BM / WR / 32, TN = BN / WC / 32, RA = BM / 8 / NW, RB = BN / 8 / NW, NDMA = RA + RB;
     static_assert(TM >= 1 && TN >= 1 && RA >= 1 && RB >= 1, "tile too small for this wave grid");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,21 +203,21 @@ __global__ __launch_bounds__(64 * WR * WC) void k_ladder_w(const float* src, uns
 #endif
 }
 
-template <int BM, int BN, int WR, int WC>
+template <int BM, int BN, int WR, int WC, int NST = 3>
 void run_w(int blocks_per_cu, const float* src, unsigned src_bytes, float* out) {
     const int blocks = 256 * blocks_per_cu, steps = 4000 / blocks_per_cu * 8192 / (BM * BN) ;
-    const size_t lds = (size_t)3 * (BM + BN) * BK * 4;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ladder_w<BM, BN, WR, WC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t lds = (size_t)NST * (BM + BN) * BK * 4;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ladder_w<BM, BN, WR, WC, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_ladder_w<BM, BN, WR, WC>), dim3(blocks), dim3(64 * WR * WC), lds, 0, src, src_bytes, out, steps, (int)(src_bytes / 1024));
+        hipLaunchKernelGGL((k_ladder_w<BM, BN, WR, WC, NST>), dim3(blocks), dim3(64 * WR * WC), lds, 0, src, src_bytes, out, steps, (int)(src_bytes / 1024));
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
     }
     const double flops = (double)blocks * steps * 2.0 * BM * BN * BK;
-    printf("tile %3dx%-3d  %d waves (%d x %d)  %d block(s)/CU  %.3f ms  %.1f TFLOP/s\n", BM, BN, WR * WC, WR, WC, blocks_per_cu, best, flops / best / 1e9);
+    printf("tile %3dx%-3d  %d waves (%d x %d)  %d-stage ring  %d block(s)/CU  %.3f ms  %.1f TFLOP/s\n", BM, BN, WR * WC, WR, WC, NST, blocks_per_cu, best, flops / best / 1e9);
 }
 
 // Producer / consumer waves ("warp specialisation"): WR x WC consumer waves do nothing but fragment reads + MFMAs + the step
@@ -506,6 +506,20 @@ int main(int argc, char** argv) {
             run_w<128, 128, 2, 4>(1, src, src_bytes, out);    // 8 waves of 64 x 32
             run_w<128, 128, 4, 4>(1, src, src_bytes, out);    // 16 waves of 32 x 32
             run_w<128, 256, 2, 4>(1, src, src_bytes, out);    // 144 KB: 8 waves of 64 x 64
+        }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'n') {   // ring depth for the eight-wave blocks (round 5): does a 4-stage ring (prefetch distance 3) pay at one block per CU?
+        for (int rep = 0; rep < 2; ++rep) {
+            run_w<64, 128, 2, 2>(2, src, src_bytes, out);        // production shape
+            run_w<64, 128, 2, 4>(2, src, src_bytes, out);        // 8 waves of 32 x 32, 72 KB
+            run_w<128, 128, 2, 4>(1, src, src_bytes, out);       // 8 waves of 64 x 32, 96 KB
+            run_w<128, 128, 2, 4, 4>(1, src, src_bytes, out);    // ... 4 stages, 128 KB
+            run_w<128, 128, 4, 2, 4>(1, src, src_bytes, out);    // 8 waves of 32 x 64
+            run_w<128, 128, 4, 4, 4>(1, src, src_bytes, out);    // 16 waves of 32 x 32, 4 stages
+            run_w<128, 64, 4, 2, 4>(1, src, src_bytes, out);     // 128 x 64, 8 waves, 4 stages at ONE block (96 KB): control
+            run_w<128, 64, 4, 2, 3>(2, src, src_bytes, out);
+            run_w<64, 128, 2, 4, 4>(1, src, src_bytes, out);
         }
         return 0;
     }

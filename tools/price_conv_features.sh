@@ -1,0 +1,11 @@
+#!/bin/bash
+# On the GPU box: tools/price_conv_features.sh <out file> <variant> [<variant> ...]   (variants: bits of ICN_EXP built by
+# tools/build_exp.sh; "0" = the product library).  Two alternating passes over the variants inside one call.
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$1; shift
+: > $OUT
+for rep in 1 2; do
+  for v in "$@"; do
+    if [ "$v" = "0" ]; then unset ICN_LIB_PATH; tag=product; else export ICN_LIB_PATH=$R/geniconet_amd/csrc/build_exp/libicn_exp$v.so; tag=exp$v; fi
+    timeout -k 10 300 python3 $R/tools/price_conv_features.py --tag $tag >> $OUT 2>> $OUT.err || echo "variant $v failed" >> $OUT
+  done
+done
