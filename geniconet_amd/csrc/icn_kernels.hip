@@ -53,6 +53,9 @@
 #ifndef ICN_EXP
 #define ICN_EXP 0
 #endif
+#ifndef ICN_CONV_WAVES_DEFAULT
+#define ICN_CONV_WAVES_DEFAULT 4
+#endif
 #define ICN_EXP_STORE_POLICY ((ICN_EXP & 64) ? 2 : (ICN_EXP & 256) ? 17 : 0)
 
 namespace icn {
@@ -417,7 +420,7 @@ constexpr unsigned SIDE_FLAG = 0x80000000u;
 constexpr unsigned NOTHING_OFFSET = 0xC0000000u;
 
 // (body of the two kernels below: k_conv_dma<BM, BN, SEG> and its stream-K form k_conv_dma_sk<BM, BN>)
-template <int BM, int BN, bool SEG, bool SK>   // SEG: class-major rows + virtual taps of a composite table (icn_upconv_*)
+template <int BM, int BN, bool SEG, bool SK, int NW = 4>   // NW waves per workgroup as 2 x NW/2 (4: 256 threads; 8: 512, round 5); SEG: class-major rows + virtual taps of a composite table (icn_upconv_*)
 __device__ __forceinline__ void conv_dma_body(
     const float* __restrict__ src,      // (B, Ps, Ks)   Ks = K, or K / 2 with src2
     const float* __restrict__ src2,     // second half of the K axis (pair bwd-data), or null
@@ -448,12 +451,15 @@ __device__ __forceinline__ void conv_dma_body(
     // m = b * Pd + q; all of the class-major machinery compiles away there.
     constexpr unsigned INVALID_ROW = 0xFFFFFFFFu;      // destination-row table: padding row (nothing is stored)
     const int T = SEG ? T_arg : 7;
-    constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int RA = BM / 32, RB = BN / 32;          // rows per lane (one 16-byte chunk of each)
+    constexpr int WC = NW / 2, NTHR = 64 * NW;         // waves along N (2 along M); threads
+    constexpr int TM = BM / 64, TN = BN / (32 * WC);   // 32 x 32 MFMA tiles per wave
+    constexpr int RA = BM / (8 * NW), RB = BN / (8 * NW);   // rows per lane (one 16-byte chunk of each)
+    static_assert(NW == 4 || NW == 8, "2 x 2 or 2 x 4 waves");
+    static_assert(TN >= 1 && RA >= 1 && RB >= 1, "tile too small for this wave grid");
     constexpr int NDMA = RA + RB;                      // DMA instructions per wave per stage
     constexpr int RL = BM / 64;                        // tile rows per lane in the metadata pass (row r*64 + lane)
     constexpr int NJ = 7 * RL;                         // code DMA instructions per tile (64 codes each)
-    constexpr int JW = (NJ + 3) / 4;                   // ... per wave
+    constexpr int JW = (NJ + NW - 1) / NW;             // ... per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);        // [3][BM*32]   3-stage ring
     float* Bs = As + 3 * BM * BK;                      // [3][BN*32]
@@ -463,7 +469,7 @@ __device__ __forceinline__ void conv_dma_body(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
     const int l31 = lane & 31, h = lane >> 5;
     const int rsub = lane >> 3, pc = lane & 7;         // DMA: row within its 8-row group, physical 16-byte chunk
     const int ntn = N / BN, nk = K / BK;
@@ -537,10 +543,10 @@ __device__ __forceinline__ void conv_dma_body(
     // lane-constant parts of the DMA source offsets (bytes)
     unsigned achunk[RA], bconst[RB];
 #pragma unroll
-    for (int i = 0; i < RA; ++i) achunk[i] = 16u * (pc ^ swz(8 * (wave + 4 * i) + rsub));
+    for (int i = 0; i < RA; ++i) achunk[i] = 16u * (pc ^ swz(8 * (wave + NW * i) + rsub));
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int row = 8 * (wave + 4 * i) + rsub;
+        const int row = 8 * (wave + NW * i) + rsub;
         bconst[i] = (unsigned)row * (unsigned)K * 4u + 16u * (pc ^ swz(row));
     }
     // gather code of row (sample b) -> DMA byte offset
@@ -553,20 +559,20 @@ __device__ __forceinline__ void conv_dma_body(
     // (Later tiles: ICN_META_ISSUE / ICN_META_CONVERT below, by LDS-DMA, one tile ahead.)
     auto build_first = [&](int m0, int n0, unsigned mk) {
         const int nt = SEG ? __popc(mk) : 7;
-        for (int e = tid; e < nt * BM; e += 256) {
+        for (int e = tid; e < nt * BM; e += NTHR) {
             const int t = SEG ? nth_tap(mk, e / BM) : e / BM, row = e % BM;
             int b, q;
             decode_row(m0 + row, b, q);
             otab[e] = b >= 0 ? row_offset(dcode[(size_t)t * Pd + q], b) : NOTHING_OFFSET;
         }
         if (perm)
-            for (int row = tid; row < BM; row += 256) {
+            for (int row = tid; row < BM; row += NTHR) {
                 int b, q;
                 decode_row(m0 + row, b, q);
                 drow_s[row] = b >= 0 ? (unsigned)(b * Pd + perm[q]) : INVALID_ROW;
             }
         if (bias)
-            for (int c = tid; c < BN; c += 256) bias_s[c] = bias[n0 + c];
+            for (int c = tid; c < BN; c += NTHR) bias_s[c] = bias[n0 + c];
     };
     // taps in use by a tile (stride-2 dgrad: rows are grouped by lattice parity class, a class uses 1-2 taps);
     // wave-uniform index => scalar loads
@@ -601,7 +607,7 @@ __device__ __forceinline__ void conv_dma_body(
     f32x4 fa[2][TM], fb[2][TN];
     auto frag0 = [&](int ring) {                          // first fragments of a stage (issued before the DMA)
         const float* a_base = As + ring * BM * BK + (wr * (BM / 2) + l31) * BK;
-        const float* b_base = Bs + ring * BN * BK + (wc * (BN / 2) + l31) * BK;
+        const float* b_base = Bs + ring * BN * BK + (wc * (BN / WC) + l31) * BK;
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + 4 * (h ^ fl));
 #pragma unroll
@@ -609,7 +615,7 @@ __device__ __forceinline__ void conv_dma_body(
     };
     auto compute = [&](int ring) {
         const float* a_base = As + ring * BM * BK + (wr * (BM / 2) + l31) * BK;
-        const float* b_base = Bs + ring * BN * BK + (wc * (BN / 2) + l31) * BK;
+        const float* b_base = Bs + ring * BN * BK + (wc * (BN / WC) + l31) * BK;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if (kk < 3) {
@@ -716,7 +722,7 @@ __device__ __forceinline__ void conv_dma_body(
     int i_left = c_s1 - c_s0, i_ring = 0, i_own = 1, i_live = 1;   // steps left in the pointer's segment; i_own: inside compute tile
     unsigned pbase[RA];                                   // row offsets of the next stage to be issued (prefetched)
 #pragma unroll
-    for (int i = 0; i < RA; ++i) pbase[i] = otab[(SEG ? 0 : i_t) * BM + 8 * (wave + 4 * i) + rsub];   // SEG: rank 0
+    for (int i = 0; i < RA; ++i) pbase[i] = otab[(SEG ? 0 : i_t) * BM + 8 * (wave + NW * i) + rsub];   // SEG: rank 0
     int issued = 0, p_exact = 1;
     int mb[RL];                                           // metadata pass: sample of the lane's rows in the next tile, or -1
     // Issue the stage under the DMA pointer, advance the pointer, prefetch the next stage's row offsets.
@@ -737,7 +743,7 @@ _Pragma("unroll") \
             if ((ICN_EXP & 4) || __builtin_amdgcn_ballot_w64(side_row) == 0) { \
 _Pragma("unroll") \
                 for (int i = 0; i < RA; ++i) { \
-                    float* lds_dst = As + __builtin_amdgcn_readfirstlane(i_ring * BM * BK + 8 * (wave + 4 * i) * BK); \
+                    float* lds_dst = As + __builtin_amdgcn_readfirstlane(i_ring * BM * BK + 8 * (wave + NW * i) * BK); \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_ptr_t)lds_dst, 16, pbase[i] + achunk[i], a_soff, 0, 0); \
                 } \
             } else { \
@@ -745,7 +751,7 @@ _Pragma("unroll") \
                 const auto rs_ = sec_ ? rsrc_s2 : rsrc_s; \
 _Pragma("unroll") \
                 for (int i = 0; i < RA; ++i) { \
-                    float* lds_dst = As + __builtin_amdgcn_readfirstlane(i_ring * BM * BK + 8 * (wave + 4 * i) * BK); \
+                    float* lds_dst = As + __builtin_amdgcn_readfirstlane(i_ring * BM * BK + 8 * (wave + NW * i) * BK); \
                     if ((int)pbase[i] >= (int)NOTHING_OFFSET) \
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_ptr_t)lds_dst, 16, pbase[i] + achunk[i], a_soff, 0, 0); \
                     else \
@@ -755,7 +761,7 @@ _Pragma("unroll") \
             } \
 _Pragma("unroll") \
             for (int i = 0; i < RB; ++i) { \
-                float* lds_dst = Bs + __builtin_amdgcn_readfirstlane(i_ring * BN * BK + 8 * (wave + 4 * i) * BK); \
+                float* lds_dst = Bs + __builtin_amdgcn_readfirstlane(i_ring * BN * BK + 8 * (wave + NW * i) * BK); \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)lds_dst, 16, bconst[i], b_soff, 0, 0); \
             } \
             i_ring = i_ring == 2 ? 0 : i_ring + 1; \
@@ -777,11 +783,11 @@ _Pragma("unroll") \
                 const int rk_ = SEG ? __popc(mr_ & ((1u << i_t) - 1u)) : i_t;   /* row of the offset table */ \
                 const int tb = __builtin_amdgcn_readfirstlane(((i_own ? slot : slot ^ 1) * 7 + rk_) * BM); \
 _Pragma("unroll") \
-                for (int i = 0; i < RA; ++i) pbase[i] = otab[tb + 8 * (wave + 4 * i) + rsub]; \
+                for (int i = 0; i < RA; ++i) pbase[i] = otab[tb + 8 * (wave + NW * i) + rsub]; \
             } \
         } \
     } while (0)
-    // Metadata of the NEXT tile (rows nm0.., columns nn0..), fetched by LDS-DMA: code DMA j (of NJ, wave j % 4) brings the
+    // Metadata of the NEXT tile (rows nm0.., columns nn0..), fetched by LDS-DMA: code DMA j (of NJ, wave j % NW) brings the
     // 64 codes of tap j / RL, rows (j % RL) * 64 + lane, to their final place in the offset table; waves < RL fetch the
     // destination-row permutation, the last BN / 64 waves the bias.
 #define ICN_META_ISSUE() do { \
@@ -792,7 +798,7 @@ _Pragma("unroll") \
         for (int r = 0; r < RL; ++r) decode_row(nm0 + r * 64 + lane, mb[r], mp_[r]); \
 _Pragma("unroll") \
         for (int jj = 0; jj < JW; ++jj) { \
-            const int j = wave + 4 * jj; \
+            const int j = wave + NW * jj; \
             if (j < nj_) { \
                 const int r = j % RL; \
                 const int b_ = RL == 1 ? mb[0] : (r ? mb[RL - 1] : mb[0]); \
@@ -809,8 +815,8 @@ _Pragma("unroll") \
             unsigned* dst_ = drow_s + __builtin_amdgcn_readfirstlane(ne_ * BM + wave * 64); \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_p, (lds_ptr_t)dst_, 4, b_ >= 0 ? (unsigned)p_ * 4u : SIDE_FLAG, 0, 0, 0); \
         } \
-        if (bias && wave >= 4 - BN / 64) { \
-            const int c_ = __builtin_amdgcn_readfirstlane((wave - (4 - BN / 64)) * 64); \
+        if (bias && wave >= NW - BN / 64) { \
+            const int c_ = __builtin_amdgcn_readfirstlane((wave - (NW - BN / 64)) * 64); \
             float* dst_ = bias_s + __builtin_amdgcn_readfirstlane(ne_ * BN + c_); \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_bias, (lds_ptr_t)dst_, 4, (unsigned)(nn0 + c_ + lane) * 4u, 0, 0, 0); \
         } \
@@ -822,7 +828,7 @@ _Pragma("unroll") \
         const int nj_ = SEG ? __builtin_amdgcn_readfirstlane(__popc(mask_n) * RL) : NJ; \
 _Pragma("unroll") \
         for (int jj = 0; jj < JW; ++jj) { \
-            const int j = wave + 4 * jj; \
+            const int j = wave + NW * jj; \
             if (j < nj_) { \
                 const int r = j % RL; \
                 const int b_ = RL == 1 ? mb[0] : (r ? mb[RL - 1] : mb[0]); \
@@ -892,7 +898,7 @@ _Pragma("unroll") \
                         for (int r4 = 0; r4 < 4; ++r4) {
                             const f32x4 v = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_k,
-                                                                   base + ((i * TN + j) * 4 + r4) * 4096u, 0, SYS);
+                                                                   base + ((i * TN + j) * 4 + r4) * (NTHR * 16u), 0, SYS);
                         }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -938,7 +944,7 @@ _Pragma("unroll") \
 #pragma unroll
                             for (int r4 = 0; r4 < 4; ++r4) {
                                 const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                                               rsrc_k, base + ((i * TN + j) * 4 + r4) * 4096u, 0, SYS));
+                                                                               rsrc_k, base + ((i * TN + j) * 4 + r4) * (NTHR * 16u), 0, SYS));
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += v[e];
                             }
@@ -975,10 +981,10 @@ _Pragma("unroll") \
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int cl = wc * (BN / 2) + j * 32 + l31, col = n0 + cl;
+                const int cl = wc * (BN / WC) + j * 32 + l31, col = n0 + cl;
                 const float bv = (bias && !(ICN_EXP & 8)) ? bias_s[eslot * BN + cl] : 0.f;
                 // pair forward: 32-column groups at or beyond N0 belong to the second output tensor (wave-uniform)
-                const bool second = __builtin_amdgcn_readfirstlane(n0 + wc * (BN / 2) + j * 32 >= N0 ? 1 : 0) != 0;
+                const bool second = __builtin_amdgcn_readfirstlane(n0 + wc * (BN / WC) + j * 32 >= N0 ? 1 : 0) != 0;
                 const unsigned rs = (unsigned)(second ? N - N0 : N0) * 4u;                  // row stride of the tensor, bytes
                 const auto rd = second ? rsrc_d2 : rsrc_d;
                 const unsigned cb = (unsigned)(second ? col - N0 : col) * 4u;
@@ -1087,6 +1093,39 @@ __global__ __launch_bounds__(256) void k_conv_dma_sk(const float* __restrict__ s
                                      src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
 }
 
+// Eight waves per workgroup (2 x 4 waves of 32 x 32; round 5): the same tile, LDS image, ring and tables as the four-wave kernels, the
+// stage's DMA rows / metadata entries / epilogue columns dealt over twice the waves -- 3 instead of 6 DMA instructions and 16 instead
+// of 32 MFMAs per wave and K-step, four waves per SIMD at two workgroups per CU to cover each other's barriers and stage issues
+// (tools/mfma_ladder w / s: +2.6 - 3 % for this tile at the conv's real traffic, on 4 ms and on 0.2 ms launches).
+template <int BM, int BN, bool SEG>
+__global__ __launch_bounds__(512, 2) void k_conv_dma8(const float* __restrict__ src, const float* __restrict__ src2,
+                                                       const float* __restrict__ wt, const float* __restrict__ bias,
+                                                       float* __restrict__ dst, float* __restrict__ dst2,
+                                                       const int32_t* __restrict__ dcode, const float* __restrict__ side,
+                                                       const float* __restrict__ side2, const int32_t* __restrict__ perm,
+                                                       const uint32_t* __restrict__ mask32, int M, int Ps, int Pd, int K, int N, int N0,
+                                                       int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles, int T_arg,
+                                                       const RowSegs segs, unsigned long long* __restrict__ trace,
+                                                       const int* __restrict__ tlist) {
+    conv_dma_body<BM, BN, SEG, false, 8>(src, src2, wt, bias, dst, dst2, dcode, side, side2, perm, mask32, M, Ps, Pd, K, N, N0, n_slots,
+                                         src_bytes, side_bytes, ntiles, T_arg, segs, 4, nullptr, nullptr, nullptr, 0, trace, nullptr, tlist);
+}
+
+template <int BM, int BN, bool SEG>
+__global__ __launch_bounds__(512, 2) void k_conv_dma_sk8(const float* __restrict__ src, const float* __restrict__ src2,
+                                                          const float* __restrict__ wt, const float* __restrict__ bias,
+                                                          float* __restrict__ dst, float* __restrict__ dst2,
+                                                          const int32_t* __restrict__ dcode, const float* __restrict__ side,
+                                                          const float* __restrict__ side2, const int32_t* __restrict__ perm, int M, int Ps,
+                                                          int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes,
+                                                          unsigned side_bytes, int ntiles, int T_arg, const RowSegs segs, int sk_mp,
+                                                          float* __restrict__ sk_part, int* __restrict__ sk_flag,
+                                                          int* __restrict__ sk_status, int sk_spin_limit,
+                                                          unsigned long long* __restrict__ trace, const int* __restrict__ sk_bnd) {
+    conv_dma_body<BM, BN, SEG, true, 8>(src, src2, wt, bias, dst, dst2, dcode, side, side2, SEG ? perm : nullptr, nullptr, M, Ps, Pd, K, N, N0, n_slots,
+                                        src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
+}
+
 // dynamic LDS of k_conv_dma: A/B rings, offset table, destination-row table (row permutation only), bias (bias only)
 static size_t conv_dma_lds(int bm, int bn, bool perm, bool bias) {
     return (size_t)3 * (bm + bn) * BK * 4 + (size_t)2 * 7 * bm * 4 + (perm ? (size_t)3 * bm * 4 : 0) + (bias ? (size_t)3 * bn * 4 : 0) +
@@ -1170,8 +1209,12 @@ static void check_dma_ranges(const GatherGemmArgs& a) {
         throw std::invalid_argument("icn: tensor beyond the LDS-DMA kernels' 32-bit buffer offsets");
 }
 
-template <int BM, int BN, bool SEG>
+template <int BM, int BN, bool SEG, int NW = 4>
 static void launch_conv_dma_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
+    constexpr auto kern = [] {
+        if constexpr (NW == 8) return &k_conv_dma8<BM, BN, SEG>;
+        else return &k_conv_dma<BM, BN, SEG>;
+    }();
     check_dma_ranges(a);
     const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);   // class-major rows: M is a multiple of 8 * BM
     int grid = std::min(ntiles, 256 * occ);              // (more blocks than slots: measured, no difference -- DESIGN 4.2)
@@ -1179,8 +1222,7 @@ static void launch_conv_dma_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
     const size_t lds = conv_dma_lds(BM, BN, a.perm != nullptr, a.bias != nullptr);
     static std::atomic<uint64_t> attr_devices{0};        // LDS opt-in, once per device
     if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_dma<BM, BN, SEG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
     }
     const int Ks = a.src2 ? a.K / 2 : a.K;
@@ -1190,10 +1232,11 @@ static void launch_conv_dma_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
     const int* tlist = nullptr;
     if (!SEG && a.mask32 && a.mask32_host && a.mask_key && grid % 8 == 0 && !(dbg_flags() & 512))
         tlist = tile_lists(a, BM, BN, ntiles, grid, occ);
-    prof_mark_begin((BM == 64 ? (BN == 128 ? PROF_DMA_64x128 : PROF_DMA_64x64) : (BN == 128 ? PROF_DMA_128x128 : PROF_DMA_128x64)) +
-                        (SEG ? PROF_DMAS_128x128 - PROF_DMA_128x128 : 0),
+    prof_mark_begin(NW == 8 ? (SEG ? PROF_DMAS8_64x128 : PROF_DMA8_64x128)
+                            : (BM == 64 ? (BN == 128 ? PROF_DMA_64x128 : PROF_DMA_64x64) : (BN == 128 ? PROF_DMA_128x128 : PROF_DMA_128x64)) +
+                                  (SEG ? PROF_DMAS_128x128 - PROF_DMA_128x128 : 0),
                     a.algo_flops, s);
-    hipLaunchKernelGGL((k_conv_dma<BM, BN, SEG>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2,
                        a.dcode, a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.mask32, a.M,
                        a.Ps, a.Pd, a.K, a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs,
                        g_trace_cap >= (size_t)grid * 8 ? g_trace : nullptr, tlist);
@@ -1254,8 +1297,12 @@ static const int* sk_boundary_tables(int ntiles, int grid, int S, int occ) {
     return cache.emplace(key, d).first->second;
 }
 
-template <int BM, int BN, bool SEG>
+template <int BM, int BN, bool SEG, int NW = 4>
 static void launch_conv_dma_sk_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
+    constexpr auto kern = [] {
+        if constexpr (NW == 8) return &k_conv_dma_sk8<BM, BN, SEG>;
+        else return &k_conv_dma_sk<BM, BN, SEG>;
+    }();
     check_dma_ranges(a);
     const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);   // SEG: M is the padded row count
     const int grid = 256 * occ;                           // every block slot of the chip: all of them resident at once
@@ -1264,15 +1311,15 @@ static void launch_conv_dma_sk_t(const GatherGemmArgs& a, int occ, hipStream_t s
     const size_t lds = conv_dma_lds(BM, BN, a.perm != nullptr, a.bias != nullptr);
     static std::atomic<uint64_t> attr_devices{0};
     if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_dma_sk<BM, BN, SEG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
     }
     const int Ks = a.src2 ? a.K / 2 : a.K;
     const size_t nb = SEG ? (size_t)a.segs.B : (size_t)(a.M / a.Pd);
     const unsigned src_bytes = (unsigned)(nb * a.Ps * Ks * 4), side_bytes = (unsigned)(nb * a.n_slots * Ks * 4);
-    prof_mark_begin((SEG ? PROF_DMAKS_64x128 : PROF_DMAK_64x128) + (BN == 128 ? 0 : 1), a.algo_flops, s);
-    hipLaunchKernelGGL((k_conv_dma_sk<BM, BN, SEG>), dim3(grid), dim3(256), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,
+    prof_mark_begin(NW == 8 ? (SEG ? PROF_DMAKS8_64x128 : PROF_DMAK8_64x128) : (SEG ? PROF_DMAKS_64x128 : PROF_DMAK_64x128) + (BN == 128 ? 0 : 1),
+                    a.algo_flops, s);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,
                        a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.M, a.Ps, a.Pd, a.K,
                        a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs, CONV_SK_MIN_PIECE,
                        a.sk_part, a.sk_flag, device_status_word(), (dbg_flags() & 256) ? -1 : ((1 << 22) | ((dbg_flags() & 8192) ? (1 << 28) : 0)),
@@ -1291,20 +1338,38 @@ static long seg_rows(const RowSegs& sg, int bm, int* row0) {
     return row;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NW = 4>
 static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
-    if (a.segs.nseg == 0) return launch_conv_dma_t<BM, BN, false>(a, occ, s);
+    if (a.segs.nseg == 0) return launch_conv_dma_t<BM, BN, false, NW>(a, occ, s);
     GatherGemmArgs b = a;
     b.M = (int)seg_rows(a.segs, BM, b.segs.row0);
-    launch_conv_dma_t<BM, BN, true>(b, occ, s);
+    launch_conv_dma_t<BM, BN, true, NW>(b, occ, s);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NW = 4>
 static void launch_conv_dma_sk(const GatherGemmArgs& a, int occ, hipStream_t s) {
-    if (a.segs.nseg == 0) return launch_conv_dma_sk_t<BM, BN, false>(a, occ, s);
+    if (a.segs.nseg == 0) return launch_conv_dma_sk_t<BM, BN, false, NW>(a, occ, s);
     GatherGemmArgs b = a;
     b.M = (int)seg_rows(a.segs, BM, b.segs.row0);
-    launch_conv_dma_sk_t<BM, BN, true>(b, occ, s);
+    launch_conv_dma_sk_t<BM, BN, true, NW>(b, occ, s);
+}
+
+// Waves per workgroup of the 64 x 128 tile's launches: 8 (2 x 4 waves of 32 x 32: k_conv_dma8 / k_conv_dma_sk8) or 4 (2 x 2 waves
+// of 32 x 64); the other tiles have the four-wave form only.  Default 4: measured in round 5 (profiles/r05_ladder_production_rungs.txt)
+// the eight-wave form is +1 % on the dominant class alone, -2 % on the decoder heads' dense GEMMs and -0.9 % in the training step.
+// Debug flag 16384 (tests, in-process) or ICN_CONV_WAVES=8 selects it for every 64 x 128 launch; ICN_CONV_WAVES=84 / 80 for the
+// plain (SEG = false) launches only / for launches with a bias (the forward convolutions) only (A/B runs).
+static int conv_waves_64x128(const GatherGemmArgs& a) {
+    static const int mode = [] {
+        const char* e = getenv("ICN_CONV_WAVES");
+        const int v = e ? atoi(e) : ICN_CONV_WAVES_DEFAULT;
+        if (v != 4 && v != 8 && v != 84 && v != 80) throw std::invalid_argument("icn: ICN_CONV_WAVES must be 4, 8, 84 or 80");
+        return v;
+    }();
+    if (dbg_flags() & 16384) return 8;
+    if (mode == 84) return a.segs.nseg == 0 ? 8 : 4;
+    if (mode == 80) return (a.segs.nseg == 0 && a.bias != nullptr) ? 8 : 4;
+    return mode;
 }
 
 bool conv_dma_usable(const GatherGemmArgs& a) {
@@ -1371,12 +1436,13 @@ static void launch_conv_dma_auto(const GatherGemmArgs& a, hipStream_t s) {
         const long rows = a.segs.nseg > 0 ? seg_rows(a.segs, c.bm, nullptr) : a.M;
         const long tiles = ((rows + c.bm - 1) / c.bm) * (a.N / c.bn);
         if (conv_sk_splits(tiles, 256 * best_occ, std::max(1, conv_sk_steps(a) / CONV_SK_MIN_PIECE)))
-            return best == 2 ? launch_conv_dma_sk<64, 128>(a, best_occ, s) : launch_conv_dma_sk<64, 64>(a, best_occ, s);
+            return best == 2 ? (conv_waves_64x128(a) == 8 ? launch_conv_dma_sk<64, 128, 8>(a, best_occ, s) : launch_conv_dma_sk<64, 128>(a, best_occ, s))
+                             : launch_conv_dma_sk<64, 64>(a, best_occ, s);
     }
     switch (best) {
         case 0: return launch_conv_dma<128, 128>(a, best_occ, s);
         case 1: return launch_conv_dma<128, 64>(a, best_occ, s);
-        case 2: return launch_conv_dma<64, 128>(a, best_occ, s);
+        case 2: return conv_waves_64x128(a) == 8 ? launch_conv_dma<64, 128, 8>(a, best_occ, s) : launch_conv_dma<64, 128>(a, best_occ, s);
         default: return launch_conv_dma<64, 64>(a, best_occ, s);
     }
 }

@@ -203,14 +203,15 @@ __global__ __launch_bounds__(64 * WR * WC) void k_ladder_w(const float* src, uns
 #endif
 }
 
+static int g_steps_div = 1;      // mode 's': launches of ~200 us instead of ~4 ms (the chip holds a higher clock on short launches)
 template <int BM, int BN, int WR, int WC, int NST = 3>
 void run_w(int blocks_per_cu, const float* src, unsigned src_bytes, float* out) {
-    const int blocks = 256 * blocks_per_cu, steps = 4000 / blocks_per_cu * 8192 / (BM * BN) ;
+    const int blocks = 256 * blocks_per_cu, steps = 4000 / blocks_per_cu * 8192 / (BM * BN) / g_steps_div;
     const size_t lds = (size_t)NST * (BM + BN) * BK * 4;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ladder_w<BM, BN, WR, WC, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9;
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int rep = 0; rep < (g_steps_div > 1 ? 12 : 3); ++rep) {
         hipEventRecord(e0);
         hipLaunchKernelGGL((k_ladder_w<BM, BN, WR, WC, NST>), dim3(blocks), dim3(64 * WR * WC), lds, 0, src, src_bytes, out, steps, (int)(src_bytes / 1024));
         hipEventRecord(e1); hipEventSynchronize(e1);
@@ -506,6 +507,18 @@ int main(int argc, char** argv) {
             run_w<128, 128, 2, 4>(1, src, src_bytes, out);    // 8 waves of 64 x 32
             run_w<128, 128, 4, 4>(1, src, src_bytes, out);    // 16 waves of 32 x 32
             run_w<128, 256, 2, 4>(1, src, src_bytes, out);    // 144 KB: 8 waves of 64 x 64
+        }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 's') {   // SHORT launches (~200 us, as in the training step): wave count at the clock short launches hold
+        g_steps_div = 20;
+        for (int rep = 0; rep < 3; ++rep) {
+            run_w<64, 128, 2, 2>(2, src, src_bytes, out);        // production shape
+            run_w<64, 128, 2, 4>(2, src, src_bytes, out);        // 8 waves of 32 x 32
+            run_w<128, 128, 2, 4>(1, src, src_bytes, out);       // 8 waves of 64 x 32
+            run_w<64, 64, 2, 2>(3, src, src_bytes, out);
+            run_w<128, 64, 2, 2>(2, src, src_bytes, out);
+            run_w<128, 64, 4, 2>(2, src, src_bytes, out);
         }
         return 0;
     }
