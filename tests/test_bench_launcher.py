@@ -1,5 +1,5 @@
 """bench.py's own launcher (`python bench.py --gpus N` with no WORLD_SIZE in the environment): host-side behaviour that needs no
-GPU.  The N-rank run itself is tests/test_gpu_dp_rehearsal.py::test_bench_self_launch_rehearsal (one-GPU box, gloo)."""
+GPU.  The N-rank run itself is tests/test_gpu_dp_rehearsal.py::test_bench_launch_forms_rehearsal (one-GPU box, gloo)."""
 import os
 import subprocess
 import sys

@@ -85,24 +85,34 @@ def test_two_ranks_on_one_gpu_average_gradients_through_the_hip_operators(tmp_pa
 
 
 @pytest.mark.timeout(900)
-def test_bench_self_launch_rehearsal():
-    """`python3 bench.py --gpus 2` with NO WORLD_SIZE in the environment -- the form the driver uses for N = 1 -- must start its two
-    ranks itself (fresh interpreters; the launcher never touches the GPU), meet over the backend, and print ONE JSON line that
-    says how many ranks met.  On this one-GPU box the ranks share cuda:0 over gloo (ICN_BENCH_REHEARSAL=1); on an 8-GPU node the
-    same entry runs one rank per GPU over RCCL."""
+@pytest.mark.parametrize('launcher', ['self', 'torch.distributed.run'])
+def test_bench_launch_forms_rehearsal(launcher):
+    """Both ways the driver may start the N > 1 bench, two ranks each:
+      'self'  -- `python3 bench.py --gpus 2` with NO WORLD_SIZE in the environment (the form it uses for N = 1): bench.py must start
+                 its ranks itself (fresh interpreters; the launcher never touches the GPU);
+      'torch.distributed.run' -- `python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+                 --master-port P bench.py --gpus 2` (the form the contract names).
+    Either way the ranks meet over the backend and rank 0 prints ONE JSON line that says how many met and who launched them.  On
+    this one-GPU box the ranks share cuda:0 over gloo (ICN_BENCH_REHEARSAL=1); on an 8-GPU node the same entries run one rank per
+    GPU over RCCL."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(ICN_BENCH_REHEARSAL='1', PYTHONFAULTHANDLER='1')
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=840)
+    bench = [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1']
+    if launcher == 'self':
+        cmd = [sys.executable] + bench
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port())] + bench
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=840)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['value'] > 0 and out['scaling'] == 'weak'
     d = out['distributed']
-    assert d['n_ranks_seen'] == 2 and d['backend'] == 'gloo' and d['launcher'] == 'self' and d['ddp'] is True
+    assert d['n_ranks_seen'] == 2 and d['backend'] == 'gloo' and d['launcher'] == launcher and d['ddp'] is True
     assert d['bucket_mb'] > 0 and d['visible_devices'] >= 1
     assert 0 < d['rank_ms_per_step']['min'] <= d['rank_ms_per_step']['max'] <= out['ms_per_step'] + 1e-3
     assert out['config']['global_batch'] == 72 and 'cpu_baseline' not in out and 'also' not in out
