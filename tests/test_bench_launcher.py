@@ -38,3 +38,29 @@ def test_a_world_size_mismatch_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=3' in r.stderr
+
+
+def test_roofline_traffic_is_only_reported_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    """bench.committed_traffic: the committed counter profile's HBM bytes are reported only when it records the sha256 of the kernel
+    sources of THIS tree (tools/profile_summary.py writes it); a profile of other / unrecorded sources gives None + the reason."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from geniconet_amd import _lib
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    kernel = 'k_conv_dma_sk<64, 128, false>'
+    assert bench.committed_traffic(kernel)[0] is None                                   # no profile at all
+    entry = {'icn::' + kernel: {'hbm_bytes_per_launch': 123.0}}
+    (prof / 'r07_pmc_per_kernel.json').write_text(json.dumps(entry))                    # hash unrecorded (rounds 1-4)
+    t, why = bench.committed_traffic(kernel)
+    assert t is None and 'unrecorded' in why
+    (prof / 'r08_pmc_per_kernel.json').write_text(json.dumps(dict(entry, _kernel_sources_sha256='0' * 64)))
+    t, why = bench.committed_traffic(kernel)
+    assert t is None and 're-run tools/profile_round.sh' in why                         # other sources
+    (prof / 'r09_pmc_per_kernel.json').write_text(json.dumps(dict(entry, _kernel_sources_sha256=_lib.source_sha256())))
+    t, why = bench.committed_traffic(kernel)
+    assert t == 123.0 and 'r09_pmc_per_kernel.json' in why
+    assert bench.committed_traffic('k_other')[0] is None                                # a kernel the profile does not have
