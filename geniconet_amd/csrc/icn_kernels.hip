@@ -2160,11 +2160,12 @@ __global__ void k_wgrad_generic(const float* __restrict__ x, const float* __rest
 // Both stem kernels stage the gathered 7*CIN input values of a group of 64 pixels in LDS first (all 256 threads
 // issue independent gathers), then stream the wide side (y or dy, Cout floats per pixel) with coalesced accesses.
 constexpr int STEM_PIX = 64;
+constexpr int STEM_WG_PIX = 256;                       // pixels whose inputs k_stem_wgrad gathers per phase
 
-template <int CIN>
+template <int CIN, int NPIX = STEM_PIX>
 __device__ __forceinline__ void stem_gather(const float* __restrict__ x, const int32_t* __restrict__ idx, float* xs, int m0,
                                             int M, int Ps, int Pd, int ns) {
-    for (int i = threadIdx.x; i < STEM_PIX * 7; i += 256) {
+    for (int i = threadIdx.x; i < NPIX * 7; i += 256) {
         const int row = i / 7, t = i % 7, m = m0 + row;
         float v[CIN];
 #pragma unroll
@@ -2216,43 +2217,50 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x,
                                                      float* __restrict__ bias_partial, int M, int Ps, int Pd, int Cout, int ns,
                                                      int rows_per_block) {
     // A thread owns 4 output channels (one 16-byte load of dy per row: a wave streams 1 KiB per instruction instead of 256 B)
-    // and every (256 / (Cout / 4))-th row of the 64-pixel group; the gathered inputs come from LDS as broadcasts.
+    // and every (256 / (Cout / 4))-th row of a 64-pixel group; the gathered inputs come from LDS as broadcasts.
+    // Round 5: the inputs of STEM_WG_PIX = 256 pixels (a block's whole row range with the default split) are gathered in ONE phase --
+    // 7 independent (code, value) load chains per thread instead of four phases of 2 with a barrier pair each: the gather's latency
+    // (~2 us per phase) was most of a block's time -- and the cross-wave reduction buffer aliases the gather buffer.
     constexpr int KT = 7 * CIN, NA = KT + 1;           // 7*CIN weight sums + 1 bias sum
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = reinterpret_cast<float*>(smem);        // [STEM_PIX][KT]
-    f32x4* red = reinterpret_cast<f32x4*>(xs + STEM_PIX * KT);   // [G][NA][Cout / 4]
+    float* xs = reinterpret_cast<float*>(smem);        // [STEM_WG_PIX][KT]
+    f32x4* red = reinterpret_cast<f32x4*>(smem);       // [G][NA][Cout / 4]  (after the last read of xs)
     const int q = Cout / 4, G = 256 / q, g = threadIdx.x / q, c4 = threadIdx.x % q;
     const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
     f32x4 acc[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int m0 = mb; m0 < me; m0 += STEM_PIX) {
+    for (int mg = mb; mg < me; mg += STEM_WG_PIX) {
         __syncthreads();
-        stem_gather<CIN>(x, idx, xs, m0, me, Ps, Pd, ns);
+        stem_gather<CIN, STEM_WG_PIX>(x, idx, xs, mg, me, Ps, Pd, ns);
         __syncthreads();
-        const int nrow = min(STEM_PIX, me - m0);
-        // up to 4 rows per thread and group of 64 pixels (G >= 16): all loads issued before the first add, ascending row order
-        f32x4 dyv[4];
+        for (int m0 = mg; m0 < min(me, mg + STEM_WG_PIX); m0 += STEM_PIX) {
+            const float* xg = xs + (m0 - mg) * KT;
+            const int nrow = min(STEM_PIX, me - m0);
+            // up to 4 rows per thread and group of 64 pixels (G >= 16): all loads issued before the first add, ascending row order
+            f32x4 dyv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = g + u * G;
-            dyv[u] = (row < nrow && u * G < STEM_PIX) ? ld4(dy + (size_t)(m0 + row) * Cout + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+            for (int u = 0; u < 4; ++u) {
+                const int row = g + u * G;
+                dyv[u] = (row < nrow && u * G < STEM_PIX) ? ld4(dy + (size_t)(m0 + row) * Cout + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = g + u * G;
-            if (row >= nrow || u * G >= STEM_PIX) break;
-            acc[KT] += dyv[u];
+            for (int u = 0; u < 4; ++u) {
+                const int row = g + u * G;
+                if (row >= nrow || u * G >= STEM_PIX) break;
+                acc[KT] += dyv[u];
 #pragma unroll
-            for (int k = 0; k < KT; ++k) acc[k] += dyv[u] * xs[row * KT + k];
-        }
-        for (int row = g + 4 * G; row < nrow; row += G) {       // (G < 16: Cout > 64)
-            const f32x4 d = ld4(dy + (size_t)(m0 + row) * Cout + 4 * c4);
-            acc[KT] += d;
+                for (int k = 0; k < KT; ++k) acc[k] += dyv[u] * xg[row * KT + k];
+            }
+            for (int row = g + 4 * G; row < nrow; row += G) {       // (G < 16: Cout > 64)
+                const f32x4 d = ld4(dy + (size_t)(m0 + row) * Cout + 4 * c4);
+                acc[KT] += d;
 #pragma unroll
-            for (int k = 0; k < KT; ++k) acc[k] += d * xs[row * KT + k];
+                for (int k = 0; k < KT; ++k) acc[k] += d * xg[row * KT + k];
+            }
         }
     }
+    __syncthreads();                                   // every thread is done with xs: `red` may overwrite it
     // the row groups of a wave (64 / q of them, q a power of two) are combined with shuffles, the (at most) 4 waves through LDS:
     // fixed orders, deterministic
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wq = q < 64 ? q : 64;
@@ -2326,7 +2334,10 @@ static int wgrad_base_splits(int M, int Cin, int Cout, int Cout0) {     // MFMA 
 static int wgrad_splits_pertap(int M, int Cin, int Cout, int Cout0) {
     if (Cout0 <= 0 || Cout0 > Cout) Cout0 = Cout;
     if (wgrad_supported(Cin, Cout)) return wgrad_base_splits(M, Cin, Cout, Cout0);
-    if (stem_supported(Cin, Cout)) return std::min(2048, (M + 255) / 256);
+    if (stem_supported(Cin, Cout)) {                    // (ICN_STEM_ROWS: developer A/B of the rows per block; 512: two gather phases per block, half the slabs of 256)
+        static const int rows = getenv("ICN_STEM_ROWS") ? std::max(64, atoi(getenv("ICN_STEM_ROWS"))) : 512;
+        return std::min(2048, (M + rows - 1) / rows);
+    }
     return std::min(512, (M + 127) / 128);
 }
 int wgrad7_splits(int M, int Pd, int Cin, int Cout, int Cout0);
@@ -2443,7 +2454,7 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
 #undef ICN_WG
     } else if (stem_supported(a.Cin, a.Cout)) {
         const int rows = (a.M + S - 1) / S;
-        const size_t lds = ((size_t)STEM_PIX * 7 * a.Cin + (size_t)4 * (7 * a.Cin + 1) * a.Cout) * 4;   // xs + one partial per wave
+        const size_t lds = std::max((size_t)STEM_WG_PIX * 7 * a.Cin, (size_t)4 * (7 * a.Cin + 1) * a.Cout) * 4;   // xs, then one partial per wave in its place
 #define ICN_SW(C)                                                                                                    \
     hipLaunchKernelGGL((k_stem_wgrad<C>), dim3(S), dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M, \
                        a.Ps, a.Pd, a.Cout, a.ns, rows)
