@@ -236,6 +236,16 @@ def measure(cfg, args, ctx, headline):
     final_loss = float(loss)
     _lib.raise_on_device_status(device)      # a kernel-side failure (lost stream-K partner) must not yield a bench line
     ddp = tr.net is not tr.model                                      # DistributedDataParallel around the model
+    # Evidence that the gradient exchange really happened: the replicas start from rank 0's weights, see DIFFERENT data (seed
+    # 1234 + rank) and must still hold bit-identical weights after W + K steps -- true only if every step's gradients were averaged
+    # over all ranks.  One float64 checksum per rank, gathered.
+    replicas_identical = None
+    if group and ddp:
+        cs = torch.stack([q.detach().double().sum() for q in tr.model.parameters()]).sum().reshape(1)
+        cs = cs.cpu() if rehearsal else cs
+        sums = [torch.zeros_like(cs) for _ in range(dist.get_world_size())]
+        dist.all_gather(sums, cs)
+        replicas_identical = bool(all(float(v) == float(sums[0]) for v in sums))
     del tr, x, t, loss
     import gc
     gc.collect()
@@ -291,7 +301,7 @@ def measure(cfg, args, ctx, headline):
             'frac_hbm': round(value * TRAIN_MB_PER_MESH[key] / 1e3 / world / PEAK_HBM_GBPS, 4),
         }
     return {'value': round(value, 2), 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'final_loss': final_loss,
-            'roofline': roofline, 'ddp': ddp,
+            'roofline': roofline, 'ddp': ddp, 'replicas_identical': replicas_identical,
             'rank_ms_per_step': {'min': round(min(per_rank) / args.steps * 1e3, 3), 'max': round(max(per_rank) / args.steps * 1e3, 3)}}
 
 
@@ -382,6 +392,7 @@ def run(args):
                             'visible_devices': visible, 'ddp': head['ddp'],
                             'bucket_mb': icn_train.GRAD_BUCKET_MB if head['ddp'] else None,
                             'rank_ms_per_step': head['rank_ms_per_step'],
+                            'replicas_identical_after_run': head['replicas_identical'],
                             'launcher': os.environ.get('ICN_BENCH_LAUNCHER') or ('torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ
                                                                                   else 'none')},
         }

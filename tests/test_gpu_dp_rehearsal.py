@@ -114,6 +114,7 @@ def test_bench_launch_forms_rehearsal(launcher):
     d = out['distributed']
     assert d['n_ranks_seen'] == 2 and d['backend'] == 'gloo' and d['launcher'] == launcher and d['ddp'] is True
     assert d['bucket_mb'] > 0 and d['visible_devices'] >= 1
+    assert d['replicas_identical_after_run'] is True          # different data per rank, identical weights: the gradients were averaged
     assert 0 < d['rank_ms_per_step']['min'] <= d['rank_ms_per_step']['max'] <= out['ms_per_step'] + 1e-3
     assert out['config']['global_batch'] == 72 and 'cpu_baseline' not in out and 'also' not in out
     assert out['roofline'] is not None and out['roofline']['kernel'].startswith('k_')
