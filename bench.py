@@ -249,7 +249,10 @@ def measure(cfg, args, ctx, headline):
     del tr, x, t, loss
     import gc
     gc.collect()
-    torch.cuda.empty_cache()
+    # (NO torch.cuda.empty_cache() here: handing the pool back to the driver between configurations made the caching allocator fall,
+    #  one run in five, into a state in which every step of the NEXT configuration blocked the host in hipMalloc / hipFree -- 25 to
+    #  83 ms per step instead of 8, enqueue-bound: tools/_exp/also_repro.py, round 5.  The three configurations together reserve 48 GB
+    #  of the 288.)
     if rank != 0:
         return None
 
@@ -406,8 +409,8 @@ def run(args):
                 r = m['roofline'] or {}
                 # Plausibility guard for these secondary entries only (the headline is timed exactly once): the MFMA kernels' one-stream
                 # time per step (survey) is a floor of the step; a timed region far above it means something other than the device held
-                # the steps up (one run of round 5 showed the I6 entry at 2.5 x directly after profiler passes and never again).  Such a
-                # region is measured a second time and BOTH are reported.
+                # the steps up (round 5: the host, blocked in the allocator after an empty_cache() between configurations -- removed,
+                # see measure()).  Such a region is measured a second time and BOTH are reported.
                 runs = [m['ms_per_step']]
                 if r.get('mfma_kernels_ms_per_step') and m['ms_per_step'] > 1.8 * r['mfma_kernels_ms_per_step']:
                     m2 = measure(c, args, ctx, headline=False)
