@@ -420,7 +420,7 @@ constexpr unsigned SIDE_FLAG = 0x80000000u;
 constexpr unsigned NOTHING_OFFSET = 0xC0000000u;
 
 // (body of the two kernels below: k_conv_dma<BM, BN, SEG> and its stream-K form k_conv_dma_sk<BM, BN>)
-template <int BM, int BN, bool SEG, bool SK, int NW = 4>   // NW waves per workgroup as 2 x NW/2 (4: 256 threads; 8: 512, round 5); SEG: class-major rows + virtual taps of a composite table (icn_upconv_*)
+template <int BM, int BN, bool SEG, bool SK, int NW = 4, int NT = 7>   // NW waves per workgroup as 2 x NW/2 (4: 256 threads; 8: 512, round 5); NT: taps of a plain launch (7; 1 = a dense GEMM through the plain code path, round 5); SEG: class-major rows + virtual taps of a composite table (icn_upconv_*)
 __device__ __forceinline__ void conv_dma_body(
     const float* __restrict__ src,      // (B, Ps, Ks)   Ks = K, or K / 2 with src2
     const float* __restrict__ src2,     // second half of the K axis (pair bwd-data), or null
@@ -450,7 +450,7 @@ __device__ __forceinline__ void conv_dma_body(
     // The plain instantiation (SEG = false) is the kernel of every ordinary convolution: 7 taps, rank == tap id, rows
     // m = b * Pd + q; all of the class-major machinery compiles away there.
     constexpr unsigned INVALID_ROW = 0xFFFFFFFFu;      // destination-row table: padding row (nothing is stored)
-    const int T = SEG ? T_arg : 7;
+    const int T = SEG ? T_arg : NT;
     constexpr int WC = NW / 2, NTHR = 64 * NW;         // waves along N (2 along M); threads
     constexpr int TM = BM / 64, TN = BN / (32 * WC);   // 32 x 32 MFMA tiles per wave
     constexpr int RA = BM / (8 * NW), RB = BN / (8 * NW);   // rows per lane (one 16-byte chunk of each)
@@ -458,7 +458,7 @@ __device__ __forceinline__ void conv_dma_body(
     static_assert(TN >= 1 && RA >= 1 && RB >= 1, "tile too small for this wave grid");
     constexpr int NDMA = RA + RB;                      // DMA instructions per wave per stage
     constexpr int RL = BM / 64;                        // tile rows per lane in the metadata pass (row r*64 + lane)
-    constexpr int NJ = 7 * RL;                         // code DMA instructions per tile (64 codes each)
+    constexpr int NJ = (SEG ? 7 : NT) * RL;            // code DMA instructions per tile (64 codes each)
     constexpr int JW = (NJ + NW - 1) / NW;             // ... per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);        // [3][BM*32]   3-stage ring
@@ -558,7 +558,7 @@ __device__ __forceinline__ void conv_dma_body(
     // Metadata of the block's FIRST tile, built synchronously with ordinary loads: row offsets, destination rows, bias.
     // (Later tiles: ICN_META_ISSUE / ICN_META_CONVERT below, by LDS-DMA, one tile ahead.)
     auto build_first = [&](int m0, int n0, unsigned mk) {
-        const int nt = SEG ? __popc(mk) : 7;
+        const int nt = SEG ? __popc(mk) : NT;
         for (int e = tid; e < nt * BM; e += NTHR) {
             const int t = SEG ? nth_tap(mk, e / BM) : e / BM, row = e % BM;
             int b, q;
@@ -577,7 +577,7 @@ __device__ __forceinline__ void conv_dma_body(
     // taps in use by a tile (stride-2 dgrad: rows are grouped by lattice parity class, a class uses 1-2 taps);
     // wave-uniform index => scalar loads
     auto tile_taps = [&](int m0) __attribute__((always_inline)) {
-        unsigned mk = 0x7f;
+        unsigned mk = SEG ? 0x7fu : (1u << NT) - 1u;
         if constexpr (SEG) {                             // the tile lies in one segment
             mk = segs.mask[0];
 #pragma unroll
@@ -670,7 +670,7 @@ __device__ __forceinline__ void conv_dma_body(
     unsigned tr_nseg = 0;
     if (trace) tr_t0 = __builtin_amdgcn_s_memrealtime();
     SkWalk skw{};                                         // (icn_streamk.h; plain ints: stays in scalar registers)
-    const int sk_S = (SEG ? __popc(segs.mask[0]) : 7) * nk;   // SK: K-steps of a tile (every tile of an SK launch runs the same taps)
+    const int sk_S = (SEG ? __popc(segs.mask[0]) : NT) * nk;   // SK: K-steps of a tile (every tile of an SK launch runs the same taps)
     if constexpr (SK) skw.init(blockIdx.x, gridDim.x, ntiles, sk_S, sk_mp, sk_bnd);
     auto seg_fetch = [&](int& tile_, int& s0_, int& s1_) __attribute__((always_inline)) { return skw.next(tile_, s0_, s1_); };
     int tile = blockIdx.x, m0, n0;
@@ -705,7 +705,7 @@ __device__ __forceinline__ void conv_dma_body(
     if constexpr (SK) has_next = seg_fetch(next_tile, n_s0, n_s1);
     int nm0 = m0, nn0 = n0;
     if (has_next) tile_origin(next_tile, nm0, nn0);
-    unsigned mask_c = tile_taps(m0), mask_n = has_next ? tile_taps(nm0) : 0x7fu;   // taps of the compute / next tile
+    unsigned mask_c = tile_taps(m0), mask_n = has_next ? tile_taps(nm0) : (SEG ? 0x7fu : (1u << NT) - 1u);   // taps of the compute / next tile
     if constexpr (!SK) {                                  // whole tiles: every step of the tile's taps
         c_s1 = __popc(mask_c) * nk;
         n_s1 = __popc(mask_n) * nk;
@@ -1093,6 +1093,24 @@ __global__ __launch_bounds__(256) void k_conv_dma_sk(const float* __restrict__ s
                                      src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
 }
 
+// A dense GEMM -- one "tap" whose gather is the identity: the decoder heads' z = x W (N = 7 C) and dx = g W (K = 7 C), DESIGN 4.2 --
+// through the PLAIN code path (SEG = false, NT = 1) instead of the class-major one (round 5): the plain K-loop is the one hipcc peels
+// and carries no segment tables, rank look-ups or per-tile tap counts.  Same arguments as k_conv_dma_sk.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv_dense_sk(const float* __restrict__ src, const float* __restrict__ src2,
+                                                        const float* __restrict__ wt, const float* __restrict__ bias,
+                                                        float* __restrict__ dst, float* __restrict__ dst2,
+                                                        const int32_t* __restrict__ dcode, const float* __restrict__ side,
+                                                        const float* __restrict__ side2, const int32_t* __restrict__ perm, int M, int Ps,
+                                                        int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes,
+                                                        unsigned side_bytes, int ntiles, int T_arg, const RowSegs segs, int sk_mp,
+                                                        float* __restrict__ sk_part, int* __restrict__ sk_flag,
+                                                        int* __restrict__ sk_status, int sk_spin_limit,
+                                                        unsigned long long* __restrict__ trace, const int* __restrict__ sk_bnd) {
+    conv_dma_body<BM, BN, false, true, 4, 1>(src, src2, wt, bias, dst, dst2, dcode, side, side2, nullptr, nullptr, M, Ps, Pd, K, N, N0, n_slots,
+                                             src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
+}
+
 // Eight waves per workgroup (2 x 4 waves of 32 x 32; round 5): the same tile, LDS image, ring and tables as the four-wave kernels, the
 // stage's DMA rows / metadata entries / epilogue columns dealt over twice the waves -- 3 instead of 6 DMA instructions and 16 instead
 // of 32 MFMAs per wave and K-step, four waves per SIMD at two workgroups per CU to cover each other's barriers and stage issues
@@ -1297,10 +1315,11 @@ static const int* sk_boundary_tables(int ntiles, int grid, int S, int occ) {
     return cache.emplace(key, d).first->second;
 }
 
-template <int BM, int BN, bool SEG, int NW = 4>
+template <int BM, int BN, bool SEG, int NW = 4, bool DENSE = false>
 static void launch_conv_dma_sk_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
     constexpr auto kern = [] {
-        if constexpr (NW == 8) return &k_conv_dma_sk8<BM, BN, SEG>;
+        if constexpr (DENSE) return &k_conv_dense_sk<BM, BN>;
+        else if constexpr (NW == 8) return &k_conv_dma_sk8<BM, BN, SEG>;
         else return &k_conv_dma_sk<BM, BN, SEG>;
     }();
     check_dma_ranges(a);
@@ -1317,13 +1336,15 @@ static void launch_conv_dma_sk_t(const GatherGemmArgs& a, int occ, hipStream_t s
     const int Ks = a.src2 ? a.K / 2 : a.K;
     const size_t nb = SEG ? (size_t)a.segs.B : (size_t)(a.M / a.Pd);
     const unsigned src_bytes = (unsigned)(nb * a.Ps * Ks * 4), side_bytes = (unsigned)(nb * a.n_slots * Ks * 4);
-    prof_mark_begin(NW == 8 ? (SEG ? PROF_DMAKS8_64x128 : PROF_DMAK8_64x128) : (SEG ? PROF_DMAKS_64x128 : PROF_DMAK_64x128) + (BN == 128 ? 0 : 1),
+    prof_mark_begin(DENSE ? PROF_DENSEK_64x128 + (BN == 128 ? 0 : 1)
+                          : NW == 8 ? (SEG ? PROF_DMAKS8_64x128 : PROF_DMAK8_64x128) : (SEG ? PROF_DMAKS_64x128 : PROF_DMAK_64x128) + (BN == 128 ? 0 : 1),
                     a.algo_flops, s);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,
                        a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.M, a.Ps, a.Pd, a.K,
                        a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, a.T > 0 ? a.T : 7, a.segs, CONV_SK_MIN_PIECE,
                        a.sk_part, a.sk_flag, device_status_word(), (dbg_flags() & 256) ? -1 : ((1 << 22) | ((dbg_flags() & 8192) ? (1 << 28) : 0)),
-                       g_trace_cap >= (size_t)grid * 8 ? g_trace : nullptr, sk_boundary_tables(ntiles, grid, conv_sk_steps(a), occ));
+                       g_trace_cap >= (size_t)grid * 8 ? g_trace : nullptr,
+                       sk_boundary_tables(ntiles, grid, DENSE ? a.K / BK : conv_sk_steps(a), occ));
     prof_mark_end(s);
 }
 
@@ -1346,9 +1367,20 @@ static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
     launch_conv_dma_t<BM, BN, true, NW>(b, occ, s);
 }
 
+// dense one-tap GEMM with identity rows (conv_sk_eligible's second form): runs through the plain code path unless debug flag 32768
+// (tests, A/B) keeps it on the class-major one
+static bool conv_dense_plain(const GatherGemmArgs& a) {
+    return a.segs.nseg == 1 && a.T == 1 && a.segs.mask[0] == 1u && a.perm == nullptr && a.segs.off[0] == 0 && a.segs.cnt[0] == a.Pd &&
+           a.mask32 == nullptr && a.n_slots == 0 && a.src2 == nullptr && a.M == a.segs.B * a.Pd && !(dbg_flags() & 32768);
+}
 template <int BM, int BN, int NW = 4>
 static void launch_conv_dma_sk(const GatherGemmArgs& a, int occ, hipStream_t s) {
     if (a.segs.nseg == 0) return launch_conv_dma_sk_t<BM, BN, false, NW>(a, occ, s);
+    if (NW == 4 && conv_dense_plain(a)) {
+        GatherGemmArgs d = a;                             // rows m = b * Pd + q as in a convolution; stores past M are range-checked away
+        d.segs = RowSegs{};
+        return launch_conv_dma_sk_t<BM, BN, false, 4, true>(d, occ, s);
+    }
     GatherGemmArgs b = a;
     b.M = (int)seg_rows(a.segs, BM, b.segs.row0);
     launch_conv_dma_sk_t<BM, BN, true, NW>(b, occ, s);

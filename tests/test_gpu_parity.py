@@ -296,8 +296,9 @@ def test_stream_k_equals_whole_tile_schedule(r, cin, cout, B, pair):
 
 @pytest.mark.parametrize('r,cin,cout,B', [(2, 256, 256, 36), (3, 256, 128, 36), (4, 128, 64, 9)])
 def test_stream_k_in_the_decoder_heads_dense_gemms(r, cin, cout, B):
-    """The one-tap dense GEMMs of icn_upconv_fwd / icn_upconv_bwd (k_conv_dma_sk<.., true>: class-major rows, destination
-    rows through the permutation table) against the whole-tile schedule, new data each trial."""
+    """The one-tap dense GEMMs of icn_upconv_fwd / icn_upconv_bwd in their stream-K form -- since round 5 on the plain code path
+    (k_conv_dense_sk: SEG = false with one tap), under debug flag 32768 on the class-major one (k_conv_dma_sk<.., true>) -- against
+    the whole-tile schedule (flag 128: k_conv_dma<.., true>), new data each trial."""
     from geniconet_amd import _lib
     from geniconet_amd.ico_conv import ico_upconv_pair
     g = torch.Generator().manual_seed(r * 7 + cin)
@@ -331,7 +332,11 @@ def test_stream_k_in_the_decoder_heads_dense_gemms(r, cin, cout, B):
         again, _ = run(0, x, gy)
         for a, b in zip(got, again):
             assert torch.equal(a, b), trial
-    assert any(k.startswith('k_conv_dma_sk') and k.endswith('true>') for k in seen), seen
+        cm, k_cm = run(32768, x, gy)                              # the class-major stream-K kernel: another split of K, same sums
+        assert any(k.startswith('k_conv_dma_sk') and k.endswith('true>') for k in k_cm) and not any('dense' in k for k in k_cm), k_cm
+        for a, b in zip(cm, want):
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, trial
+    assert any(k.startswith('k_conv_dense_sk') for k in seen), seen
 
 
 @pytest.mark.parametrize('r,cin,cout,B,pair', [(4, 128, 256, 36, True), (5, 64, 128, 12, True), (3, 256, 256, 36, False), (3, 256, 512, 5, True)])
@@ -953,7 +958,8 @@ def test_upconv_pair_matches_oracle_upsample_then_convs(case):
     _lib.profile_start(64)
     yg = ico_upconv_pair(xg, wg[0], bg[0], wg[1], bg[1], r, mode)
     prof = _lib.profile_stop()
-    assert sum(e['launches'] for e in prof) == 1 and prof[0]['kernel'].startswith('k_conv_dma') and 'true' in prof[0]['kernel'], prof
+    assert sum(e['launches'] for e in prof) == 1 and (prof[0]['kernel'].startswith('k_conv_dense') or
+                                                      (prof[0]['kernel'].startswith('k_conv_dma') and 'true' in prof[0]['kernel'])), prof
     torch.autograd.backward(yg, [gy.cuda() for gy in gys])
     pairs = {'y0': (yg[0], yr[0]), 'y1': (yg[1], yr[1]), 'dx': (xg.grad, xr.grad), 'dw0': (wg[0].grad, wr[0].grad),
              'dw1': (wg[1].grad, wr[1].grad)}
