@@ -1093,6 +1093,24 @@ __global__ __launch_bounds__(256) void k_conv_dma_sk(const float* __restrict__ s
                                      src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
 }
 
+// A SINGLE convolution (one source tensor, one destination: src2 = dst2 = side2 = null) through a wrapper that says so at compile
+// time (round 5): the pair forms' second buffer resources, the per-step resource selects and the epilogue's second-tensor test
+// compile away, as the row permutation and the tap masks already do in k_conv_dma_sk.  Same arguments as k_conv_dma_sk.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv_single_sk(const float* __restrict__ src, const float* __restrict__ src2,
+                                                         const float* __restrict__ wt, const float* __restrict__ bias,
+                                                         float* __restrict__ dst, float* __restrict__ dst2,
+                                                         const int32_t* __restrict__ dcode, const float* __restrict__ side,
+                                                         const float* __restrict__ side2, const int32_t* __restrict__ perm, int M, int Ps,
+                                                         int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes,
+                                                         unsigned side_bytes, int ntiles, int T_arg, const RowSegs segs, int sk_mp,
+                                                         float* __restrict__ sk_part, int* __restrict__ sk_flag,
+                                                         int* __restrict__ sk_status, int sk_spin_limit,
+                                                         unsigned long long* __restrict__ trace, const int* __restrict__ sk_bnd) {
+    conv_dma_body<BM, BN, false, true>(src, nullptr, wt, bias, dst, nullptr, dcode, side, nullptr, nullptr, nullptr, M, Ps, Pd, K, N, N, n_slots,
+                                       src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
+}
+
 // A dense GEMM -- one "tap" whose gather is the identity: the decoder heads' z = x W (N = 7 C) and dx = g W (K = 7 C), DESIGN 4.2 --
 // through the PLAIN code path (SEG = false, NT = 1) instead of the class-major one (round 5): the plain K-loop is the one hipcc peels
 // and carries no segment tables, rank look-ups or per-tile tap counts.  Same arguments as k_conv_dma_sk.
@@ -1317,26 +1335,33 @@ static const int* sk_boundary_tables(int ntiles, int grid, int S, int occ) {
 
 template <int BM, int BN, bool SEG, int NW = 4, bool DENSE = false>
 static void launch_conv_dma_sk_t(const GatherGemmArgs& a, int occ, hipStream_t s) {
-    constexpr auto kern = [] {
+    constexpr auto kern_general = [] {
         if constexpr (DENSE) return &k_conv_dense_sk<BM, BN>;
         else if constexpr (NW == 8) return &k_conv_dma_sk8<BM, BN, SEG>;
         else return &k_conv_dma_sk<BM, BN, SEG>;
     }();
+    // single convolutions (no second source / destination) take the wrapper that knows it (debug flag 65536: the general kernel)
+    const bool single = !SEG && !DENSE && NW == 4 && a.src2 == nullptr && a.dst2 == nullptr && !(dbg_flags() & 65536);
+    auto kern = kern_general;
+    if constexpr (!SEG && !DENSE && NW == 4) {
+        if (single) kern = &k_conv_single_sk<BM, BN>;
+    }
     check_dma_ranges(a);
     const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);   // SEG: M is the padded row count
     const int grid = 256 * occ;                           // every block slot of the chip: all of them resident at once
     if ((size_t)grid * BM * BN * sizeof(float) > conv_sk_part_bytes() || grid > CONV_SK_ERROR)
         throw std::invalid_argument("icn: stream-K grid beyond its scratch");
     const size_t lds = conv_dma_lds(BM, BN, a.perm != nullptr, a.bias != nullptr);
-    static std::atomic<uint64_t> attr_devices{0};
-    if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
+    static std::atomic<uint64_t> attr_devices[2] = {{0}, {0}};          // LDS opt-in, once per device and kernel (general / single)
+    if (!((attr_devices[single].load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
+        attr_devices[single].fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
     }
     const int Ks = a.src2 ? a.K / 2 : a.K;
     const size_t nb = SEG ? (size_t)a.segs.B : (size_t)(a.M / a.Pd);
     const unsigned src_bytes = (unsigned)(nb * a.Ps * Ks * 4), side_bytes = (unsigned)(nb * a.n_slots * Ks * 4);
     prof_mark_begin(DENSE ? PROF_DENSEK_64x128 + (BN == 128 ? 0 : 1)
+                          : single ? PROF_SINGLEK_64x128 + (BN == 128 ? 0 : 1)
                           : NW == 8 ? (SEG ? PROF_DMAKS8_64x128 : PROF_DMAK8_64x128) : (SEG ? PROF_DMAKS_64x128 : PROF_DMAK_64x128) + (BN == 128 ? 0 : 1),
                     a.algo_flops, s);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,

@@ -223,7 +223,7 @@ def test_tensors_beyond_2gib_take_the_fallback_kernels_and_agree_with_half_batch
     dw_sum, db_sum = torch.zeros_like(dw), torch.zeros_like(db)
     for lo in (0, h):
         (yh, dxh, dwh, dbh), half = kernels(run, x[lo:lo + h], gy[lo:lo + h])
-        assert {k.rstrip('8') for k in half} == {'k_conv_dma', 'k_wgrad7'}, half   # the production kernels (either wave count)
+        assert {k.rstrip('8').replace('k_conv_single_sk', 'k_conv_dma').replace('k_conv_dma_sk', 'k_conv_dma') for k in half} == {'k_conv_dma', 'k_wgrad7'}, half   # the production kernels
         assert close(y[lo:lo + h], yh) and close(dx[lo:lo + h], dxh)
         dw_sum += dwh
         db_sum += dbh
@@ -239,6 +239,11 @@ def test_tensors_beyond_2gib_take_the_fallback_kernels_and_agree_with_half_batch
 # a fixed order.  Shapes chosen to hit each plan at batch 36: 2.8 rounds of 64x128 tiles (r = 4, 128 -> 128), fewer tiles than
 # block slots (r = 2, 256 -> 256: 360 tiles, every tile shared by 2-3 blocks), a pair (two outputs / two gradient tensors),
 # 7.5 rounds of 64x64 tiles with two k-chunks per tile (r = 5, 64 -> 64, batch 12: 2.5 rounds).
+def _is_stream_k(kernel):
+    """The stream-K forms of the persistent GEMM: the general kernel and its compile-time specialisations (round 5)."""
+    return kernel.startswith(('k_conv_dma_sk', 'k_conv_single_sk', 'k_conv_dense_sk'))
+
+
 SK_CASES = [(4, 128, 128, 36, False), (2, 256, 256, 36, False), (3, 128, 128, 36, True), (5, 64, 64, 12, False), (3, 256, 256, 7, False)]
 
 
@@ -277,7 +282,7 @@ def test_stream_k_equals_whole_tile_schedule(r, cin, cout, B, pair):
         gy = [torch.randn(B, cout, 5 * n, 2 * n, generator=g).cuda() for _ in range(2)]
         got, k_sk = run(0)
         want, k_plain = run(128)
-        assert any(k.startswith('k_conv_dma_sk') for k in k_sk) and not any(k.startswith('k_conv_dma_sk') for k in k_plain), (k_sk, k_plain)
+        assert any(_is_stream_k(k) for k in k_sk) and not any(_is_stream_k(k) for k in k_plain), (k_sk, k_plain)
         for a, b in zip(got, want):
             assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, trial
         again, _ = run(0)                                    # fixed summation order: bit-identical when repeated
@@ -287,7 +292,7 @@ def test_stream_k_equals_whole_tile_schedule(r, cin, cout, B, pair):
         # partners' pieces long parked, here it really spins on their flags -- the hand-off (system-scope slot stores complete
         # before the flag is raised, slot loads issued after the flag was seen) must give the same bits
         slow, k_slow = run(8192)
-        assert any(k.startswith('k_conv_dma_sk') for k in k_slow)
+        assert any(_is_stream_k(k) for k in k_slow)
         for a, b in zip(got, slow):
             assert torch.equal(a, b), trial
     from geniconet_amd import _lib as lib_
@@ -326,7 +331,7 @@ def test_stream_k_in_the_decoder_heads_dense_gemms(r, cin, cout, B):
         got, k_sk = run(0, x, gy)
         want, k_plain = run(128, x, gy)
         seen |= k_sk
-        assert not any(k.startswith('k_conv_dma_sk') for k in k_plain), k_plain
+        assert not any(_is_stream_k(k) for k in k_plain), k_plain
         for a, b in zip(got, want):
             assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, trial
         again, _ = run(0, x, gy)
@@ -400,6 +405,32 @@ def test_lds_staged_sparse_passes_equal_the_row_per_thread_kernels(r, cin, cout,
     for a, b in zip(new, ref):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
         assert bool(torch.isfinite(a).all())
+
+
+def test_the_single_convolution_wrapper_equals_the_general_stream_k_kernel():
+    """k_conv_single_sk (round 5: src2 = dst2 = side2 = null known at compile time) against k_conv_dma_sk<.., false> (debug flag
+    65536): the same instructions minus the pair forms' selects -- forward and data gradient bit-identical."""
+    from geniconet_amd import _lib
+    from geniconet_amd.ico_conv import ico_conv
+    g = torch.Generator().manual_seed(5)
+    for r, cin, cout, B in ((4, 128, 128, 36), (2, 256, 256, 36), (5, 64, 64, 12)):
+        n = 2 ** r
+        x = torch.randn(B, cin, 5 * n, 2 * n, generator=g).cuda().requires_grad_()
+        w = (torch.randn(cout, cin, 7, generator=g) / (7 * cin) ** 0.5).cuda()
+        b = torch.randn(cout, generator=g).cuda()
+        res = {}
+        for flags in (0, 65536):
+            old = _lib.lib().icn_set_debug_flags(flags)
+            try:
+                _lib.profile_start(64)
+                y = ico_conv(x, w, b, r, 1, 'average')
+                dx, = torch.autograd.grad(y, x, torch.ones_like(y) * 0.25)
+                names = {e['kernel'].split('<')[0] for e in _lib.profile_stop()}
+            finally:
+                _lib.lib().icn_set_debug_flags(old)
+            res[flags] = (y.detach().clone(), dx.clone(), names)
+        assert 'k_conv_single_sk' in res[0][2] and 'k_conv_single_sk' not in res[65536][2] and 'k_conv_dma_sk' in res[65536][2], (res[0][2], res[65536][2])
+        assert torch.equal(res[0][0], res[65536][0]) and torch.equal(res[0][1], res[65536][1])
 
 
 EIGHT_WAVE_CASES = [(4, 128, 128, 36, False), (3, 256, 256, 7, False), (2, 256, 256, 36, False), (3, 128, 128, 5, True)]
