@@ -740,7 +740,7 @@ __device__ __forceinline__ void conv_dma_body(
             bool side_row = false; \
 _Pragma("unroll") \
             for (int i = 0; i < RA; ++i) side_row |= (int)pbase[i] < (int)NOTHING_OFFSET; \
-            if ((ICN_EXP & 4) || __builtin_amdgcn_ballot_w64(side_row) == 0) { \
+            if ((ICN_EXP & 4) || side == nullptr || __builtin_amdgcn_ballot_w64(side_row) == 0) {   /* (no side buffer: no row can name one) */ \
 _Pragma("unroll") \
                 for (int i = 0; i < RA; ++i) { \
                     float* lds_dst = As + __builtin_amdgcn_readfirstlane(i_ring * BM * BK + 8 * (wave + NW * i) * BK); \
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_conv_dense_sk(const float* __restrict__
                                                         float* __restrict__ sk_part, int* __restrict__ sk_flag,
                                                         int* __restrict__ sk_status, int sk_spin_limit,
                                                         unsigned long long* __restrict__ trace, const int* __restrict__ sk_bnd) {
-    conv_dma_body<BM, BN, false, true, 4, 1>(src, src2, wt, bias, dst, dst2, dcode, side, side2, nullptr, nullptr, M, Ps, Pd, K, N, N0, n_slots,
+    conv_dma_body<BM, BN, false, true, 4, 1>(src, nullptr, wt, bias, dst, nullptr, dcode, nullptr, nullptr, nullptr, nullptr, M, Ps, Pd, K, N, N, 0,
                                              src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
 }
 
