@@ -223,7 +223,7 @@ def test_tensors_beyond_2gib_take_the_fallback_kernels_and_agree_with_half_batch
     dw_sum, db_sum = torch.zeros_like(dw), torch.zeros_like(db)
     for lo in (0, h):
         (yh, dxh, dwh, dbh), half = kernels(run, x[lo:lo + h], gy[lo:lo + h])
-        assert {k.rstrip('8').replace('k_conv_single_sk', 'k_conv_dma').replace('k_conv_dma_sk', 'k_conv_dma') for k in half} == {'k_conv_dma', 'k_wgrad7'}, half   # the production kernels
+        assert {_family(k) for k in half} == {'k_conv_dma', 'k_wgrad7'}, half      # the production kernels
         assert close(y[lo:lo + h], yh) and close(dx[lo:lo + h], dxh)
         dw_sum += dwh
         db_sum += dbh
@@ -239,9 +239,15 @@ def test_tensors_beyond_2gib_take_the_fallback_kernels_and_agree_with_half_batch
 # a fixed order.  Shapes chosen to hit each plan at batch 36: 2.8 rounds of 64x128 tiles (r = 4, 128 -> 128), fewer tiles than
 # block slots (r = 2, 256 -> 256: 360 tiles, every tile shared by 2-3 blocks), a pair (two outputs / two gradient tensors),
 # 7.5 rounds of 64x64 tiles with two k-chunks per tile (r = 5, 64 -> 64, batch 12: 2.5 rounds).
+def _family(kernel):
+    """The LDS-DMA conv GEMM and its compile-time specialisations (round 5) under one name."""
+    k = kernel.split('<')[0].rstrip('8')
+    return 'k_conv_dma' if k in ('k_conv_dma', 'k_conv_dma_sk', 'k_conv_single_sk', 'k_conv_pairfwd_sk', 'k_conv_dense_sk', 'k_conv_dgrad_masked') else k
+
+
 def _is_stream_k(kernel):
     """The stream-K forms of the persistent GEMM: the general kernel and its compile-time specialisations (round 5)."""
-    return kernel.startswith(('k_conv_dma_sk', 'k_conv_single_sk', 'k_conv_dense_sk'))
+    return kernel.startswith(('k_conv_dma_sk', 'k_conv_single_sk', 'k_conv_pairfwd_sk', 'k_conv_dense_sk'))
 
 
 SK_CASES = [(4, 128, 128, 36, False), (2, 256, 256, 36, False), (3, 128, 128, 36, True), (5, 64, 64, 12, False), (3, 256, 256, 7, False)]
