@@ -460,6 +460,9 @@ __device__ __forceinline__ void conv_dma_body(
     constexpr int RL = BM / 64;                        // tile rows per lane in the metadata pass (row r*64 + lane)
     constexpr int NJ = (SEG ? 7 : NT) * RL;            // code DMA instructions per tile (64 codes each)
     constexpr int JW = (NJ + NW - 1) / NW;             // ... per wave
+    // NT = 1 is the dense GEMM with identity rows (k_conv_dense_sk; launcher: conv_dense_plain): GEMM row m reads source row m, so
+    // the row offsets are arithmetic -- no gather codes, no offset table, no per-tile metadata DMA + convert (round 5).
+    constexpr bool IDENT = !SEG && NT == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);        // [3][BM*32]   3-stage ring
     float* Bs = As + 3 * BM * BK;                      // [3][BN*32]
@@ -555,10 +558,15 @@ __device__ __forceinline__ void conv_dma_body(
              : c == -1 ? NOTHING_OFFSET
                        : SIDE_FLAG | ((unsigned)(b * n_slots + (-2 - c)) * (unsigned)Ks * 4u);
     };
+    // IDENT: byte offset of the lane's i-th row of the tile starting at GEMM row mbase
+    auto ident_offset = [&](int mbase, int i) __attribute__((always_inline)) {
+        const int m = mbase + 8 * (wave + NW * i) + rsub;
+        return m < M ? (unsigned)m * (unsigned)Ks * 4u : NOTHING_OFFSET;
+    };
     // Metadata of the block's FIRST tile, built synchronously with ordinary loads: row offsets, destination rows, bias.
     // (Later tiles: ICN_META_ISSUE / ICN_META_CONVERT below, by LDS-DMA, one tile ahead.)
     auto build_first = [&](int m0, int n0, unsigned mk) {
-        const int nt = SEG ? __popc(mk) : NT;
+        const int nt = IDENT ? 0 : (SEG ? __popc(mk) : NT);
         for (int e = tid; e < nt * BM; e += NTHR) {
             const int t = SEG ? nth_tap(mk, e / BM) : e / BM, row = e % BM;
             int b, q;
@@ -722,7 +730,7 @@ __device__ __forceinline__ void conv_dma_body(
     int i_left = c_s1 - c_s0, i_ring = 0, i_own = 1, i_live = 1;   // steps left in the pointer's segment; i_own: inside compute tile
     unsigned pbase[RA];                                   // row offsets of the next stage to be issued (prefetched)
 #pragma unroll
-    for (int i = 0; i < RA; ++i) pbase[i] = otab[(SEG ? 0 : i_t) * BM + 8 * (wave + NW * i) + rsub];   // SEG: rank 0
+    for (int i = 0; i < RA; ++i) pbase[i] = IDENT ? ident_offset(m0, i) : otab[(SEG ? 0 : i_t) * BM + 8 * (wave + NW * i) + rsub];   // SEG: rank 0
     int issued = 0, p_exact = 1;
     int mb[RL];                                           // metadata pass: sample of the lane's rows in the next tile, or -1
     // Issue the stage under the DMA pointer, advance the pointer, prefetch the next stage's row offsets.
@@ -783,7 +791,7 @@ _Pragma("unroll") \
                 const int rk_ = SEG ? __popc(mr_ & ((1u << i_t) - 1u)) : i_t;   /* row of the offset table */ \
                 const int tb = __builtin_amdgcn_readfirstlane(((i_own ? slot : slot ^ 1) * 7 + rk_) * BM); \
 _Pragma("unroll") \
-                for (int i = 0; i < RA; ++i) pbase[i] = otab[tb + 8 * (wave + NW * i) + rsub]; \
+                for (int i = 0; i < RA; ++i) pbase[i] = IDENT ? ident_offset(i_own ? m0 : nm0, i) : otab[tb + 8 * (wave + NW * i) + rsub]; \
             } \
         } \
     } while (0)
@@ -792,7 +800,7 @@ _Pragma("unroll") \
     // destination-row permutation, the last BN / 64 waves the bias.
 #define ICN_META_ISSUE() do { \
         const int ne_ = __builtin_amdgcn_readfirstlane(eslot == 2 ? 0 : eslot + 1); \
-        const int nj_ = SEG ? __builtin_amdgcn_readfirstlane(__popc(mask_n) * RL) : NJ;   /* SEG: the next tile's taps only */ \
+        const int nj_ = IDENT ? 0 : (SEG ? __builtin_amdgcn_readfirstlane(__popc(mask_n) * RL) : NJ);   /* SEG: the next tile's taps only */ \
         int mp_[RL]; \
 _Pragma("unroll") \
         for (int r = 0; r < RL; ++r) decode_row(nm0 + r * 64 + lane, mb[r], mp_[r]); \
@@ -825,7 +833,7 @@ _Pragma("unroll") \
     // lane that fetched them; the step's barrier publishes the tables.
 #define ICN_META_CONVERT() do { \
         const int ne_ = eslot == 2 ? 0 : eslot + 1; \
-        const int nj_ = SEG ? __builtin_amdgcn_readfirstlane(__popc(mask_n) * RL) : NJ; \
+        const int nj_ = IDENT ? 0 : (SEG ? __builtin_amdgcn_readfirstlane(__popc(mask_n) * RL) : NJ); \
 _Pragma("unroll") \
         for (int jj = 0; jj < JW; ++jj) { \
             const int j = wave + NW * jj; \
@@ -1396,7 +1404,7 @@ static void launch_conv_dma(const GatherGemmArgs& a, int occ, hipStream_t s) {
 // (tests, A/B) keeps it on the class-major one
 static bool conv_dense_plain(const GatherGemmArgs& a) {
     return a.segs.nseg == 1 && a.T == 1 && a.segs.mask[0] == 1u && a.perm == nullptr && a.segs.off[0] == 0 && a.segs.cnt[0] == a.Pd &&
-           a.mask32 == nullptr && a.n_slots == 0 && a.src2 == nullptr && a.M == a.segs.B * a.Pd && !(dbg_flags() & 32768);
+           a.mask32 == nullptr && a.n_slots == 0 && a.src2 == nullptr && a.M == a.segs.B * a.Pd && a.Ps == a.Pd && !(dbg_flags() & 32768);
 }
 template <int BM, int BN, int NW = 4>
 static void launch_conv_dma_sk(const GatherGemmArgs& a, int occ, hipStream_t s) {
