@@ -689,7 +689,8 @@ const char* const PROF_NAMES[PROF_KINDS] = {"k_conv_dma<128, 128, false>", "k_co
                                             "k_conv_dma_sk<64, 64, true>", "k_wgrad7",
                                             "k_conv_dma8<64, 128, false>", "k_conv_dma8<64, 128, true>", "k_conv_dma_sk8<64, 128, false>",
                                             "k_conv_dma_sk8<64, 128, true>", "k_conv_dense_sk<64, 128>", "k_conv_dense_sk<64, 64>", "k_conv_single_sk<64, 128>",
-                                            "k_conv_single_sk<64, 64>"};
+                                            "k_conv_single_sk<64, 64>", "k_wgrad_dense<128, 128>", "k_wgrad_dense<128, 64>",
+                                            "k_wgrad_dense<64, 128>", "k_wgrad_dense<64, 64>"};
 void prof_mark_begin(int kind, double flops, hipStream_t s) {
     if (!g_prof_on) return;
     g_prof_mu.lock();

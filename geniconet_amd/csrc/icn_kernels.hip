@@ -1679,8 +1679,8 @@ __global__ __launch_bounds__(256) void k_wgrad(
 // ---------------------------------------------------------------------------------------------------------
 constexpr int WG_RS = 16;   // rows per stage
 
-template <int BI, int BJ>
-__global__ __launch_bounds__(256) void k_wgrad_dma(
+template <int BI, int BJ, bool DENSE>
+__device__ __forceinline__ void wgrad_dma_body(
     const float* __restrict__ x,        // (B, Ps, Cin)
     const float* __restrict__ dy,       // (B, Pd, Cout0)
     const float* __restrict__ dy2,      // (B, Pd, Cout - Cout0): output channels Cout0.. (pair sharing x), or null
@@ -1764,7 +1764,7 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
     // rows past m_end are sorted out in ICN_WG_MAKE_OFFSETS)
 #define ICN_WG_FETCH_CODES() do { \
         _Pragma("unroll") \
-        for (int i = 0; i < NA; ++i) { \
+        for (int i = 0; i < (DENSE ? 0 : NA); ++i) { \
             int32_t* dst_ = Cs + __builtin_amdgcn_readfirstlane(((c_slot * 4 + wave) * NA + i) * 64); \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)dst_, 4, (unsigned)c_p[i] * 4u, 0, 0, 0); \
         } \
@@ -1773,7 +1773,7 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
 #define ICN_WG_ADVANCE_CODE_PTR() do { \
         c_m0 += WG_RS; \
         _Pragma("unroll") \
-        for (int i = 0; i < NA; ++i) { c_p[i] += WG_RS; while (c_p[i] >= Pd) { c_p[i] -= Pd; c_b[i] += 1; } } \
+        for (int i = 0; i < (DENSE ? 0 : NA); ++i) { c_p[i] += WG_RS; while (c_p[i] >= Pd) { c_p[i] -= Pd; c_b[i] += 1; } } \
     } while (0)
     // codes (fetched one step ago into slot c_slot ^ 1, landed and retired by that step's counted wait) -> byte offsets;
     // uses the row state BEFORE it is advanced; bit 31: side buffer (pole mean) or nothing
@@ -1781,6 +1781,10 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
         _Pragma("unroll") \
         for (int i = 0; i < NA; ++i) { \
             const int m = c_m0 + (wave + 4 * i) * RPA + arow; \
+            if constexpr (DENSE) { \
+                aoff[i] = m < m_end ? ((unsigned)m * (unsigned)Cin + (unsigned)(ci0 + 4 * achunk)) * 4u : NOTHING_OFFSET; \
+                continue; \
+            } \
             const int32_t c = m < m_end ? Cs[(((c_slot ^ 1) * 4 + wave) * NA + i) * 64 + lane] : -1; \
             aoff[i] = c >= 0 ? ((unsigned)(c_b[i] * Ps + c) * (unsigned)Cin + (unsigned)(ci0 + 4 * achunk)) * 4u \
                     : c == -1 ? NOTHING_OFFSET \
@@ -1794,8 +1798,8 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
         if (issued) { \
             bool side_row = false; \
             _Pragma("unroll") \
-            for (int i = 0; i < NA; ++i) side_row |= (int)aoff[i] < (int)NOTHING_OFFSET; \
-            if ((ICN_EXP & 4) || __builtin_amdgcn_ballot_w64(side_row) == 0) { \
+            for (int i = 0; i < (DENSE ? 0 : NA); ++i) side_row |= (int)aoff[i] < (int)NOTHING_OFFSET; \
+            if (DENSE || (ICN_EXP & 4) || __builtin_amdgcn_ballot_w64(side_row) == 0) { \
                 _Pragma("unroll") \
                 for (int i = 0; i < NA; ++i) { \
                     float* dst_ = Xs + __builtin_amdgcn_readfirstlane(d_ring * WG_RS * BI + (wave + 4 * i) * RPA * BI); \
@@ -1901,6 +1905,27 @@ __global__ __launch_bounds__(256) void k_wgrad_dma(
         o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);
     }
 #endif
+}
+
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void k_wgrad_dma(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ dy2,
+                                                   const int32_t* __restrict__ dcode, const float* __restrict__ side,
+                                                   float* __restrict__ partial, float* __restrict__ bias_partial, int M, int Ps, int Pd,
+                                                   int Cin, int Cout, int Cout0, int n_slots, int rows_per_split, int n_splits,
+                                                   unsigned x_bytes, unsigned side_bytes, int y_taps, unsigned long long* __restrict__ trace) {
+    wgrad_dma_body<BI, BJ, false>(x, dy, dy2, dcode, side, partial, bias_partial, M, Ps, Pd, Cin, Cout, Cout0, n_slots, rows_per_split,
+                                  n_splits, x_bytes, side_bytes, y_taps, trace);
+}
+
+// k_wgrad_dense: the decoder heads' dW_t = sum_s x[s]^T g_t[s] (y_taps = 7, identity rows, no pole means) through the same body with
+// the gather compiled away: row offsets are arithmetic, so the code DMAs, their LDS read-back and the side-row vote are gone.
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void k_wgrad_dense(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial,
+                                                     float* __restrict__ bias_partial, int M, int P, int Cin, int Cout, int Cout0,
+                                                     int rows_per_split, int n_splits, unsigned x_bytes,
+                                                     unsigned long long* __restrict__ trace) {
+    wgrad_dma_body<BI, BJ, true>(x, g, nullptr, nullptr, nullptr, partial, bias_partial, M, P, P, Cin, Cout, Cout0, 0, rows_per_split,
+                                 n_splits, x_bytes, 0u, 7, trace);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2497,9 +2522,16 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         // chain's HBM-bound passes registers to run beside it on the second stream (three workgroups of 168 registers fill a SIMD)
         static const int occ_cap = getenv("ICN_WG_OCC") ? atoi(getenv("ICN_WG_OCC")) : 0;
         const size_t lds_dma = std::max(wgrad_lds(BI, BJ, true), occ_cap == 2 ? (size_t)(160 * 1024 / 3 + 1024) : (size_t)0);
+        // the decoder heads' dense dW (identity rows, tap-major g, no pole means): the body with the gather compiled away
+        static const bool dense_env = !(getenv("ICN_WG_DENSE") && atoi(getenv("ICN_WG_DENSE")) == 0);   // developer A/B
+        const bool dense = dense_env && dma && a.y_taps == 7 && a.n_slots == 0 && a.Ps == a.Pd && a.dy2 == nullptr && !(dbg_flags() & 32768);
 #define ICN_WG(I, J)                                                                                                       \
     do {                                                                                                                   \
-        if (dma)                                                                                                           \
+        if (dense)                                                                                                         \
+            hipLaunchKernelGGL((k_wgrad_dense<I, J>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.partial, a.bias_partial, a.M,  \
+                               a.Pd, a.Cin, a.Cout, a.Cout, rows, S, (unsigned)x_bytes,                                     \
+                               g_trace_cap >= (size_t)grid.x * 8 ? g_trace : nullptr);                                      \
+        else if (dma)                                                                                                      \
             hipLaunchKernelGGL((k_wgrad_dma<I, J>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.dy2, a.dcode,                  \
                                a.n_slots > 0 ? a.side : nullptr, a.partial, a.bias_partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout,   \
                                a.y_taps ? a.Cout : Cout0, a.n_slots, rows, S, (unsigned)x_bytes, (unsigned)side_bytes, a.y_taps, \
@@ -2508,8 +2540,9 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M,   \
                                a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows, S);                                                  \
     } while (0)
-        prof_mark_begin((bi128 ? (bj128 ? PROF_WG_128x128 : PROF_WG_128x64) : (bj128 ? PROF_WG_64x128 : PROF_WG_64x64)) -
-                            (dma ? PROF_WG_128x128 - PROF_WGD_128x128 : 0),
+        prof_mark_begin(dense ? (bi128 ? (bj128 ? PROF_WGDENSE_128x128 : PROF_WGDENSE_128x64) : (bj128 ? PROF_WGDENSE_64x128 : PROF_WGDENSE_64x64))
+                              : (bi128 ? (bj128 ? PROF_WG_128x128 : PROF_WG_128x64) : (bj128 ? PROF_WG_64x128 : PROF_WG_64x64)) -
+                                    (dma ? PROF_WG_128x128 - PROF_WGD_128x128 : 0),
                         a.algo_flops, s);
         if (bi128 && bj128) ICN_WG(128, 128);
         else if (bi128) ICN_WG(128, 64);

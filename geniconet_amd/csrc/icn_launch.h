@@ -220,6 +220,7 @@ enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA
                 PROF_DMA8_64x128, PROF_DMAS8_64x128, PROF_DMAK8_64x128, PROF_DMAKS8_64x128,  // eight-wave forms of the 64 x 128 tile
                 PROF_DENSEK_64x128, PROF_DENSEK_64x64,       // k_conv_dense_sk: one-tap dense GEMMs on the plain path
                 PROF_SINGLEK_64x128, PROF_SINGLEK_64x64,     // k_conv_single_sk: single convolutions (no second tensors)
+                PROF_WGDENSE_128x128, PROF_WGDENSE_128x64, PROF_WGDENSE_64x128, PROF_WGDENSE_64x64,   // k_wgrad_dense: the heads' dW = x^T g
                 PROF_KINDS };
 extern const char* const PROF_NAMES[PROF_KINDS];
 void prof_mark_begin(int kind, double flops, hipStream_t s);   // no-ops unless profiling is on

@@ -279,7 +279,8 @@ int icn_profile_select(const char* kernel);
  * stream-K finisher reports its partners lost), 2048 / 4096 = every weight gradient on the per-tap kernel / stride-2 weight gradients on
  * k_wgrad7 too, 8192 = slow stream-K partners (tests of the hand-off), 16384 = the 64 x 128 tile's launches on the eight-wave kernels
  * k_conv_dma8 / k_conv_dma_sk8 (round 5: built, bit-identical, not faster in the training step), 32768 = the decoder heads' dense
- * one-tap GEMMs on the class-major kernel k_conv_dma_sk<.., true> instead of the plain-path k_conv_dense_sk, 65536 = single convolutions on the general stream-K kernel instead of
+ * one-tap GEMMs on the class-major kernel k_conv_dma_sk<.., true> instead of the plain-path k_conv_dense_sk and their dense
+ * weight gradient on the general k_wgrad_dma instead of k_wgrad_dense, 65536 = single convolutions on the general stream-K kernel instead of
  * k_conv_single_sk.  Returns the previous flags. */
 int icn_set_debug_flags(int flags);
 

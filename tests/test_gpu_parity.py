@@ -347,6 +347,12 @@ def test_stream_k_in_the_decoder_heads_dense_gemms(r, cin, cout, B):
         assert any(k.startswith('k_conv_dma_sk') and k.endswith('true>') for k in k_cm) and not any('dense' in k for k in k_cm), k_cm
         for a, b in zip(cm, want):
             assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, trial
+        # the heads' dense weight gradient: k_wgrad_dense is the per-tap body with the gather compiled away (flag 32768: the
+        # general k_wgrad_dma walking an identity table) -- same splits, same sums: dW and dbias bit-identical
+        assert any(k.startswith('k_wgrad_dense') for k in k_sk) and not any(k.startswith('k_wgrad_dense') for k in k_cm), (k_sk, k_cm)
+        assert any(k.startswith('k_wgrad_dma') for k in k_cm), k_cm
+        for a, b in zip(got[3:], cm[3:]):
+            assert torch.equal(a, b), trial
     assert any(k.startswith('k_conv_dense_sk') for k in seen), seen
 
 
