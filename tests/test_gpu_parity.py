@@ -356,6 +356,40 @@ def test_stream_k_in_the_decoder_heads_dense_gemms(r, cin, cout, B):
     assert any(k.startswith('k_conv_dense_sk') for k in seen), seen
 
 
+@pytest.mark.parametrize('r,cin,cout,B,tile', [(2, 256, 256, 7, '128, 128'), (3, 128, 64, 5, '128, 64'), (3, 64, 128, 5, '64, 128'),
+                                               (3, 64, 64, 7, '64, 64'), (2, 128, 128, 1, '128, 128')])
+def test_the_dense_weight_gradient_kernel_equals_the_general_per_tap_kernel(r, cin, cout, B, tile):
+    """k_wgrad_dense (round 5) is k_wgrad_dma's body with the identity gather compiled in; debug flag 32768 keeps the general
+    kernel walking an identity table.  Same row splits, same MFMA order: dW and dbias of both branches BIT-identical, on every
+    tile instantiation (the pair's 2 * cout output channels pick the co tile), ragged row splits and a one-sample batch included."""
+    from geniconet_amd import _lib
+    from geniconet_amd.ico_conv import ico_upconv_pair
+    g = torch.Generator().manual_seed(r * 11 + cin + cout)
+    n = 2 ** r
+    ws = [(torch.randn(cout, cin, 7, generator=g) / (7 * cin) ** 0.5).cuda().requires_grad_() for _ in range(2)]
+    bs = [torch.randn(cout, generator=g).cuda().requires_grad_() for _ in range(2)]
+    x = torch.randn(B, cin, 5 * n, 2 * n, generator=g).cuda()
+    gy = [torch.randn(B, cout, 10 * n, 4 * n, generator=g).cuda() for _ in range(2)]
+
+    def run(flags):
+        old = _lib.lib().icn_set_debug_flags(flags)
+        try:
+            _lib.profile_start(64)
+            ys = ico_upconv_pair(x, ws[0], bs[0], ws[1], bs[1], r, 'average')
+            grads = torch.autograd.grad(ys, ws + bs, gy)
+            torch.cuda.synchronize()
+            return grads, {e['kernel'] for e in _lib.profile_stop()}
+        finally:
+            _lib.lib().icn_set_debug_flags(old)
+
+    dense, k_dense = run(0)
+    general, k_general = run(32768)
+    assert 'k_wgrad_dense<%s>' % tile in k_dense, k_dense
+    assert 'k_wgrad_dma<%s>' % tile in k_general and not any(k.startswith('k_wgrad_dense') for k in k_general), k_general
+    for a, b in zip(dense, general):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('r,cin,cout,B,pair', [(4, 128, 256, 36, True), (5, 64, 128, 12, True), (3, 256, 256, 36, False), (3, 256, 512, 5, True)])
 def test_balanced_tile_lists_equal_the_round_robin_walk(r, cin, cout, B, pair):
     """Stride-2 data gradients: the tiles of such a launch run 1 or 2 of the 7 taps, and the launcher deals them to the
