@@ -573,21 +573,6 @@ void build_bwd_row_order(int r_in, int stride, const std::vector<int32_t>& bwd_i
         std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) {
             return cls(x) != cls(y) ? cls(x) < cls(y) : taps[x] < taps[y];
         });
-        // Experiment of round 5 (ICN_S2_MIX=1, read when the tables are built): TWO parity classes per 64-row
-        // tile -- 32-row groups of two classes alternate, so that a tile runs the union of their tap sets (3 - 4 taps, >= 16 K-steps
-        // instead of 8 - 16) and there are half as many tile switches per K-step; rows gather zeros for the taps of the other class.
-        // Measured: profiles/r05_s2_dgrad_mixed_tiles.txt.  Off by default.
-        static const bool mix = getenv("ICN_S2_MIX") && atoi(getenv("ICN_S2_MIX")) == 1;
-        if (mix && Pin % 256 == 0) {
-            const int seg = Pin / 4;                          // rows per class (the four classes are equally large)
-            std::vector<int32_t> mixed;
-            mixed.reserve(Pin);
-            for (int pair = 0; pair < 2; ++pair)
-                for (int g = 0; g < seg / 32; ++g)
-                    for (int half = 0; half < 2; ++half)
-                        for (int k = 0; k < 32; ++k) mixed.push_back(perm[(size_t)(2 * pair + half) * seg + g * 32 + k]);
-            perm.swap(mixed);
-        }
     }
     mask32.assign((Pin + 31) / 32, 0);
     for (int k = 0; k < Pin; ++k) mask32[k / 32] |= (uint8_t)taps[perm[k]];

@@ -98,7 +98,7 @@ class _BnReluFn(torch.autograd.Function):
     """y = relu(bn_a(a) [+ bn_b(b)]) with batch statistics; updates the running statistics in place."""
 
     @staticmethod
-    def forward(ctx, a, ga, ba, rm_a, rv_a, eps_a, mom_a, b, gb, bb, rm_b, rv_b, eps_b, mom_b, early=None):
+    def forward(ctx, a, ga, ba, rm_a, rv_a, eps_a, mom_a, b, gb, bb, rm_b, rv_b, eps_b, mom_b):
         L = _lib.lib()
         ap = _nhwc(a)
         Bn, H, W, C = ap.shape
@@ -108,16 +108,11 @@ class _BnReluFn(torch.autograd.Function):
         dev = a.device
         ws = torch.empty(L.icn_bn_workspace_floats(M, C), dtype=torch.float32, device=dev)
         stat_a = torch.empty(2 * C, dtype=torch.float32, device=dev)
-        stat_b = torch.empty(2 * C, dtype=torch.float32, device=dev) if (dual and early is None) else None
+        stat_b = torch.empty(2 * C, dtype=torch.float32, device=dev) if dual else None
         y = torch.empty_like(ap)
         with torch.cuda.device(dev):
             st = _stream()
-            if dual and early is not None:      # the skip branch's statistics were started on the side stream (skip_stats_start)
-                stat_b, side = early
-                _lib.check(L.icn_bn_stats(ap.data_ptr(), M, C, eps_a, mom_a, rm_a.data_ptr(), rv_a.data_ptr(), stat_a.data_ptr(),
-                                          ws.data_ptr(), st), 'icn_bn_stats')
-                torch.cuda.current_stream(dev).wait_stream(side)
-            elif dual:      # both inputs' statistics in one pass
+            if dual:        # both inputs' statistics in one pass
                 _lib.check(L.icn_bn_stats2(ap.data_ptr(), bp.data_ptr(), M, C, eps_a, mom_a, rm_a.data_ptr(), rv_a.data_ptr(),
                                            stat_a.data_ptr(), eps_b, mom_b, rm_b.data_ptr(), rv_b.data_ptr(), stat_b.data_ptr(),
                                            ws.data_ptr(), st), 'icn_bn_stats2')
@@ -163,7 +158,7 @@ class _BnReluFn(torch.autograd.Function):
             out += [db.permute(0, 3, 1, 2), dgb, dbb, None, None, None, None]
         else:
             out += [None] * 7
-        return tuple(out) + (None,)
+        return tuple(out)
 
 
 def _args(bn):
@@ -208,42 +203,11 @@ def bn_relu(a, bn):
     return _BnReluFn.apply(a, *_args(bn), None, None, None, None, None, 0.0, 0.0)
 
 
-def bn_add_relu(a, bn_a, b, bn_b, early=None):
-    """relu(bn_a(a) + bn_b(b)).  `early`: what skip_stats_start returned for (b, bn_b), or None."""
+def bn_add_relu(a, bn_a, b, bn_b):
+    """relu(bn_a(a) + bn_b(b))."""
     _bump(bn_a)
     _bump(bn_b)
-    return _BnReluFn.apply(a, *_args(bn_a), b, *_args(bn_b), early)
-
-
-# ---- VERDICT r4 item 6a (experiment, ICN_SKIP_STATS_STREAM=1): the skip branch's batch statistics -- bn10 on c10, ready right after
-# the pair convolution -- on a second stream while conv01 (MFMA-bound) runs on the current one; the residual BatchNorm's own
-# statistics pass then reads one tensor instead of two.  Measured in round 5: profiles/r05_overlap_forward_stats.txt.
-_SKIP_STATS_STREAM = os.environ.get('ICN_SKIP_STATS_STREAM', '') == '1'
-_stats_streams = {}
-
-
-def skip_stats_start(b, bn_b):
-    """Start bn_b's batch statistics of `b` (and its running-statistics update) on the side stream; returns the handle for
-    bn_add_relu(early=...), or None when the experiment is off."""
-    if not _SKIP_STATS_STREAM or not b.is_cuda:
-        return None
-    L = _lib.lib()
-    bp = _nhwc(b.detach())
-    Bn, H, W, C = bp.shape
-    M = Bn * H * W
-    dev = b.device
-    ws = torch.empty(L.icn_bn_workspace_floats(M, C), dtype=torch.float32, device=dev)
-    stat_b = torch.empty(2 * C, dtype=torch.float32, device=dev)
-    side = _stats_streams.get(dev.index)
-    if side is None:
-        side = _stats_streams[dev.index] = torch.cuda.Stream(device=dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.device(dev):
-        _lib.check(L.icn_bn_stats(bp.data_ptr(), M, C, float(bn_b.eps), float(bn_b.momentum), bn_b.running_mean.data_ptr(),
-                                  bn_b.running_var.data_ptr(), stat_b.data_ptr(), ws.data_ptr(), side.cuda_stream), 'icn_bn_stats')
-    for t in (bp, ws, stat_b):
-        t.record_stream(side)
-    return stat_b, side
+    return _BnReluFn.apply(a, *_args(bn_a), b, *_args(bn_b))
 
 
 # ---- inference: relu(bn(a) [+ bn(b)]) with the RUNNING statistics, one streaming pass (icn_bn_relu_fwd; no statistics pass)

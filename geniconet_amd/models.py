@@ -39,9 +39,8 @@ class BasicIcoS2SDownBlock(nn.Module):
     def forward(self, x):
         c00, c10 = fused.conv_pair(x, self.conv00, self.conv10)             # both branches read x: one launch per pass
         if fused.can_fuse(x, self.icobn00, self.icobn01, self.icobn10):    # same math, fused HIP BN / ReLU passes
-            early = fused.skip_stats_start(c10, self.icobn10)
             h = fused.bn_relu(c00, self.icobn00)
-            return fused.bn_add_relu(self.conv01(h), self.icobn01, c10, self.icobn10, early)
+            return fused.bn_add_relu(self.conv01(h), self.icobn01, c10, self.icobn10)
         if fused.can_fuse_eval(x, self.icobn00, self.icobn01, self.icobn10):   # inference: running statistics, one pass each
             h = fused.bn_relu_eval(c00, self.icobn00)
             return fused.bn_add_relu_eval(self.conv01(h), self.icobn01, c10, self.icobn10)
@@ -72,9 +71,8 @@ class BasicIcoS2SUpBlock(nn.Module):
         # when the shape allows (fused.upconv_pair; module by module when someone hooked one of them).
         c00, c10 = fused.upconv_pair(x, self.upsample00, self.upsample10, self.conv00, self.conv10)
         if fused.can_fuse(x, self.icobn00, self.icobn01, self.icobn10):
-            early = fused.skip_stats_start(c10, self.icobn10)
             h = fused.bn_relu(c00, self.icobn00)
-            return fused.bn_add_relu(self.conv01(h), self.icobn01, c10, self.icobn10, early)
+            return fused.bn_add_relu(self.conv01(h), self.icobn01, c10, self.icobn10)
         if fused.can_fuse_eval(x, self.icobn00, self.icobn01, self.icobn10):   # inference: running statistics, one pass each
             h = fused.bn_relu_eval(c00, self.icobn00)
             return fused.bn_add_relu_eval(self.conv01(h), self.icobn01, c10, self.icobn10)
