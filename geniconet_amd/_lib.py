@@ -14,22 +14,13 @@ LIB_PATH = os.environ.get('ICN_LIB_PATH') or os.path.join(_HERE, 'libicn.so')
 
 OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT = 0, 1, 2
 CORNER_MODES = {'zeros': 0, 'average': 1}
-ABI_VERSION = 7
+ABI_VERSION = 6
 LAP_MODES = {'mean-v': 0, 'v-mean': 1, 'sum-kv': 2, 'kv-sum': 3}   # ICN_LAP_* of include/icn.h
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses
 _i32p = ctypes.POINTER(ctypes.c_int32)
 _f32p = ctypes.POINTER(ctypes.c_float)
 _intp = ctypes.POINTER(ctypes.c_int)
-
-
-
-class NextConv(ctypes.Structure):
-    """icn_next_conv of include/icn.h: the convolution whose prologue icn_bn_stats_next runs in its finalize launch."""
-    _fields_ = [('w0', ctypes.c_void_p), ('bias0', ctypes.c_void_p), ('w1', ctypes.c_void_p), ('bias1', ctypes.c_void_p),
-                ('B', ctypes.c_int), ('Cout0', ctypes.c_int), ('Cout1', ctypes.c_int), ('r_in', ctypes.c_int),
-                ('stride', ctypes.c_int), ('corner_mode', ctypes.c_int), ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_size_t)]
-
 
 # name -> (restype, argtypes); mirrors include/icn.h one to one (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -59,10 +50,6 @@ SIGNATURES = {
     'icn_bn_stats2': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int] + ([ctypes.c_float] * 2 + [_c_float_p] * 3) * 2 + [_c_float_p, ctypes.c_void_p]),
     'icn_bn_stats': (ctypes.c_int, [_c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float] + [_c_float_p] * 4 + [ctypes.c_void_p]),
     'icn_bn_relu_fwd': (ctypes.c_int, [_c_float_p] * 9 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
-    'icn_bn_stats_next': (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int] + ([ctypes.c_float] * 2 + [_c_float_p] * 5) * 2 +
-                          [_c_float_p, ctypes.POINTER(NextConv), ctypes.c_void_p]),
-    'icn_conv_fwd_prepared': (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    'icn_conv_pair_fwd_prepared': (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'icn_bn_relu_bwd': (ctypes.c_int, [_c_float_p] * 13 + [ctypes.c_int] * 2 + [_c_float_p] * 4 + [ctypes.c_void_p]),
     'icn_head_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 2),
     'icn_head_fwd': (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),

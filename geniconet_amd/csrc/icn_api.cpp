@@ -579,42 +579,29 @@ size_t conv_ws_bytes(int op, int B, int Cin, int C0, int C1, int r_in, int strid
 char* at(void* ws, size_t off) { return static_cast<char*>(ws) + off; }
 
 // ---- the three passes; w1 == nullptr: one convolution, else a pair sharing x (C1 = its output channels) -------------
-// workspace layout of a forward call and the prologue that fills it (weight pack, concatenated bias, side rows, stream-K flags)
-struct FwdWs { float* wf; float* bias_cat; float* side; int* sk_flag; float* sk_part; };
-FwdWs conv_fwd_ws(bool pair, bool has_bias, int B, int Cin, int C, int r_in, int stride, void* ws) {
-    const size_t wbytes = align256((size_t)7 * Cin * C * sizeof(float));
-    FwdWs o{};
-    o.wf = static_cast<float*>(ws);
-    o.bias_cat = (pair && has_bias) ? reinterpret_cast<float*>(at(ws, wbytes)) : nullptr;
-    const size_t side_off = wbytes + (pair ? align256((size_t)C * sizeof(float)) : 0);
-    o.side = reinterpret_cast<float*>(at(ws, side_off));
-    o.sk_flag = reinterpret_cast<int*>(at(ws, side_off + align256((size_t)B * table_counts(r_in, stride).slots_fwd * Cin * sizeof(float))));
-    o.sk_part = reinterpret_cast<float*>(reinterpret_cast<char*>(o.sk_flag) + align256((size_t)icn::CONV_SK_FLAGS * sizeof(int)));
-    return o;
-}
-icn::PrologueArgs conv_fwd_prologue(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, int B, int Cin,
-                                    int C0, int C1, const ConvTables& t, const FwdWs& o) {
-    icn::PrologueArgs p{};
-    p.zero = o.sk_flag; p.n_zero = icn::CONV_SK_FLAGS;
-    p.w = w0; p.w2 = w1; p.packed = o.wf; p.Cout = C0; p.Cout2 = C1; p.Cin = Cin; p.transpose = 0;
-    p.bias = b0; p.bias2 = b1; p.bias_cat = o.bias_cat;
-    p.src = x; p.slots = t.d_fwd.slots; p.side = o.side; p.n_slots = t.d_fwd.n_slots; p.E = 1; p.B = B; p.Ps = t.Pin; p.K = Cin;
-    p.ns = t.n_in;
-    return p;
-}
-
-// `prepared`: the prologue has already run into `ws` (icn_bn_stats_next: in the finalize launch of the BatchNorm that produced x)
 void conv_fwd_impl(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, float* y0, float* y1, int B,
-                   int Cin, int C0, int C1, int r_in, int stride, const ConvTables& t, void* ws, hipStream_t s, bool prepared = false) {
+                   int Cin, int C0, int C1, int r_in, int stride, const ConvTables& t, void* ws, hipStream_t s) {
     const int C = C0 + C1;
-    const FwdWs o = conv_fwd_ws(w1 != nullptr, b0 != nullptr, B, Cin, C, r_in, stride, ws);
-    if (!prepared) icn::launch_conv_prologue(conv_fwd_prologue(x, w0, b0, w1, b1, B, Cin, C0, C1, t, o), s);
+    const size_t wbytes = align256((size_t)7 * Cin * C * sizeof(float));
+    float* wf = static_cast<float*>(ws);
+    float* bias_cat = (w1 && b0) ? reinterpret_cast<float*>(at(ws, wbytes)) : nullptr;
+    const size_t side_off = wbytes + (w1 ? align256((size_t)C * sizeof(float)) : 0);
+    float* side = reinterpret_cast<float*>(at(ws, side_off));
+    int* sk_flag = reinterpret_cast<int*>(at(ws, side_off + align256((size_t)B * table_counts(r_in, stride).slots_fwd * Cin * sizeof(float))));
+    float* sk_part = reinterpret_cast<float*>(reinterpret_cast<char*>(sk_flag) + align256((size_t)icn::CONV_SK_FLAGS * sizeof(int)));
+    icn::PrologueArgs p{};
+    p.zero = sk_flag; p.n_zero = icn::CONV_SK_FLAGS;
+    p.w = w0; p.w2 = w1; p.packed = wf; p.Cout = C0; p.Cout2 = C1; p.Cin = Cin; p.transpose = 0;
+    p.bias = b0; p.bias2 = b1; p.bias_cat = bias_cat;
+    p.src = x; p.slots = t.d_fwd.slots; p.side = side; p.n_slots = t.d_fwd.n_slots; p.E = 1; p.B = B; p.Ps = t.Pin; p.K = Cin;
+    p.ns = t.n_in;
+    icn::launch_conv_prologue(p, s);
     icn::GatherGemmArgs a{};
-    a.src = x; a.wt = o.wf; a.bias = w1 ? o.bias_cat : b0; a.dst = y0; a.dst2 = w1 ? y1 : nullptr; a.N0 = C0;
-    a.idx = t.fwd; a.dcode = t.d_fwd.code; a.side = o.side; a.n_slots = t.d_fwd.n_slots;
+    a.src = x; a.wt = wf; a.bias = w1 ? bias_cat : b0; a.dst = y0; a.dst2 = w1 ? y1 : nullptr; a.N0 = C0;
+    a.idx = t.fwd; a.dcode = t.d_fwd.code; a.side = side; a.n_slots = t.d_fwd.n_slots;
     a.M = B * t.Pout; a.Ps = t.Pin; a.Pd = t.Pout; a.K = Cin; a.N = C; a.E = 1; a.ns = t.n_in;
     a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pout;
-    a.sk_part = o.sk_part; a.sk_flag = o.sk_flag;
+    a.sk_part = sk_part; a.sk_flag = sk_flag;
     icn::launch_gather_gemm_auto(a, s);
 }
 
@@ -808,8 +795,8 @@ size_t icn_conv_workspace_bytes(int op, int B, int Cin, int Cout, int r_in, int 
     }
 }
 
-static int conv_fwd_entry(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int r_in,
-                          int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream, bool prepared) {
+int icn_conv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int r_in,
+                 int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream) {
     try {
         check_conv(x, w, y, B, Cin, Cout, r_in, stride);
         const ConvTables& t = conv_tables(r_in, stride, corner_mode);
@@ -817,9 +804,7 @@ static int conv_fwd_entry(const float* x, const float* w, const float* bias, flo
         if (icn::gather_gemm_supported(Cin, Cout)) {
             if (!ws || ws_bytes < conv_ws_bytes(ICN_OP_CONV_FWD, B, Cin, Cout, 0, r_in, stride))
                 throw std::invalid_argument("icn_conv_fwd: workspace too small");
-            conv_fwd_impl(x, w, bias, nullptr, nullptr, y, nullptr, B, Cin, Cout, 0, r_in, stride, t, ws, s, prepared);
-        } else if (prepared) {
-            throw std::invalid_argument("icn_conv_fwd_prepared: this shape has no prologue to prepare");
+            conv_fwd_impl(x, w, bias, nullptr, nullptr, y, nullptr, B, Cin, Cout, 0, r_in, stride, t, ws, s);
         } else if (icn::stem_supported(Cin, Cout)) {
             icn::launch_stem_fwd(x, w, bias, y, t.fwd, B * t.Pout, t.Pin, t.Pout, Cin, Cout, t.n_in, s);
         } else {
@@ -830,14 +815,6 @@ static int conv_fwd_entry(const float* x, const float* w, const float* bias, flo
     } catch (const std::exception& e) {
         return fail(e.what());
     }
-}
-int icn_conv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int r_in,
-                 int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream) {
-    return conv_fwd_entry(x, w, bias, y, B, Cin, Cout, r_in, stride, corner_mode, ws, ws_bytes, stream, false);
-}
-int icn_conv_fwd_prepared(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int r_in,
-                          int stride, int corner_mode, void* ws, size_t ws_bytes, void* stream) {
-    return conv_fwd_entry(x, w, bias, y, B, Cin, Cout, r_in, stride, corner_mode, ws, ws_bytes, stream, true);
 }
 
 int icn_conv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int r_in, int stride,
@@ -896,9 +873,9 @@ size_t icn_conv_pair_workspace_bytes(int op, int B, int Cin, int Cout0, int Cout
     }
 }
 
-static int conv_pair_fwd_entry(const float* x, const float* w0, const float* bias0, const float* w1, const float* bias1, float* y0,
-                               float* y1, int B, int Cin, int Cout0, int Cout1, int r_in, int stride, int corner_mode, void* ws,
-                               size_t ws_bytes, void* stream, bool prepared) {
+int icn_conv_pair_fwd(const float* x, const float* w0, const float* bias0, const float* w1, const float* bias1, float* y0, float* y1,
+                      int B, int Cin, int Cout0, int Cout1, int r_in, int stride, int corner_mode, void* ws, size_t ws_bytes,
+                      void* stream) {
     try {
         check_conv(x, w0, y0, B, Cin, Cout0, r_in, stride);
         if (!w1 || !y1) throw std::invalid_argument("icn: null tensor pointer");
@@ -907,22 +884,12 @@ static int conv_pair_fwd_entry(const float* x, const float* w0, const float* bia
         if (!ws || ws_bytes < conv_ws_bytes(ICN_OP_CONV_FWD, B, Cin, Cout0, Cout1, r_in, stride))
             throw std::invalid_argument("icn_conv_pair_fwd: workspace too small");
         const ConvTables& t = conv_tables(r_in, stride, corner_mode);
-        conv_fwd_impl(x, w0, bias0, w1, bias1, y0, y1, B, Cin, Cout0, Cout1, r_in, stride, t, ws, static_cast<hipStream_t>(stream), prepared);
+        conv_fwd_impl(x, w0, bias0, w1, bias1, y0, y1, B, Cin, Cout0, Cout1, r_in, stride, t, ws, static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());
         return 0;
     } catch (const std::exception& e) {
         return fail(e.what());
     }
-}
-int icn_conv_pair_fwd(const float* x, const float* w0, const float* bias0, const float* w1, const float* bias1, float* y0, float* y1,
-                      int B, int Cin, int Cout0, int Cout1, int r_in, int stride, int corner_mode, void* ws, size_t ws_bytes,
-                      void* stream) {
-    return conv_pair_fwd_entry(x, w0, bias0, w1, bias1, y0, y1, B, Cin, Cout0, Cout1, r_in, stride, corner_mode, ws, ws_bytes, stream, false);
-}
-int icn_conv_pair_fwd_prepared(const float* x, const float* w0, const float* bias0, const float* w1, const float* bias1, float* y0,
-                               float* y1, int B, int Cin, int Cout0, int Cout1, int r_in, int stride, int corner_mode, void* ws,
-                               size_t ws_bytes, void* stream) {
-    return conv_pair_fwd_entry(x, w0, bias0, w1, bias1, y0, y1, B, Cin, Cout0, Cout1, r_in, stride, corner_mode, ws, ws_bytes, stream, true);
 }
 
 int icn_conv_pair_bwd_data(const float* dy0, const float* dy1, const float* w0, const float* w1, float* dx, int B, int Cin, int Cout0,
@@ -1473,39 +1440,6 @@ int icn_bn_stats2(const float* a, const float* b, int M, int C, float eps_a, flo
         if (!icn::bn_supported(C)) throw std::invalid_argument("icn_bn_stats2: unsupported channel count");
         icn::launch_bn_stats2(a, b, M, C, eps_a, momentum_a, running_mean_a, running_var_a, stat_a, eps_b, momentum_b, running_mean_b,
                               running_var_b, stat_b, ws, static_cast<hipStream_t>(stream));
-        ICN_HIP(hipGetLastError());
-        return 0;
-    } catch (const std::exception& e) {
-        return fail(e.what());
-    }
-}
-
-int icn_bn_stats_next(const float* a, const float* b, int M, int C, float eps_a, float momentum_a, float* running_mean_a,
-                      float* running_var_a, float* stat_a, const float* gamma_a, const float* beta_a, float eps_b, float momentum_b,
-                      float* running_mean_b, float* running_var_b, float* stat_b, const float* gamma_b, const float* beta_b, float* ws,
-                      const icn_next_conv* next, void* stream) {
-    try {
-        if (!a || !stat_a || !gamma_a || !beta_a || !ws || !next || M < 1) throw std::invalid_argument("icn_bn_stats_next: bad arguments");
-        if (b && (!stat_b || !gamma_b || !beta_b)) throw std::invalid_argument("icn_bn_stats_next: the second input needs its BatchNorm");
-        if ((running_mean_a == nullptr) != (running_var_a == nullptr) || (b && (running_mean_b == nullptr) != (running_var_b == nullptr)))
-            throw std::invalid_argument("icn_bn_stats_next: running mean and variance go together");
-        if (!icn::bn_supported(C)) throw std::invalid_argument("icn_bn_stats_next: unsupported channel count");
-        const icn_next_conv& n = *next;
-        const int Cin = C, Cn = n.Cout0 + n.Cout1;
-        if (!n.w0 || !n.ws || n.B < 1 || n.Cout0 < 1 || n.Cout1 < 0 || (n.Cout1 > 0) != (n.w1 != nullptr))
-            throw std::invalid_argument("icn_bn_stats_next: bad description of the next convolution");
-        if (n.w1 && (n.bias0 == nullptr) != (n.bias1 == nullptr)) throw std::invalid_argument("icn_bn_stats_next: both biases or none");
-        const ConvTables& t = conv_tables(n.r_in, n.stride, n.corner_mode);       // (checks level / stride / corner mode)
-        if ((long long)n.B * t.Pin != M) throw std::invalid_argument("icn_bn_stats_next: the next convolution's input is not this tensor's shape");
-        if (n.w1 ? !pair_supported(n.B, Cin, n.Cout0, n.Cout1, n.r_in, n.stride) : !icn::gather_gemm_supported(Cin, Cn))
-            throw std::invalid_argument("icn_bn_stats_next: the next convolution does not take the MFMA path (no prologue to prepare)");
-        if (n.ws_bytes < conv_ws_bytes(ICN_OP_CONV_FWD, n.B, Cin, n.Cout0, n.Cout1, n.r_in, n.stride))
-            throw std::invalid_argument("icn_bn_stats_next: the next convolution's workspace is too small");
-        const FwdWs o = conv_fwd_ws(n.w1 != nullptr, n.bias0 != nullptr, n.B, Cin, Cn, n.r_in, n.stride, n.ws);
-        const icn::PrologueArgs p = conv_fwd_prologue(nullptr, n.w0, n.bias0, n.w1, n.bias1, n.B, Cin, n.Cout0, n.Cout1, t, o);
-        icn::launch_bn_stats_prologue(a, b, M, C, eps_a, momentum_a, running_mean_a, running_var_a, stat_a, gamma_a, beta_a, eps_b,
-                                      momentum_b, running_mean_b, running_var_b, stat_b, gamma_b, beta_b, ws, p,
-                                      static_cast<hipStream_t>(stream));
         ICN_HIP(hipGetLastError());
         return 0;
     } catch (const std::exception& e) {

@@ -205,22 +205,6 @@ __device__ __forceinline__ void chunk_sums(const double* __restrict__ partial, i
     }
 }
 
-struct BnFin { const float* x; float eps, momentum; float* running_mean; float* running_var; float* stat; };
-// mean / invstd of the batch, running statistics (momentum, unbiased variance) from s = sum (x - x0), s2 = sum (x - x0)^2
-__device__ __forceinline__ void bn_finish_fwd(const BnFin& f, double s, double s2, int M, int C, int c) {
-    const double ms = s / M;                              // mean of x - x0 (x0 = first row: the shift of k_bn_partial<0>)
-    const double mean = (double)f.x[c] + ms;
-    double var = s2 / M - ms * ms;
-    if (var < 0.0) var = 0.0;
-    f.stat[c] = (float)mean;
-    f.stat[C + c] = (float)(1.0 / sqrt(var + (double)f.eps));
-    if (f.running_mean) {
-        const double unbiased = M > 1 ? var * M / (M - 1) : var;
-        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
-        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
-    }
-}
-
 // forward finalize: mean / invstd of the batch, running statistics (momentum, unbiased variance); 16 channels per block
 __global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict__ x, const double* __restrict__ partial, int chunks,
                                                           int M, int C, float eps, float momentum,
@@ -230,11 +214,23 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd(const float* __restrict
     const int c = blockIdx.x * 16 + threadIdx.x % 16, slice = threadIdx.x / 16;
     double sums[2];
     chunk_sums<2>(partial, chunks, 2, 0, C, c, slice, red, sums);
+    const double s = sums[0], s2 = sums[1];
     if (slice != 0 || c >= C) return;
-    bn_finish_fwd(BnFin{x, eps, momentum, running_mean, running_var, stat}, sums[0], sums[1], M, C, c);
+    const double ms = s / M;                              // mean of x - x0 (x0 = first row: the shift of k_bn_partial<0>)
+    const double mean = (double)x[c] + ms;
+    double var = s2 / M - ms * ms;
+    if (var < 0.0) var = 0.0;
+    stat[c] = (float)mean;
+    stat[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * M / (M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
 }
 
 // the same for the two inputs of a residual BatchNorm after a MODE 3 partial pass (4 sums per chunk); blockIdx.y = input
+struct BnFin { const float* x; float eps, momentum; float* running_mean; float* running_var; float* stat; };
 __global__ __launch_bounds__(256) void k_bn_finalize_fwd2(const BnFin fa, const BnFin fb, const double* __restrict__ partial, int chunks,
                                                            int M, int C) {
     __shared__ double red[16][16];
@@ -243,7 +239,17 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd2(const BnFin fa, const 
     double sums[2];
     chunk_sums<2>(partial, chunks, 4, 2 * blockIdx.y, C, c, slice, red, sums);
     if (slice != 0 || c >= C) return;
-    bn_finish_fwd(f, sums[0], sums[1], M, C, c);
+    const double ms = sums[0] / M;
+    const double mean = (double)f.x[c] + ms;
+    double var = sums[1] / M - ms * ms;
+    if (var < 0.0) var = 0.0;
+    f.stat[c] = (float)mean;
+    f.stat[C + c] = (float)(1.0 / sqrt(var + (double)f.eps));
+    if (f.running_mean) {
+        const double unbiased = M > 1 ? var * M / (M - 1) : var;
+        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+    }
 }
 
 // backward finalize: sums[k][C] = sum over chunks (k < NS); blockIdx.y = k.  The same values also go to the parameter
@@ -267,92 +273,6 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double* __restric
         } else if (out.dgamma_b) {
             out.dgamma_b[c] = v;
         }
-    }
-}
-
-// ---- forward finalize + the NEXT convolution's prologue in one launch (round 5) ------------------------------------------------
-// Priced in the training step (profiles/r05_bn_finalize_launches.txt): the 30 k_conv_prologue launches cost 0.23 ms of 8.0, ~7.7 us
-// each for ~5.5 us of execution.  A prologue (weight pack, stream-K flag words, pole-mean side rows of the convolution's input) has no
-// consumer inside its own launch, so it can ride in an EARLIER one without any device-side hand-off -- and the finalize launch of the
-// BatchNorm that produces the convolution's input is the natural carrier: a finalize workgroup has just computed mean / invstd of its
-// 16 channels and evaluates relu(bn_a(a) [+ bn_b(b)]) at the pole-corner rows for those channels itself -- through bn_pre4 / relu4,
-// the apply pass's own functions, so the side rows are bit-identical to what k_conv_prologue would read from the apply pass's output
-// -- while workgroups behind the finalize ones pack the weights and clear the flag words (k_conv_prologue's code).
-__device__ __forceinline__ int corner_pixel(int n, int k, int c) {        // (icn_kernels.hip: the 5 pixels around pole k)
-    return k == 0 ? (c * n) * 2 * n : ((c + 1) * n - 1) * 2 * n + (2 * n - 1);
-}
-struct BnAffine { const float* gamma; const float* beta; };
-template <int DUAL>
-__global__ __launch_bounds__(256) void k_bn_finalize_prologue(const BnFin fa, const BnFin fb, const BnAffine aa, const BnAffine ab,
-                                                               const float* __restrict__ a, const float* __restrict__ b,
-                                                               const double* __restrict__ partial, int chunks, int M, int C,
-                                                               const PrologueArgs p, int cb, int npack) {
-    if ((int)blockIdx.x >= cb) {                          // ---- the convolution's weight pack, bias, flag words
-        const int blk = blockIdx.x - cb;
-        if (p.zero && blk == 0)
-            for (int i = threadIdx.x; i < p.n_zero; i += 256) p.zero[i] = 0;
-        const int Ct = p.Cout + p.Cout2, total = Ct * p.Cin * 7;
-        for (int i = blk * 256 + threadIdx.x; i < total; i += npack * 256) {      // (forward layout: transpose == 0)
-            const int ci = i % p.Cin, co = (i / p.Cin) % Ct, t = i / (p.Cin * Ct);
-            p.packed[i] = co < p.Cout ? p.w[((size_t)co * p.Cin + ci) * 7 + t] : p.w2[((size_t)(co - p.Cout) * p.Cin + ci) * 7 + t];
-        }
-        if (p.bias_cat && blk == 0)
-            for (int c = threadIdx.x; c < Ct; c += 256) p.bias_cat[c] = c < p.Cout ? p.bias[c] : p.bias2[c - p.Cout];
-        return;
-    }
-    // ---- finalize: 16 channels (k_bn_finalize_fwd / _fwd2's arithmetic), their statistics kept in LDS for the side rows
-    __shared__ double red[16][16];
-    __shared__ __attribute__((aligned(16))) float st[4][16];               // mean_a, invstd_a, mean_b, invstd_b
-    const int c = blockIdx.x * 16 + threadIdx.x % 16, slice = threadIdx.x / 16;
-    double sums[2];
-    chunk_sums<2>(partial, chunks, DUAL ? 4 : 2, 0, C, c, slice, red, sums);
-    if (slice == 0 && c < C) {
-        bn_finish_fwd(fa, sums[0], sums[1], M, C, c);
-        st[0][threadIdx.x] = fa.stat[c];
-        st[1][threadIdx.x] = fa.stat[C + c];
-    }
-    if (DUAL) {
-        chunk_sums<2>(partial, chunks, 4, 2, C, c, slice, red, sums);
-        if (slice == 0 && c < C) {
-            bn_finish_fwd(fb, sums[0], sums[1], M, C, c);
-            st[2][threadIdx.x] = fb.stat[c];
-            st[3][threadIdx.x] = fb.stat[C + c];
-        }
-    }
-    __syncthreads();
-    if (p.n_slots <= 0 || !p.side) return;
-    // ---- side rows of the convolution's input y = relu(bn_a(a) [+ bn_b(b)]) for these 16 channels: a thread owns 4 of them
-    const int q = threadIdx.x % 4, c4 = blockIdx.x * 16 + 4 * q;
-    if (c4 >= C) return;
-    const f32x4 mean_a = *reinterpret_cast<const f32x4*>(&st[0][4 * q]);
-    const f32x4 scale_a = *reinterpret_cast<const f32x4*>(&st[1][4 * q]) * ldv(aa.gamma + c4), beta_a = ldv(aa.beta + c4);
-    f32x4 mean_b{}, scale_b{}, beta_b{};
-    if (DUAL) {
-        mean_b = *reinterpret_cast<const f32x4*>(&st[2][4 * q]);
-        scale_b = *reinterpret_cast<const f32x4*>(&st[3][4 * q]) * ldv(ab.gamma + c4);
-        beta_b = ldv(ab.beta + c4);
-    }
-    auto y_at = [&](int bs, int row) {
-        const size_t o = ((size_t)bs * p.Ps + row) * C + c4;
-        f32x4 bv{};
-        if (DUAL) bv = ldv(b + o);
-        return relu4(bn_pre4<DUAL>(ldv(a + o), mean_a, scale_a, beta_a, bv, mean_b, scale_b, beta_b));
-    };
-    for (int j = threadIdx.x / 4; j < p.B * p.n_slots; j += 64) {
-        const int bs = j / p.n_slots, sl = j % p.n_slots;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int e = 0; e < p.E; ++e) {
-            const int32_t code = p.slots[sl * p.E + e];
-            if (code >= 0) {
-                v += y_at(bs, code);
-            } else if (code <= -2) {                      // (pole_mean4 of icn_kernels.hip: sum in corner order, then * 0.2)
-                f32x4 sp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int cc = 0; cc < 5; ++cc) sp += y_at(bs, corner_pixel(p.ns, -2 - code, cc));
-                v += sp * 0.2f;
-            }
-        }
-        stv(p.side + ((size_t)bs * p.n_slots + sl) * C + c4, v);
     }
 }
 
@@ -459,26 +379,6 @@ void launch_bn_stats2(const float* a, const float* b, int M, int C, float eps_a,
                        nullptr, reinterpret_cast<double*>(ws), M, C, rows);
     hipLaunchKernelGGL(k_bn_finalize_fwd2, dim3((C + 15) / 16, 2), dim3(256), 0, s, BnFin{a, eps_a, mom_a, rm_a, rv_a, stat_a},
                        BnFin{b, eps_b, mom_b, rm_b, rv_b, stat_b}, reinterpret_cast<const double*>(ws), chunks, M, C);
-}
-
-// statistics of one / two tensors, and in the finalize launch the prologue `p` of the convolution that will read relu(bn(..)) (see
-// k_bn_finalize_prologue; p.src is not used: the input does not exist yet)
-void launch_bn_stats_prologue(const float* a, const float* b, int M, int C, float eps_a, float mom_a, float* rm_a, float* rv_a,
-                              float* stat_a, const float* gamma_a, const float* beta_a, float eps_b, float mom_b, float* rm_b, float* rv_b,
-                              float* stat_b, const float* gamma_b, const float* beta_b, float* ws, const PrologueArgs& p, hipStream_t s) {
-    const int chunks = bn_chunks(M), rows = (M + chunks - 1) / chunks;
-    const int cb = (C + 15) / 16, npack = p.w ? std::min(2048, ((p.Cout + p.Cout2) * p.Cin * 7 + 255) / 256) : (p.zero ? 1 : 0);
-    double* wsd = reinterpret_cast<double*>(ws);
-    const BnFin fa{a, eps_a, mom_a, rm_a, rv_a, stat_a}, fb{b, eps_b, mom_b, rm_b, rv_b, stat_b};
-    if (b) {
-        hipLaunchKernelGGL(k_bn_partial<3>, dim3(chunks), dim3(256), 0, s, a, b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, wsd, M, C, rows);
-        hipLaunchKernelGGL(k_bn_finalize_prologue<1>, dim3(cb + npack), dim3(256), 0, s, fa, fb, BnAffine{gamma_a, beta_a}, BnAffine{gamma_b, beta_b},
-                           a, b, wsd, chunks, M, C, p, cb, npack);
-    } else {
-        hipLaunchKernelGGL(k_bn_partial<0>, dim3(chunks), dim3(256), 0, s, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, wsd, M, C, rows);
-        hipLaunchKernelGGL(k_bn_finalize_prologue<0>, dim3(cb + npack), dim3(256), 0, s, fa, fb, BnAffine{gamma_a, beta_a}, BnAffine{nullptr, nullptr},
-                           a, b, wsd, chunks, M, C, p, cb, npack);
-    }
 }
 
 void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga, const float* ba,

@@ -166,11 +166,6 @@ void launch_bn_stats(const float* x, int M, int C, float eps, float momentum, fl
                      float* ws, hipStream_t s);
 void launch_bn_stats2(const float* a, const float* b, int M, int C, float eps_a, float mom_a, float* rm_a, float* rv_a, float* stat_a,
                       float eps_b, float mom_b, float* rm_b, float* rv_b, float* stat_b, float* ws, hipStream_t s);   // ws: chunks * 4 * C
-// b == null: one tensor.  The finalize launch also runs `next` -- the prologue of the convolution that will read relu(bn(..)) -- with
-// the side rows evaluated from a (, b) and the fresh statistics (icn_bn.hip: k_bn_finalize_prologue)
-void launch_bn_stats_prologue(const float* a, const float* b, int M, int C, float eps_a, float mom_a, float* rm_a, float* rv_a,
-                              float* stat_a, const float* gamma_a, const float* beta_a, float eps_b, float mom_b, float* rm_b, float* rv_b,
-                              float* stat_b, const float* gamma_b, const float* beta_b, float* ws, const PrologueArgs& next, hipStream_t s);
 void launch_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga, const float* ba,
                         const float* gb, const float* bb, float* y, int M, int C, hipStream_t s);
 void launch_bn_relu_bwd(const float* dy, const float* a, const float* b, const float* stat_a, const float* stat_b, const float* ga,

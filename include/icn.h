@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ICN_ABI_VERSION 7
+#define ICN_ABI_VERSION 6
 
 #define ICN_CORNER_ZEROS 0
 #define ICN_CORNER_AVERAGE 1
@@ -146,31 +146,6 @@ int icn_bn_stats2(const float* a, const float* b, int M, int C, float eps_a, flo
                   float* stat_b, float* ws, void* stream);
 int icn_bn_stats(const float* x, int M, int C, float eps, float momentum, float* running_mean, float* running_var, float* stat,
                  float* ws, void* stream);
-/* ABI 7 -- the NEXT convolution's prologue in the statistics pass.  Every MFMA convolution call starts with a small launch of its
- * own (weight pack, stream-K flag words, pole-mean side rows of its input: ~8 us on the critical path, 30 of them per training
- * step).  When the convolution's input is y = relu(bn_a(a) [+ bn_b(b)]), icn_bn_stats_next does that work inside the finalize launch of
- * the statistics pass -- the side rows are evaluated from a (, b) and the fresh statistics with the apply pass's own arithmetic, so
- * they are bit-identical to what the convolution's prologue would read from y -- into the convolution's OWN workspace `next->ws`
- * (icn_conv_workspace_bytes / icn_conv_pair_workspace_bytes with ICN_OP_CONV_FWD), and icn_conv_fwd_prepared /
- * icn_conv_pair_fwd_prepared then run the convolution on y without a prologue.  Same results, one launch less per convolution.
- * The caller keeps w / bias unchanged and `next->ws` alive and untouched between the two calls, runs icn_bn_relu_fwd on the same
- * a (, b), stat, gamma, beta in between (or before the convolution at the latest), and passes that y to the prepared call.
- * b == NULL: single input (icn_bn_stats); else icn_bn_stats2's pass.  next->w1 == NULL (Cout1 = 0): a single convolution, else a pair.
- * Errors (-1): the next convolution's shape does not take the MFMA path, its input is not (B * pixels(r_in), C), workspace too small. */
-typedef struct icn_next_conv {
-    const float* w0; const float* bias0; const float* w1; const float* bias1;
-    int B, Cout0, Cout1, r_in, stride, corner_mode;
-    void* ws; size_t ws_bytes;
-} icn_next_conv;
-int icn_bn_stats_next(const float* a, const float* b, int M, int C, float eps_a, float momentum_a, float* running_mean_a,
-                      float* running_var_a, float* stat_a, const float* gamma_a, const float* beta_a, float eps_b, float momentum_b,
-                      float* running_mean_b, float* running_var_b, float* stat_b, const float* gamma_b, const float* beta_b, float* ws,
-                      const icn_next_conv* next, void* stream);
-int icn_conv_fwd_prepared(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int r_in, int stride,
-                          int corner_mode, void* ws, size_t ws_bytes, void* stream);
-int icn_conv_pair_fwd_prepared(const float* x, const float* w0, const float* bias0, const float* w1, const float* bias1, float* y0,
-                               float* y1, int B, int Cin, int Cout0, int Cout1, int r_in, int stride, int corner_mode, void* ws,
-                               size_t ws_bytes, void* stream);
 int icn_bn_relu_fwd(const float* a, const float* b, const float* stat_a, const float* stat_b, const float* gamma_a,
                     const float* beta_a, const float* gamma_b, const float* beta_b, float* y, int M, int C, void* stream);
 int icn_bn_relu_bwd(const float* dy, const float* a, const float* b, const float* stat_a, const float* stat_b, const float* gamma_a,

@@ -813,78 +813,6 @@ def test_bn_stats_of_two_tensors_in_one_pass_equal_two_single_passes():
     assert float((got - ref).abs().max()) < 1e-3          # mean -50, std 0.1: the shifted sums keep the variance
 
 
-@pytest.mark.parametrize('r,C,cout,B,stride,dual,pair,mode', [
-    (3, 64, 64, 5, 1, False, False, 'average'), (3, 128, 128, 3, 2, True, True, 'average'), (4, 64, 128, 2, 2, False, True, 'average'),
-    (2, 256, 256, 7, 1, True, False, 'average'), (3, 64, 64, 4, 1, True, False, 'zeros'), (1, 128, 64, 2, 1, False, False, 'average')])
-def test_next_convolutions_prologue_in_the_batchnorm_finalize_launch(r, C, cout, B, stride, dual, pair, mode):
-    """ABI 7: icn_bn_stats_next runs the prologue of the convolution that will read y = relu(bn_a(a) [+ bn_b(b)]) -- weight pack, flag
-    words, pole-mean side rows evaluated from a (, b) and the fresh statistics -- inside the statistics pass's finalize launch, and
-    icn_conv[_pair]_fwd_prepared then runs without a prologue launch.  Statistics, running statistics and the convolution's output
-    must be BIT-identical to icn_bn_stats[2] + icn_conv[_pair]_fwd, and the prepared path must not launch k_conv_prologue."""
-    import ctypes
-    from geniconet_amd import _lib
-    L = _lib.lib()
-    n = 2 ** r
-    P = 10 * n * n
-    M = B * P
-    m = _lib.corner_code(mode)
-    g = torch.Generator().manual_seed(r * 100 + C + cout)
-    a = (torch.randn(M, C, generator=g) * 1.5 + 0.5).cuda()
-    b = (torch.randn(M, C, generator=g) * 0.7 - 0.3).cuda() if dual else None
-    ga, ba, gb, bb = [(torch.rand(C, generator=g) + 0.5).cuda() for _ in range(4)]
-    ws_ = [(torch.randn(cout, C, 7, generator=g) / (7 * C) ** 0.5).cuda() for _ in range(2)]
-    bs_ = [torch.randn(cout, generator=g).cuda() for _ in range(2)]
-    n_out = n // stride
-    st = torch.cuda.current_stream().cuda_stream
-    if pair:
-        assert L.icn_conv_pair_supported(B, C, cout, cout, r, stride)
-        cws_bytes = L.icn_conv_pair_workspace_bytes(_lib.OP_CONV_FWD, B, C, cout, cout, r, stride)
-    else:
-        cws_bytes = L.icn_conv_workspace_bytes(_lib.OP_CONV_FWD, B, C, cout, r, stride)
-    assert cws_bytes > 0
-    p_ = lambda t: t.data_ptr() if t is not None else None
-
-    def run(prepared):
-        bn_ws = torch.empty(L.icn_bn_workspace_floats(M, C), device='cuda')
-        cws = torch.empty(cws_bytes, dtype=torch.uint8, device='cuda')
-        fa = [torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.empty(2 * C, device='cuda')]
-        fb = [torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.empty(2 * C, device='cuda')]
-        y = torch.empty(M, C, device='cuda')
-        outs = [torch.empty(B * 10 * n_out * n_out, cout, device='cuda') for _ in range(2 if pair else 1)]
-        _lib.profile_start(16)
-        if prepared:
-            nxt = _lib.NextConv(p_(ws_[0]), p_(bs_[0]), p_(ws_[1]) if pair else None, p_(bs_[1]) if pair else None, B, cout,
-                                cout if pair else 0, r, stride, m, cws.data_ptr(), cws_bytes)
-            _lib.check(L.icn_bn_stats_next(p_(a), p_(b), M, C, 1e-5, 0.1, p_(fa[0]), p_(fa[1]), p_(fa[2]), p_(ga), p_(ba), 1e-3, 0.2,
-                                           p_(fb[0]) if dual else None, p_(fb[1]) if dual else None, p_(fb[2]) if dual else None,
-                                           p_(gb) if dual else None, p_(bb) if dual else None, p_(bn_ws), ctypes.byref(nxt), st),
-                       'icn_bn_stats_next')
-        elif dual:
-            _lib.check(L.icn_bn_stats2(p_(a), p_(b), M, C, 1e-5, 0.1, p_(fa[0]), p_(fa[1]), p_(fa[2]), 1e-3, 0.2, p_(fb[0]), p_(fb[1]),
-                                       p_(fb[2]), p_(bn_ws), st), 'icn_bn_stats2')
-        else:
-            _lib.check(L.icn_bn_stats(p_(a), M, C, 1e-5, 0.1, p_(fa[0]), p_(fa[1]), p_(fa[2]), p_(bn_ws), st), 'icn_bn_stats')
-        _lib.check(L.icn_bn_relu_fwd(p_(a), p_(b), p_(fa[2]), p_(fb[2]) if dual else None, p_(ga), p_(ba), p_(gb) if dual else None,
-                                     p_(bb) if dual else None, p_(y), M, C, st), 'icn_bn_relu_fwd')
-        if pair:
-            f = L.icn_conv_pair_fwd_prepared if prepared else L.icn_conv_pair_fwd
-            _lib.check(f(p_(y), p_(ws_[0]), p_(bs_[0]), p_(ws_[1]), p_(bs_[1]), p_(outs[0]), p_(outs[1]), B, C, cout, cout, r, stride, m,
-                         cws.data_ptr(), cws_bytes, st), 'conv pair')
-        else:
-            f = L.icn_conv_fwd_prepared if prepared else L.icn_conv_fwd
-            _lib.check(f(p_(y), p_(ws_[0]), p_(bs_[0]), p_(outs[0]), B, C, cout, r, stride, m, cws.data_ptr(), cws_bytes, st), 'conv')
-        torch.cuda.synchronize()
-        _lib.profile_stop()
-        return fa + (fb if dual else []) + [y] + outs
-
-    want = run(False)
-    for _ in range(2):
-        got = run(True)
-        for x, y in zip(got, want):
-            assert torch.equal(x, y)
-    assert _lib.device_status() == 0
-
-
 def test_fused_head_matches_conv1x1_tanh():
     from geniconet_amd import fused
     torch.manual_seed(4)
