@@ -1,0 +1,531 @@
+// Ladder rung for the three-way bf16 split of the fp32 channel-mixing contraction (profiles/r06_plan.txt E1).
+//
+// Same traffic as tools/mfma_ladder.hip level 4 (the conv's real gather: A = 92160 rows x 1 KiB fp32, 7 taps = the tile's rows
+// shifted by {0,+64,+1,-63,-64,-1,+63}, 8 channel chunks of 128 B, 56 K-steps per tile), two arithmetic forms:
+//   k_f32  : v_mfma_f32_32x32x2_f32 on fp32 A and fp32 B (the production K-step; copy of k_ladder_w)
+//   k_b3   : A rows stay fp32 in LDS (LDS-DMA as today); after the fragment read every value is cut into three bf16 pieces
+//            a = a1 + a2 + a3 (truncation: a1 = a & 0xffff0000, r = a - a1, a2 = r & 0xffff0000, a3 = r - a2; exact, 3 x 8 = 24
+//            significand bits), B comes from a packed image of three bf16 planes the host splits the same way (what the conv's
+//            weight prologue would write): v_mfma_f32_32x32x16_bf16 x NP per 32x32x16 block,
+//            NP = 6: a1b3 a3b1 a2b2 a1b2 a2b1 a1b1 (small terms first), NP = 8: + a2b3 a3b2, fp32 accumulate.
+// Pricing: fp32-input MFMA runs at 1/16 of the bf16 rate on gfx950, so 6 products = 2.67x less pipe time, 8 = 2x.
+// Mode 'c' checks both forms against float64 on the host (one tile, K = 7 * 256), which also shows how the bf16 MFMA
+// accumulates its 16 products; mode 't' prints fp32-equivalent TF/s on ~4 ms and ~0.2 ms launches.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+constexpr int BK = 32;
+constexpr int A_ROWS = 92160;
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }      // fp32 rows of 128 B: 8 chunks of 16 B
+__device__ __forceinline__ int swzb(int row) { return (row >> 2) & 3; }     // bf16 rows of 64 B: 4 chunks of 16 B
+// tap shifts {0,+64,+1,-63,-64,-1,+63} + 64 packed a byte each (a branch-free scalar lookup)
+__host__ __device__ inline int shift_of(int t) { return (int)((0x7f3f00014180'40ull >> (8 * t)) & 0xff) - 64; }
+
+// ---------------------------------------------------------------------------------------------------------------- fp32 form
+template <int BM, int BN, int WR, int WC, int NST>
+__global__ __launch_bounds__(64 * WR * WC) void k_f32(const float* src, unsigned src_bytes, float* out, int steps, float* tile_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WR * WC;
+    constexpr int TM = BM / WR / 32, TN = BN / WC / 32, RA = BM / 8 / NW, RB = BN / 8 / NW, NDMA = RA + RB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);
+    float* Bs = As + NST * BM * BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC, l31 = lane & 31, h = lane >> 5, rsub = lane >> 3, pc = lane & 7;
+    for (int i = tid; i < NST * (BM + BN) * BK; i += 64 * NW) As[i] = 1e-3f * (float)((i * 37) % 101 - 50);
+    __syncthreads();
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+    const unsigned b_base = (unsigned)A_ROWS * 1024u;
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fl = swz(l31);
+    f32x4 fa[2][TM], fb[2][TN];
+    int ring = 0, iring = NST - 1;
+    auto dma = [&](int slot, int step) {
+        const int tile = (blockIdx.x + (step / 56) * gridDim.x) % (A_ROWS / BM);
+        const int t = step % 7, kc = (step / 7) % 8;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int row = tile * BM + 8 * (wave + NW * i) + rsub + shift_of(t);
+            row = row < 0 ? row + A_ROWS : (row >= A_ROWS ? row - A_ROWS : row);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(As + slot * BM * BK + 8 * (wave + NW * i) * BK), 16,
+                                                     (unsigned)row * 1024u + 16u * (pc ^ swz(8 * (wave + NW * i) + rsub)), kc * 128, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(Bs + slot * BN * BK + 8 * (wave + NW * i) * BK), 16,
+                                                     b_base + (unsigned)(t * BN + 8 * (wave + NW * i) + rsub) * 1024u +
+                                                         16u * (pc ^ swz(8 * (wave + NW * i) + rsub)), kc * 128, 0, 0);
+    };
+#pragma unroll
+    for (int q = 0; q < NST - 1; ++q) dma(q, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int step = 0; step < steps; ++step) {
+        const float* a_base = As + ring * BM * BK + (wr * (BM / WR) + l31) * BK;
+        const float* b_base_l = Bs + ring * BN * BK + (wc * (BN / WC) + l31) * BK;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + 4 * (h ^ fl));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b_base_l + j * 32 * BK + 4 * (h ^ fl));
+        dma(iring, step + NST - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                const int off = 4 * ((2 * (kk + 1) + h) ^ fl);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[(kk + 1) & 1][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + off);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[(kk + 1) & 1][j] = *reinterpret_cast<const f32x4*>(b_base_l + j * 32 * BK + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i][s], fb[kk & 1][j][s], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NDMA) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ring = ring == NST - 1 ? 0 : ring + 1;
+        iring = iring == NST - 1 ? 0 : iring + 1;
+    }
+    if (tile_out) {
+        if (blockIdx.x == 0)
+            for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r)
+                tile_out[(wr * (BM / WR) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + wc * (BN / WC) + j * 32 + l31] = acc[i][j][r];
+        return;
+    }
+    float sum = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    out[(blockIdx.x * 64 * NW + tid) % (1024 * 256)] = sum;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------ bf16 x 3 form
+// B image (global, packed by the host = the weight prologue): [7 taps][8 k-chunks] blocks of BN * 192 B laid out exactly as
+// the LDS stage wants them: [3 planes][BN rows][64 B], 16-byte chunk q of row r at chunk q ^ swzb(r) -- the DMA is a linear copy.
+struct Pieces { u32x4 p1, p2, p3; };
+__device__ __forceinline__ Pieces split8(const f32x4 lo, const f32x4 hi) {
+    unsigned x[8], r[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float l_ = lo[e], h_ = hi[e]; x[e] = __float_as_uint(l_); x[4 + e] = __float_as_uint(h_); }   // (bit_cast of a vector ELEMENT reads element 0: hipcc 7.2)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float xf = __builtin_bit_cast(float, x[e]);
+        const float rf = xf - __builtin_bit_cast(float, x[e] & 0xffff0000u);
+        r[e] = __builtin_bit_cast(unsigned, rf);
+        r2[e] = __builtin_bit_cast(unsigned, rf - __builtin_bit_cast(float, r[e] & 0xffff0000u));
+    }
+    Pieces o;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        o.p1[m] = __builtin_amdgcn_perm(x[2 * m + 1], x[2 * m], 0x07060302u);     // high halves: element 2m low, 2m+1 high
+        o.p2[m] = __builtin_amdgcn_perm(r[2 * m + 1], r[2 * m], 0x07060302u);
+        o.p3[m] = __builtin_amdgcn_perm(r2[2 * m + 1], r2[2 * m], 0x07060302u);
+    }
+    return o;
+}
+#define MF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+
+template <int BM, int BN, int WR, int WC, int NST, int NP>
+__global__ __launch_bounds__(64 * WR * WC) void k_b3(const float* src, unsigned src_bytes, float* out, int steps, float* tile_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WR * WC;
+    constexpr int TM = BM / WR / 32, TN = BN / WC / 32, RA = BM / 8 / NW, BBYTES = BN * 192, RB = BBYTES / 1024 / NW, NDMA = RA + RB;
+    static_assert(RA >= 1 && RB >= 1 && RB * NW * 1024 == BBYTES, "tile / wave grid mismatch");
+    constexpr int STAGE = BM * BK * 4 + BBYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC, l31 = lane & 31, h = lane >> 5, rsub = lane >> 3, pc = lane & 7;
+    // (the compiler does not see LDS-DMA as a store: without an ordinary store to the array every fragment read is "undef")
+    for (int i = tid; i < NST * STAGE / 4; i += 64 * NW) reinterpret_cast<float*>(smem)[i] = 1e-3f * (float)((i * 37) % 101 - 50);
+    __syncthreads();
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+    const unsigned b_base = (unsigned)A_ROWS * 1024u + (unsigned)(7 * BN) * 1024u;     // the bf16 image lies behind the fp32 weights
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int ring = 0, iring = NST - 1;
+    auto dma = [&](int slot, int step) {
+        const int tile = (blockIdx.x + (step / 56) * gridDim.x) % (A_ROWS / BM);
+        const int t = step % 7, kc = (step / 7) % 8;
+        char* st = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int row = tile * BM + 8 * (wave + NW * i) + rsub + shift_of(t);
+            row = row < 0 ? row + A_ROWS : (row >= A_ROWS ? row - A_ROWS : row);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(st + 8 * (wave + NW * i) * 128), 16,
+                                                     (unsigned)row * 1024u + 16u * (pc ^ swz(8 * (wave + NW * i) + rsub)), kc * 128, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(st + BM * 128 + (wave + NW * i) * 1024), 16,
+                                                     b_base + (unsigned)((t * 8 + kc) * BBYTES + (wave + NW * i) * 1024 + lane * 16), 0, 0, 0);
+    };
+#pragma unroll
+    for (int q = 0; q < NST - 1; ++q) dma(q, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int fa_s = swz(l31), fb_s = swzb(l31);
+    for (int step = 0; step < steps; ++step) {
+        const char* st = smem + ring * STAGE;
+        const char* a_row = st + (wr * (BM / WR) + l31) * 128;
+        const char* b_row = st + BM * 128 + (wc * (BN / WC) + l31) * 64;
+        f32x4 ra[2][TM][2];
+        u32x4 rb[2][TN][3];
+        auto read_frag = [&](int buf, int kb) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ra[buf][i][0] = *reinterpret_cast<const f32x4*>(a_row + i * 32 * 128 + 16 * ((4 * kb + 2 * h) ^ fa_s));
+                ra[buf][i][1] = *reinterpret_cast<const f32x4*>(a_row + i * 32 * 128 + 16 * ((4 * kb + 2 * h + 1) ^ fa_s));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    rb[buf][j][p] = *reinterpret_cast<const u32x4*>(b_row + p * BN * 64 + j * 32 * 64 + 16 * ((2 * kb + h) ^ fb_s));
+        };
+        read_frag(0, 0);
+        dma(iring, step + NST - 1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 0) read_frag(1, 1);
+            Pieces pa[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) pa[i] = split8(ra[kb][i][0], ra[kb][i][1]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    if (NP >= 8) { c = MF(pa[i].p2, rb[kb][j][2], c); c = MF(pa[i].p3, rb[kb][j][1], c); }
+                    c = MF(pa[i].p1, rb[kb][j][2], c);
+                    c = MF(pa[i].p3, rb[kb][j][0], c);
+                    c = MF(pa[i].p2, rb[kb][j][1], c);
+                    c = MF(pa[i].p1, rb[kb][j][1], c);
+                    c = MF(pa[i].p2, rb[kb][j][0], c);
+                    c = MF(pa[i].p1, rb[kb][j][0], c);
+                    acc[i][j] = c;
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NDMA) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ring = ring == NST - 1 ? 0 : ring + 1;
+        iring = iring == NST - 1 ? 0 : iring + 1;
+    }
+    if (tile_out) {
+        if (blockIdx.x == 0)
+            for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r)
+                tile_out[(wr * (BM / WR) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + wc * (BN / WC) + j * 32 + l31] = acc[i][j][r];
+        return;
+    }
+    float sum = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    out[(blockIdx.x * 64 * NW + tid) % (1024 * 256)] = sum;
+#endif
+}
+
+// Rotated K-step (software pipeline across the step barrier): the MFMAs of a step's SECOND k-block run after the barrier, beside
+// the fragment reads and the split of the next step's first k-block, so no wave waits for LDS latency + 44 VALU instructions with
+// an empty matrix pipe.  sched_group_barrier fixes the interleave: LEAD MFMAs alone (covers the read latency), then one MFMA per
+// VPM VALU instructions.
+template <int BM, int BN, int WR, int WC, int NST, int LEAD>
+__global__ __launch_bounds__(64 * WR * WC) void k_b3p(const float* src, unsigned src_bytes, float* out, int steps, float* tile_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WR * WC;
+    constexpr int TM = BM / WR / 32, TN = BN / WC / 32, RA = BM / 8 / NW, BBYTES = BN * 192, RB = BBYTES / 1024 / NW, NDMA = RA + RB;
+    static_assert(RA >= 1 && RB >= 1 && RB * NW * 1024 == BBYTES, "tile / wave grid mismatch");
+    constexpr int STAGE = BM * BK * 4 + BBYTES;
+    constexpr int NMF = TM * TN * 6, NVALU = 44 * TM, VPM = (NVALU + (NMF - LEAD) - 1) / (NMF - LEAD);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC, l31 = lane & 31, h = lane >> 5, rsub = lane >> 3, pc = lane & 7;
+    for (int i = tid; i < NST * STAGE / 4; i += 64 * NW) reinterpret_cast<float*>(smem)[i] = 1e-3f * (float)((i * 37) % 101 - 50);
+    __syncthreads();
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+    const unsigned b_base = (unsigned)A_ROWS * 1024u + (unsigned)(7 * BN) * 1024u;
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int ring = 0, iring = NST - 1;
+    auto dma = [&](int slot, int step) __attribute__((always_inline)) {
+        const int tile = (blockIdx.x + (step / 56) * gridDim.x) % (A_ROWS / BM);
+        const int t = step % 7, kc = (step / 7) % 8;
+        char* st = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int row = tile * BM + 8 * (wave + NW * i) + rsub + shift_of(t);
+            row = row < 0 ? row + A_ROWS : (row >= A_ROWS ? row - A_ROWS : row);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(st + 8 * (wave + NW * i) * 128), 16,
+                                                     (unsigned)row * 1024u + 16u * (pc ^ swz(8 * (wave + NW * i) + rsub)), kc * 128, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(st + BM * 128 + (wave + NW * i) * 1024), 16,
+                                                     b_base + (unsigned)((t * 8 + kc) * BBYTES + (wave + NW * i) * 1024 + lane * 16), 0, 0, 0);
+    };
+#pragma unroll
+    for (int q = 0; q < NST - 1; ++q) dma(q, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int fa_s = swz(l31), fb_s = swzb(l31);
+    f32x4 ra[TM][2];
+    u32x4 rb0[TN][3], rb1[TN][3];
+    Pieces p0[TM], p1[TM];
+    auto read_frag = [&](int rg, int kb, u32x4 (&rb)[TN][3]) __attribute__((always_inline)) {
+        const char* st = smem + rg * STAGE;
+        const char* a_row = st + (wr * (BM / WR) + l31) * 128;
+        const char* b_row = st + BM * 128 + (wc * (BN / WC) + l31) * 64;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ra[i][0] = *reinterpret_cast<const f32x4*>(a_row + i * 32 * 128 + 16 * ((4 * kb + 2 * h) ^ fa_s));
+            ra[i][1] = *reinterpret_cast<const f32x4*>(a_row + i * 32 * 128 + 16 * ((4 * kb + 2 * h + 1) ^ fa_s));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                rb[j][p] = *reinterpret_cast<const u32x4*>(b_row + p * BN * 64 + j * 32 * 64 + 16 * ((2 * kb + h) ^ fb_s));
+    };
+    auto mfmas = [&](const Pieces (&pa)[TM], const u32x4 (&rb)[TN][3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = MF(pa[i].p1, rb[j][2], c);
+                c = MF(pa[i].p3, rb[j][0], c);
+                c = MF(pa[i].p2, rb[j][1], c);
+                c = MF(pa[i].p1, rb[j][1], c);
+                c = MF(pa[i].p2, rb[j][0], c);
+                c = MF(pa[i].p1, rb[j][0], c);
+                acc[i][j] = c;
+            }
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_group_barrier(0x8, LEAD, 0);
+#pragma unroll
+        for (int q = 0; q < NMF - LEAD; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x2, VPM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        }
+    };
+    // first step's first k-block
+    read_frag(0, 0, rb0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) p0[i] = split8(ra[i][0], ra[i][1]);
+    for (int step = 0; step < steps; ++step) {
+        // (a) stage `ring` is visible; p0 / rb0 hold its first k-block.  Second k-block's reads, the next stage's DMA, then the
+        //     first k-block's MFMAs beside the split of the second.
+        read_frag(ring, 1, rb1);
+        dma(iring, step + NST - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(p0, rb0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) p1[i] = split8(ra[i][0], ra[i][1]);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NDMA) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ring = ring == NST - 1 ? 0 : ring + 1;
+        iring = iring == NST - 1 ? 0 : iring + 1;
+        // (b) the next stage is visible: its first k-block's reads, then this step's second k-block's MFMAs beside their split
+        read_frag(ring, 0, rb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(p1, rb1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) p0[i] = split8(ra[i][0], ra[i][1]);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tile_out) {
+        if (blockIdx.x == 0)
+            for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r)
+                tile_out[(wr * (BM / WR) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + wc * (BN / WC) + j * 32 + l31] = acc[i][j][r];
+        return;
+    }
+    float sum = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    out[(blockIdx.x * 64 * NW + tid) % (1024 * 256)] = sum;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------- host
+static std::vector<float> g_host;          // host copy of the fp32 part of src (activations + fp32 weights [7][128][256])
+static float* g_src; static unsigned g_src_bytes; static float* g_out; static float* g_tile;
+static int g_div = 1;
+
+static void pack_b_image(int BN) {       // three truncated bf16 planes of the fp32 weights, in the LDS stage's layout
+    const float* w = g_host.data() + (size_t)A_ROWS * 256;
+    std::vector<unsigned short> img((size_t)7 * 8 * BN * 96);
+    for (int t = 0; t < 7; ++t) for (int kc = 0; kc < 8; ++kc) for (int n = 0; n < BN; ++n) for (int k = 0; k < 32; ++k) {
+        float x = w[((size_t)t * BN + n) * 256 + kc * 32 + k];
+        unsigned u; memcpy(&u, &x, 4);
+        unsigned u1 = u & 0xffff0000u; float f1; memcpy(&f1, &u1, 4);
+        float r = x - f1; unsigned ur; memcpy(&ur, &r, 4);
+        unsigned u2 = ur & 0xffff0000u; float f2; memcpy(&f2, &u2, 4);
+        float r2 = r - f2; unsigned u3; memcpy(&u3, &r2, 4);
+        const unsigned pl[3] = {u1 >> 16, u2 >> 16, u3 >> 16};
+        const int chunk = (k / 8) ^ ((n >> 2) & 3);
+        for (int p = 0; p < 3; ++p)
+            img[((size_t)(t * 8 + kc) * BN * 96) + ((size_t)p * BN + n) * 32 + chunk * 8 + (k & 7)] = (unsigned short)pl[p];
+    }
+    hipMemcpy(reinterpret_cast<char*>(g_src) + (size_t)A_ROWS * 1024 + (size_t)7 * BN * 1024, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+}
+
+static void restore_w() {                 // the bf16 image of a narrower tile overlaps the fp32 weight rows of a wider one
+    hipMemcpy(reinterpret_cast<char*>(g_src) + (size_t)A_ROWS * 1024, g_host.data() + (size_t)A_ROWS * 256, (size_t)7 * 256 * 1024, hipMemcpyHostToDevice);
+}
+
+template <typename K> static float time_kernel(K kern, int blocks, int threads, size_t lds, int steps, int reps) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < reps; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, 0, (const float*)g_src, g_src_bytes, g_out, steps, (float*)nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
+    }
+    if (hipGetLastError() != hipSuccess) printf("  !! launch failed\n");
+    return best;
+}
+
+template <int BM, int BN, int WR, int WC, int NST> void run_f32(int bpc) {
+    restore_w();
+    const int blocks = 256 * bpc, steps = std::max(56, 4000 / bpc * 8192 / (BM * BN) / g_div);
+    const float ms = time_kernel(&k_f32<BM, BN, WR, WC, NST>, blocks, 64 * WR * WC, (size_t)NST * (BM + BN) * BK * 4, steps, g_div > 1 ? 12 : 3);
+    printf("f32    tile %3dx%-3d  %2d waves (%d x %d)  %d stages  %d block(s)/CU  %.3f ms  %7.1f TFLOP/s\n", BM, BN, WR * WC, WR, WC, NST, bpc, ms,
+           (double)blocks * steps * 2.0 * BM * BN * BK / ms / 1e9);
+}
+template <int BM, int BN, int WR, int WC, int NST, int NP> void run_b3(int bpc) {
+    pack_b_image(BN);
+    const int blocks = 256 * bpc, steps = std::max(56, 4000 / bpc * 8192 / (BM * BN) / g_div * 2);
+    const float ms = time_kernel(&k_b3<BM, BN, WR, WC, NST, NP>, blocks, 64 * WR * WC, (size_t)NST * (BM * 128 + BN * 192), steps, g_div > 1 ? 12 : 3);
+    printf("bf16x3 tile %3dx%-3d  %2d waves (%d x %d)  %d stages  %d block(s)/CU  %d products  %.3f ms  %7.1f fp32-equivalent TFLOP/s\n", BM, BN, WR * WC, WR,
+           WC, NST, bpc, NP, ms, (double)blocks * steps * 2.0 * BM * BN * BK / ms / 1e9);
+}
+
+template <int BM, int BN, int WR, int WC, int NST, int LEAD> void run_b3p(int bpc) {
+    pack_b_image(BN);
+    const int blocks = 256 * bpc, steps = std::max(56, 4000 / bpc * 8192 / (BM * BN) / g_div * 2);
+    const float ms = time_kernel(&k_b3p<BM, BN, WR, WC, NST, LEAD>, blocks, 64 * WR * WC, (size_t)NST * (BM * 128 + BN * 192), steps, g_div > 1 ? 12 : 3);
+    printf("bf16x3 tile %3dx%-3d  %2d waves (%d x %d)  %d stages  %d block(s)/CU  rotated K-step, %d lead MFMAs  %.3f ms  %7.1f fp32-equivalent TFLOP/s\n", BM, BN,
+           WR * WC, WR, WC, NST, bpc, LEAD, ms, (double)blocks * steps * 2.0 * BM * BN * BK / ms / 1e9);
+}
+
+// One tile (block 0, tile 0) after 56 K-steps = the full K = 7 * 256 contraction, against float64 on the host.
+template <int BM, int BN> static void check(const char* name, const std::vector<float>& got) {
+    const float* w = g_host.data() + (size_t)A_ROWS * 256;
+    double num = 0, den = 0, worst = 0;
+    for (int m = 0; m < BM; ++m) for (int n = 0; n < BN; ++n) {
+        double ref = 0;
+        for (int t = 0; t < 7; ++t) {
+            int row = m + shift_of(t); row = row < 0 ? row + A_ROWS : row;
+            const float* a = g_host.data() + (size_t)row * 256;
+            const float* b = w + ((size_t)t * BN + n) * 256;
+            for (int k = 0; k < 256; ++k) ref += (double)a[k] * (double)b[k];
+        }
+        const double d = got[(size_t)m * BN + n] - ref;
+        num += d * d; den += ref * ref; worst = std::max(worst, std::fabs(d));
+    }
+    printf("  %-44s rel-L2 error vs float64 %.3e   max abs %.3e (rms of the result %.3e)\n", name, std::sqrt(num / den), worst, std::sqrt(den / (BM * BN)));
+}
+template <int BM, int BN, int WR, int WC, int NP> static void check_b3(const char* name) {
+    pack_b_image(BN);
+    auto kern = &k_b3<BM, BN, WR, WC, 3, NP>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipMemset(g_tile, 0, BM * BN * 4);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64 * WR * WC), (size_t)3 * (BM * 128 + BN * 192), 0, (const float*)g_src, g_src_bytes, g_out, 56, g_tile);
+    std::vector<float> got((size_t)BM * BN);
+    hipMemcpy(got.data(), g_tile, got.size() * 4, hipMemcpyDeviceToHost);
+    check<BM, BN>(name, got);
+}
+template <int BM, int BN, int WR, int WC, int LEAD> static void check_b3p(const char* name) {
+    pack_b_image(BN);
+    auto kern = &k_b3p<BM, BN, WR, WC, 3, LEAD>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipMemset(g_tile, 0, BM * BN * 4);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64 * WR * WC), (size_t)3 * (BM * 128 + BN * 192), 0, (const float*)g_src, g_src_bytes, g_out, 56, g_tile);
+    std::vector<float> got((size_t)BM * BN);
+    hipMemcpy(got.data(), g_tile, got.size() * 4, hipMemcpyDeviceToHost);
+    check<BM, BN>(name, got);
+}
+template <int BM, int BN, int WR, int WC> static void check_f32(const char* name) {
+    restore_w();
+    auto kern = &k_f32<BM, BN, WR, WC, 3>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipMemset(g_tile, 0, BM * BN * 4);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64 * WR * WC), (size_t)3 * (BM + BN) * BK * 4, 0, (const float*)g_src, g_src_bytes, g_out, 56, g_tile);
+    std::vector<float> got((size_t)BM * BN);
+    hipMemcpy(got.data(), g_tile, got.size() * 4, hipMemcpyDeviceToHost);
+    check<BM, BN>(name, got);
+}
+
+int main(int argc, char** argv) {
+    g_src_bytes = 100u << 20;             // 92160 KiB of activations + 0.9 MB of fp32 weights + <= 2.7 MB of bf16 planes
+    hipMalloc(&g_src, g_src_bytes); hipMalloc(&g_out, 1024 * 256 * 4); hipMalloc(&g_tile, 256 * 256 * 4);
+    hipMemset(g_src, 0, g_src_bytes);
+    g_host.resize(((size_t)A_ROWS + 7 * 256) * 256);
+    {   // post-ReLU-like activations (half zeros, half |normal|-ish), weights ~ 1 / sqrt(K)
+        unsigned long long st = 88172645463325252ull;
+        auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)((st >> 11) & 0xfffffffffffffull) / 4503599627370496.0; };
+        for (size_t i = 0; i < (size_t)A_ROWS * 256; ++i) { const double u = rnd(), v = rnd(); const double g = std::sqrt(-2 * std::log(u + 1e-300)) * std::cos(6.283185307179586 * v); g_host[i] = g > 0 ? (float)(1.3 * g) : 0.f; }
+        for (size_t i = (size_t)A_ROWS * 256; i < g_host.size(); ++i) { const double u = rnd(), v = rnd(); g_host[i] = (float)(std::sqrt(-2 * std::log(u + 1e-300)) * std::cos(6.283185307179586 * v) / std::sqrt(1792.0)); }
+        hipMemcpy(g_src, g_host.data(), g_host.size() * 4, hipMemcpyHostToDevice);
+    }
+    const char mode = argc > 1 ? argv[1][0] : 't';
+    if (mode == 'c') {
+        printf("one 64x128 / 128x128 tile, K = 7 * 256 = 1792, gathered rows; fp32 activations (post-ReLU-like), weights ~ N(0, 1/K)\n");
+        check_f32<64, 128, 2, 2>("exact fp32 MFMA 32x32x2 (fmaf chain)");
+        check_b3<64, 128, 2, 2, 6>("bf16 x 3 split, 6 products (64x128)");
+        check_b3<64, 128, 2, 2, 8>("bf16 x 3 split, 8 products (64x128)");
+        check_f32<128, 128, 4, 2>("exact fp32 MFMA 32x32x2 (128x128, 8 waves)");
+        check_b3<128, 128, 4, 2, 6>("bf16 x 3 split, 6 products (128x128, 8 waves)");
+        check_b3p<128, 128, 4, 2, 3>("... rotated K-step (128x128, 8 waves)");
+        check_b3p<64, 128, 2, 2, 3>("... rotated K-step (64x128, 4 waves)");
+        check_b3p<128, 128, 4, 1, 3>("... rotated K-step (128x128, 4 waves of 32x128)");
+        return 0;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        g_div = pass == 0 ? 1 : 20;
+        printf("---- %s launches\n", pass == 0 ? "~4 ms (fp32 form)" : "~0.2 ms (fp32 form)");
+        for (int rep = 0; rep < 2; ++rep) {
+            run_f32<64, 128, 2, 2, 3>(2);            // production shape
+            run_f32<128, 128, 2, 4, 3>(1);
+            run_b3<64, 128, 2, 2, 3, 6>(1);          // 96 KB: one block per CU
+            run_b3<64, 128, 2, 2, 2, 6>(2);          // 64 KB: two blocks per CU, prefetch distance 1
+            run_b3<128, 128, 4, 2, 3, 6>(1);         // 120 KB, 8 waves of 32 x 64
+            run_b3<128, 128, 2, 2, 3, 6>(1);         // 4 waves of 64 x 64
+            run_b3<128, 128, 2, 4, 3, 6>(1);         // 8 waves of 64 x 32
+            run_b3<128, 64, 2, 2, 3, 6>(2);          // 28 KB per stage, 84 KB: one block ... (two with 2 stages)
+            run_b3<128, 64, 4, 1, 3, 6>(1);
+            run_b3<128, 128, 4, 2, 3, 8>(1);
+            run_b3p<128, 128, 4, 2, 3, 3>(1);
+            run_b3p<128, 128, 4, 2, 3, 1>(1);
+            run_b3p<128, 128, 4, 2, 3, 5>(1);
+            run_b3p<128, 128, 2, 2, 3, 3>(1);
+            run_b3p<64, 128, 2, 2, 2, 3>(2);
+            run_b3p<128, 64, 4, 1, 3, 3>(1);
+            run_b3p<128, 128, 4, 1, 3, 3>(1);        // 4 waves of 32 x 128: half the split work per MFMA, one wave per SIMD
+            run_b3p<128, 128, 4, 1, 3, 6>(1);
+        }
+    }
+    return 0;
+}
