@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('ICN_LIB_PATH') or os.path.join(_HERE, 'libicn.so')
 
 OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT = 0, 1, 2
 CORNER_MODES = {'zeros': 0, 'average': 1}
-ABI_VERSION = 6
+ABI_VERSION = 7
 LAP_MODES = {'mean-v': 0, 'v-mean': 1, 'sum-kv': 2, 'kv-sum': 3}   # ICN_LAP_* of include/icn.h
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses
@@ -68,6 +68,9 @@ SIGNATURES = {
     'icn_table_tile_lists': (ctypes.c_long, [ctypes.c_int] * 7 + [_i32p, ctypes.c_size_t]),
     'icn_set_debug_flags': (ctypes.c_int, [ctypes.c_int]),
     'icn_device_status': (ctypes.c_int, [ctypes.c_int]),
+    'icn_get_arith': (ctypes.c_int, []),
+    'icn_set_arith': (ctypes.c_int, [ctypes.c_int]),
+    'icn_build_flags': (ctypes.c_uint, []),
     'icn_host_selfcheck': (ctypes.c_long, [ctypes.c_int] * 2),
     'icn_debug_trace': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     'icn_point_to_mesh': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [ctypes.c_void_p]),
@@ -111,8 +114,38 @@ def lib():
         if handle.icn_abi_version() != ABI_VERSION:
             raise RuntimeError('geniconet_amd: libicn.so ABI %d != binding ABI %d; rebuild'
                                % (handle.icn_abi_version(), ABI_VERSION))
+        exp = handle.icn_build_flags() & 0xffff
+        if exp and os.environ.get('ICN_ALLOW_EXP') != '1':
+            raise RuntimeError('geniconet_amd: %s is a pricing build (ICN_EXP=%d: a feature of the convolution kernel is compiled '
+                               'out, its RESULTS ARE WRONG by design); set ICN_ALLOW_EXP=1 to time it' % (LIB_PATH, exp))
         _lib = handle
     return _lib
+
+
+def build_info():
+    """What was loaded: path, whether ICN_LIB_PATH overrode the in-tree library, the build switches (icn_build_flags)."""
+    f = lib().icn_build_flags()
+    return dict(path=LIB_PATH, overridden=bool(os.environ.get('ICN_LIB_PATH')), exp=f & 0xffff, conv_waves_default=(f >> 16) & 0xff,
+                chain_prio=(f >> 24) & 0xf)
+
+
+ARITH_MODES = {'f32': 0, 'bf16x3': 1}
+
+
+def get_arith():
+    v = lib().icn_get_arith()
+    if v < 0:
+        check(-1, 'icn_get_arith')
+    return {0: 'f32', 1: 'bf16x3'}[v]
+
+
+def set_arith(mode):
+    """Arithmetic of the channel-mixing contraction ('f32' exact MFMA, 'bf16x3' three-way bf16 split; include/icn.h); returns
+    the previous mode."""
+    v = lib().icn_set_arith(ARITH_MODES[mode])
+    if v < 0:
+        check(-1, 'icn_set_arith')
+    return {0: 'f32', 1: 'bf16x3'}[v]
 
 
 def source_sha256():

@@ -555,9 +555,23 @@ bool pair_supported(int B, int Cin, int C0, int C1, int r_in, int stride) {
 //   stream-K scratch = [flag words CONV_SK_FLAGS][partial-tile slots]: the persistent GEMM's last round cut in K (k_conv_dma_sk)
 //   bwd-weight [partial slabs S x 7 x Cin x C][bias partials S x C][side buffer (B, slots_fwd, Cin)]
 size_t sk_ws_bytes() { return align256((size_t)icn::CONV_SK_FLAGS * sizeof(int)) + align256(icn::conv_sk_part_bytes()); }
+// Packed-weight region of a GEMM call: [fp32 B operand, n weights][bf16 x 3 image of the same operand, 6 bytes per weight].  Both are
+// always reserved (a workspace size must not depend on the arithmetic mode a later call runs under); a call fills what it reads.
+size_t wpack_f32_bytes(size_t n) { return align256(n * sizeof(float)); }
+size_t wpack_bytes(size_t n) { return wpack_f32_bytes(n) + align256(n * 6); }
+// Decide the arithmetic of one GEMM launch and point the prologue and the launch at the matching weight image (a: complete but for wt)
+void choose_arith(icn::GatherGemmArgs& a, icn::PrologueArgs& p, float* wreg, size_t n_weights, bool also_f32) {
+    const int bn = icn::conv_b3_bn(a);
+    a.arith_bn = bn;
+    p.packed = (bn == 0 || also_f32) ? wreg : nullptr;
+    p.packed_b3 = bn ? reinterpret_cast<char*>(wreg) + wpack_f32_bytes(n_weights) : nullptr;
+    p.b3_bn = bn;
+    p.b3_flat_n = (a.T == 1 && p.transpose == 0) ? 1 : 0;
+    a.wt = bn ? static_cast<const float*>(p.packed_b3) : wreg;
+}
 size_t conv_ws_bytes(int op, int B, int Cin, int C0, int C1, int r_in, int stride) {
     const int C = C0 + C1, n_out = (1 << r_in) / stride, M = B * 10 * n_out * n_out;
-    const size_t wbytes = align256((size_t)7 * Cin * C * sizeof(float));
+    const size_t wbytes = wpack_bytes((size_t)7 * Cin * C);
     switch (op) {
         case ICN_OP_CONV_FWD:
             if (!icn::gather_gemm_supported(Cin, C)) return 0;
@@ -582,7 +596,7 @@ char* at(void* ws, size_t off) { return static_cast<char*>(ws) + off; }
 void conv_fwd_impl(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, float* y0, float* y1, int B,
                    int Cin, int C0, int C1, int r_in, int stride, const ConvTables& t, void* ws, hipStream_t s) {
     const int C = C0 + C1;
-    const size_t wbytes = align256((size_t)7 * Cin * C * sizeof(float));
+    const size_t wbytes = wpack_bytes((size_t)7 * Cin * C);
     float* wf = static_cast<float*>(ws);
     float* bias_cat = (w1 && b0) ? reinterpret_cast<float*>(at(ws, wbytes)) : nullptr;
     const size_t side_off = wbytes + (w1 ? align256((size_t)C * sizeof(float)) : 0);
@@ -595,20 +609,21 @@ void conv_fwd_impl(const float* x, const float* w0, const float* b0, const float
     p.bias = b0; p.bias2 = b1; p.bias_cat = bias_cat;
     p.src = x; p.slots = t.d_fwd.slots; p.side = side; p.n_slots = t.d_fwd.n_slots; p.E = 1; p.B = B; p.Ps = t.Pin; p.K = Cin;
     p.ns = t.n_in;
-    icn::launch_conv_prologue(p, s);
     icn::GatherGemmArgs a{};
-    a.src = x; a.wt = wf; a.bias = w1 ? bias_cat : b0; a.dst = y0; a.dst2 = w1 ? y1 : nullptr; a.N0 = C0;
+    a.src = x; a.bias = w1 ? bias_cat : b0; a.dst = y0; a.dst2 = w1 ? y1 : nullptr; a.N0 = C0;
     a.idx = t.fwd; a.dcode = t.d_fwd.code; a.side = side; a.n_slots = t.d_fwd.n_slots;
     a.M = B * t.Pout; a.Ps = t.Pin; a.Pd = t.Pout; a.K = Cin; a.N = C; a.E = 1; a.ns = t.n_in;
     a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pout;
     a.sk_part = sk_part; a.sk_flag = sk_flag;
+    choose_arith(a, p, wf, (size_t)7 * Cin * C, false);
+    icn::launch_conv_prologue(p, s);
     icn::launch_gather_gemm_auto(a, s);
 }
 
 void conv_bwd_data_impl(const float* dy0, const float* dy1, const float* w0, const float* w1, float* dx, int B, int Cin, int C0,
                         int C1, int r_in, int stride, const ConvTables& t, void* ws, hipStream_t s) {
     const int C = C0 + C1;
-    const size_t wbytes = align256((size_t)7 * Cin * C * sizeof(float));
+    const size_t wbytes = wpack_bytes((size_t)7 * Cin * C);
     const TableCounts tc = table_counts(r_in, stride);
     const size_t side_bytes = align256((size_t)B * tc.slots_bwd * C0 * sizeof(float));
     float* wb = static_cast<float*>(ws);
@@ -630,19 +645,21 @@ void conv_bwd_data_impl(const float* dy0, const float* dy1, const float* w0, con
     p.src = dy0; p.src2 = dy1; p.slots = ds.slots; p.side = side; p.side2 = side2; p.n_slots = ds.n_slots; p.E = ds.E; p.B = B;
     p.Ps = t.Pout; p.K = C0; p.ns = t.n_out;
     p.zero = sk_flag; p.n_zero = icn::CONV_SK_FLAGS;
-    icn::launch_conv_prologue(p, s);
     icn::GatherGemmArgs a{};
-    a.src = dy0; a.src2 = dy1; a.wt = wb; a.dst = dx; a.N0 = Cin;
+    a.src = dy0; a.src2 = dy1; a.dst = dx; a.N0 = Cin;
     a.idx = split ? t.bwd1 : (stride == 2 ? t.bwd_perm : t.bwd); a.dcode = dm.code; a.side = side; a.side2 = side2;
     a.n_slots = dm.n_slots; a.perm = t.perm; a.mask32 = t.mask32;
     a.mask32_host = t.mask32_h.empty() ? nullptr : t.mask32_h.data(); a.mask_key = t.key;
     a.M = B * t.Pin; a.Ps = t.Pout; a.Pd = t.Pin; a.K = C; a.N = Cin; a.E = split ? 1 : t.E; a.ns = t.n_out;
     a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pout;
     a.sk_part = sk_part; a.sk_flag = sk_flag;             // (only the main launch: the flags are cleared once per call)
+    choose_arith(a, p, wb, (size_t)7 * Cin * C, split);   // (the virtual-row GEMM below stays on the fp32 operand)
+    icn::launch_conv_prologue(p, s);
     icn::launch_gather_gemm_auto(a, s);
     if (split) {
         // second, small GEMM over the virtual rows, then dx[b, vq[v], :] += result[b, v, :]
         icn::GatherGemmArgs v = a;
+        v.wt = wb; v.arith_bn = 0;
         v.sk_part = nullptr; v.sk_flag = nullptr;
         v.dst = vout; v.idx = t.vidx; v.dcode = t.d_virt.code; v.n_slots = t.d_virt.n_slots; v.perm = t.vorder; v.mask32 = t.vmask32;
         v.M = B * t.nvp; v.Pd = t.nvp; v.E = 1;
@@ -690,7 +707,9 @@ const char* const PROF_NAMES[PROF_KINDS] = {"k_conv_dma<128, 128, false>", "k_co
                                             "k_conv_dma8<64, 128, false>", "k_conv_dma8<64, 128, true>", "k_conv_dma_sk8<64, 128, false>",
                                             "k_conv_dma_sk8<64, 128, true>", "k_conv_dense_sk<64, 128>", "k_conv_dense_sk<64, 64>", "k_conv_single_sk<64, 128>",
                                             "k_conv_single_sk<64, 64>", "k_wgrad_dense<128, 128>", "k_wgrad_dense<128, 64>",
-                                            "k_wgrad_dense<64, 128>", "k_wgrad_dense<64, 64>"};
+                                            "k_wgrad_dense<64, 128>", "k_wgrad_dense<64, 64>",
+                                            "k_conv_b3_sk<128, 128, 8>", "k_conv_b3_sk<128, 64, 4>", "k_conv_b3_dense_sk<128, 128, 8>",
+                                            "k_conv_b3_dense_sk<128, 64, 4>"};
 void prof_mark_begin(int kind, double flops, hipStream_t s) {
     if (!g_prof_on) return;
     g_prof_mu.lock();
@@ -957,7 +976,7 @@ size_t upconv_ws_bytes(int B, int Cin, int C0, int C1, int r_in) {
     const size_t C = (size_t)C0 + C1;
     const size_t composite = align256((size_t)icn::UPCONV_TAPS * C * Cin * sizeof(float)) + align256(C * sizeof(float)) +
                              align256((size_t)B * upconv_slots(r_in) * Cin * sizeof(float));
-    const size_t dense = align256((size_t)7 * C * Cin * sizeof(float)) + align256(C * sizeof(float)) +
+    const size_t dense = wpack_bytes((size_t)7 * C * Cin) + align256(C * sizeof(float)) +
                          align256((size_t)B * icn::pixels(r_in) * 7 * C * sizeof(float)) + sk_ws_bytes();
     return upconv_dense_ok(B, Cin, C0, C1, r_in) ? std::max(composite, dense) : composite;
 }
@@ -992,7 +1011,7 @@ int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const fl
         const int C = Cout0 + Cout1;
         if (upconv_use_dense(B, Cin, Cout0, Cout1, r_in)) {
             const UpconvBwdDev& d = upconv_bwd_tables(r_in, corner_mode);
-            const size_t wb = align256((size_t)7 * C * Cin * sizeof(float)), bb = align256((size_t)C * sizeof(float));
+            const size_t wb = wpack_bytes((size_t)7 * C * Cin), bb = align256((size_t)C * sizeof(float));
             float* wf = static_cast<float*>(ws);
             float* bias_cat = (w1 && bias0) ? reinterpret_cast<float*>(at(ws, wb)) : nullptr;
             float* z = reinterpret_cast<float*>(at(ws, wb + bb));
@@ -1001,14 +1020,15 @@ int icn_upconv_fwd(const float* x, const float* w0, const float* bias0, const fl
             p.zero = sk_flag; p.n_zero = icn::CONV_SK_FLAGS;
             p.w = w0; p.w2 = w1; p.packed = wf; p.Cout = Cout0; p.Cout2 = Cout1; p.Cin = Cin; p.transpose = 0;
             p.bias = bias0; p.bias2 = bias1; p.bias_cat = bias_cat;
-            icn::launch_conv_prologue(p, s);
             icn::GatherGemmArgs a{};
-            a.src = x; a.wt = wf; a.dst = z; a.N0 = 7 * C; a.dcode = d.iota; a.perm = nullptr;   // identity rows: no destination-row table
+            a.src = x; a.dst = z; a.N0 = 7 * C; a.dcode = d.iota; a.perm = nullptr;   // identity rows: no destination-row table
             a.Ps = d.Pc; a.Pd = d.Pc; a.K = Cin; a.N = 7 * C; a.E = 1; a.T = 1; a.M = B * d.Pc;
             a.segs.nseg = 1; a.segs.B = B; a.segs.cnt[0] = d.Pc; a.segs.off[0] = 0; a.segs.mask[0] = 1u;
             a.algo_flops = 2.0 * 7 * Cin * C * (double)B * d.Pc;                  // executed: a quarter of the fine-level forward
             a.sk_flag = sk_flag;
             a.sk_part = reinterpret_cast<float*>(reinterpret_cast<char*>(sk_flag) + align256((size_t)icn::CONV_SK_FLAGS * sizeof(int)));
+            choose_arith(a, p, wf, (size_t)7 * C * Cin, false);
+            icn::launch_conv_prologue(p, s);
             icn::launch_gather_gemm_auto(a, s);
             const EllSplitDev& sc = d.scatter;
             const float* bias = w1 ? bias_cat : bias0;
@@ -1066,7 +1086,7 @@ UpconvBwdWs upconv_bwd_ws(int B, int Cin, int C0, int C1, int r_in) {
     UpconvBwdWs w{};
     w.g = 0;
     w.wb = align256((size_t)M * 7 * C * sizeof(float));
-    w.partial = w.wb + align256((size_t)7 * C * Cin * sizeof(float));
+    w.partial = w.wb + wpack_bytes((size_t)7 * C * Cin);
     w.bpart = w.partial + wgrad_partial_bytes(M, Cin, C, C1 ? C0 : C);
     w.sk = w.bpart + wgrad_bias_partial_bytes(M, Cin, C, C1 ? C0 : C);   // stream-K scratch of the dx GEMM
     w.total = w.sk + sk_ws_bytes();
@@ -1136,14 +1156,15 @@ int icn_upconv_bwd_streams(const float* x, const float* dy0, const float* dy1, c
             p.w = w0; p.w2 = w1; p.packed = wb; p.Cout = Cout0; p.Cout2 = Cout1; p.Cin = Cin; p.transpose = 2;
             int* sk_flag = reinterpret_cast<int*>(at(ws, wo.sk));
             p.zero = sk_flag; p.n_zero = icn::CONV_SK_FLAGS;
-            icn::launch_conv_prologue(p, s);
             icn::GatherGemmArgs a{};
-            a.src = g; a.wt = wb; a.dst = dx; a.N0 = Cin; a.dcode = t.iota; a.perm = nullptr;   // identity rows
+            a.src = g; a.dst = dx; a.N0 = Cin; a.dcode = t.iota; a.perm = nullptr;   // identity rows
             a.Ps = t.Pc; a.Pd = t.Pc; a.K = 7 * C; a.N = Cin; a.E = 1; a.T = 1; a.M = M;
             a.segs.nseg = 1; a.segs.B = B; a.segs.cnt[0] = t.Pc; a.segs.off[0] = 0; a.segs.mask[0] = 1u;
             a.algo_flops = 2.0 * 7 * Cin * C * (double)B * t.Pc;            // executed: a quarter of the fine-level bwd-data it replaces
             a.sk_flag = sk_flag;
             a.sk_part = reinterpret_cast<float*>(reinterpret_cast<char*>(sk_flag) + align256((size_t)icn::CONV_SK_FLAGS * sizeof(int)));
+            choose_arith(a, p, wb, (size_t)7 * C * Cin, false);
+            icn::launch_conv_prologue(p, s);
             icn::launch_gather_gemm_auto(a, s);
         }
         if (dw0) {
@@ -1357,6 +1378,24 @@ long icn_table_tile_lists(int r_in, int stride, int corner_mode, int B, int bm, 
 }
 
 int icn_set_debug_flags(int flags) { return icn::set_debug_flags(flags); }
+
+int icn_get_arith(void) {
+    try {
+        return icn::arith_mode();
+    } catch (const std::exception& e) {
+        fail(e.what());
+        return -1;
+    }
+}
+int icn_set_arith(int mode) {
+    try {
+        return icn::set_arith_mode(mode);
+    } catch (const std::exception& e) {
+        fail(e.what());
+        return -1;
+    }
+}
+unsigned icn_build_flags(void) { return icn::build_flags(); }
 
 int icn_debug_trace(void* device_buffer, size_t n_u64) {
     icn::set_trace_buffer(device_buffer, n_u64);

@@ -62,6 +62,7 @@ namespace icn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
 
 __device__ __forceinline__ int corner_pixel(int n, int k, int c) {
     return k == 0 ? (c * n) * 2 * n : ((c + 1) * n - 1) * 2 * n + (2 * n - 1);
@@ -99,7 +100,44 @@ __global__ __launch_bounds__(256) void k_conv_prologue(PrologueArgs a, int npack
     if (a.zero && blockIdx.x == 0)
         for (int i = threadIdx.x; i < a.n_zero; i += 256) a.zero[i] = 0;
     if ((int)blockIdx.x < npack) {
-        const int Ct = a.Cout + a.Cout2, total = Ct * a.Cin * 7;
+        const int Ct = a.Cout + a.Cout2, total = a.packed ? Ct * a.Cin * 7 : 0;
+        if (a.packed_b3) {
+            // ARITH = 1: the same B operand [T][N][K] as three planes of truncated bf16 pieces (w = w1 + w2 + w3, exact), stored block
+            // by block (tap, k-chunk of 32, column tile of b3_bn) exactly as conv_dma_body's LDS stage wants it: [3 planes][b3_bn rows]
+            // [64 B], 16-byte chunk q of row r at q ^ ((r >> 2) & 3) -- so the kernel's B DMA is a linear copy.  A thread packs 8
+            // consecutive k of one row: one 16-byte store per plane.
+            // (b3_flat_n: the dense forward GEMM of icn_upconv_fwd reads [7][Ct][Cin] as ONE tap with N = 7 * Ct columns)
+            const int T_ = (a.transpose == 2 || a.b3_flat_n) ? 1 : 7, N_ = a.transpose == 0 ? (a.b3_flat_n ? 7 * Ct : Ct) : a.Cin;
+            const int K_ = a.transpose == 0 ? a.Cin : (a.transpose == 1 ? Ct : 7 * Ct);
+            const int kg = K_ / 8, nk_ = K_ / 32, bn = a.b3_bn, ntn_ = N_ / bn, groups = T_ * N_ * kg;
+            for (int g = blockIdx.x * 256 + threadIdx.x; g < groups; g += npack * 256) {
+                const int k8 = g % kg, n = (g / kg) % N_, tt = g / (kg * N_);
+                unsigned pl[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k8 * 8 + e;
+                    int t, co, ci;
+                    if (a.transpose == 0) { t = a.b3_flat_n ? n / Ct : tt; co = a.b3_flat_n ? n - t * Ct : n; ci = k; }
+                    else if (a.transpose == 1) { t = tt; ci = n; co = k; }
+                    else { ci = n; t = k / Ct; co = k - t * Ct; }
+                    const float x = co < a.Cout ? a.w[((size_t)co * a.Cin + ci) * 7 + t] : a.w2[((size_t)(co - a.Cout) * a.Cin + ci) * 7 + t];
+                    const unsigned u1 = __float_as_uint(x) & 0xffff0000u;
+                    const float r = x - __uint_as_float(u1);
+                    const unsigned u2 = __float_as_uint(r) & 0xffff0000u;
+                    const unsigned u3 = __float_as_uint(r - __uint_as_float(u2));
+                    const int sh = 16 * (e & 1);
+                    pl[0][e >> 1] |= (u1 >> 16) << sh;
+                    pl[1][e >> 1] |= (u2 >> 16) << sh;
+                    pl[2][e >> 1] |= (u3 >> 16) << sh;
+                }
+                const int kc = k8 >> 2, q = k8 & 3, tn = n / bn, nl = n - tn * bn;
+                char* blk = reinterpret_cast<char*>(a.packed_b3) + ((size_t)(tt * nk_ + kc) * ntn_ + tn) * ((size_t)bn * 192);
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    *reinterpret_cast<u32x4_t*>(blk + (size_t)pp * bn * 64 + nl * 64 + ((q ^ ((nl >> 2) & 3)) * 16)) =
+                        u32x4_t{pl[pp][0], pl[pp][1], pl[pp][2], pl[pp][3]};
+            }
+        }
         for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += npack * 256) {
             // i enumerates the OUTPUT layout so that stores are coalesced
             int t, co, ci;
@@ -420,7 +458,34 @@ constexpr unsigned SIDE_FLAG = 0x80000000u;
 constexpr unsigned NOTHING_OFFSET = 0xC0000000u;
 
 // (body of the two kernels below: k_conv_dma<BM, BN, SEG> and its stream-K form k_conv_dma_sk<BM, BN>)
-template <int BM, int BN, bool SEG, bool SK, int NW = 4, int NT = 7>   // NW waves per workgroup as 2 x NW/2 (4: 256 threads; 8: 512, round 5); NT: taps of a plain launch (7; 1 = a dense GEMM through the plain code path, round 5); SEG: class-major rows + virtual taps of a composite table (icn_upconv_*)
+// ARITH (round 6): 0 = exact fp32 (v_mfma_f32_32x32x2_f32); 1 = the three-way bf16 split -- A rows stay fp32 in LDS and are cut into
+// three bf16 pieces after the fragment read (a = a1 + a2 + a3 by truncation: exact, 3 x 8 = 24 significand bits), B is the weight
+// prologue's packed image of three bf16 planes (pack_b3 below), six v_mfma_f32_32x32x16_bf16 per 32x32x16 block (a1b3 a3b1 a2b2 a1b2
+// a2b1 a1b1, small terms first), fp32 accumulate: 2.67x less matrix-pipe time, 1.2x the exact kernel's rounding error
+// (profiles/r06_ladder_b3.txt).  Waves are then 4 (rows) x NW/4 (columns), tiles 128 rows high.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+struct Pieces3 { u32x4 p1, p2, p3; };
+__device__ __forceinline__ Pieces3 split_bf16x3(const f32x4 lo, const f32x4 hi) {
+    unsigned x[8], r[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float l_ = lo[e], h_ = hi[e]; x[e] = __float_as_uint(l_); x[4 + e] = __float_as_uint(h_); }   // (__builtin_bit_cast of a vector ELEMENT reads element 0: hipcc 7.2)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float rf = __uint_as_float(x[e]) - __uint_as_float(x[e] & 0xffff0000u);
+        r[e] = __float_as_uint(rf);
+        r2[e] = __float_as_uint(rf - __uint_as_float(r[e] & 0xffff0000u));
+    }
+    Pieces3 o;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {                 // the high halves of two values: element 2m in the low, 2m + 1 in the high 16 bits
+        o.p1[m] = __builtin_amdgcn_perm(x[2 * m + 1], x[2 * m], 0x07060302u);
+        o.p2[m] = __builtin_amdgcn_perm(r[2 * m + 1], r[2 * m], 0x07060302u);
+        o.p3[m] = __builtin_amdgcn_perm(r2[2 * m + 1], r2[2 * m], 0x07060302u);
+    }
+    return o;
+}
+
+template <int BM, int BN, bool SEG, bool SK, int NW = 4, int NT = 7, int ARITH = 0>   // NW waves per workgroup as 2 x NW/2 (4: 256 threads; 8: 512, round 5); NT: taps of a plain launch (7; 1 = a dense GEMM through the plain code path, round 5); SEG: class-major rows + virtual taps of a composite table (icn_upconv_*)
 __device__ __forceinline__ void conv_dma_body(
     const float* __restrict__ src,      // (B, Ps, Ks)   Ks = K, or K / 2 with src2
     const float* __restrict__ src2,     // second half of the K axis (pair bwd-data), or null
@@ -451,11 +516,15 @@ __device__ __forceinline__ void conv_dma_body(
     // m = b * Pd + q; all of the class-major machinery compiles away there.
     constexpr unsigned INVALID_ROW = 0xFFFFFFFFu;      // destination-row table: padding row (nothing is stored)
     const int T = SEG ? T_arg : NT;
-    constexpr int WC = NW / 2, NTHR = 64 * NW;         // waves along N (2 along M); threads
-    constexpr int TM = BM / 64, TN = BN / (32 * WC);   // 32 x 32 MFMA tiles per wave
-    constexpr int RA = BM / (8 * NW), RB = BN / (8 * NW);   // rows per lane (one 16-byte chunk of each)
-    static_assert(NW == 4 || NW == 8, "2 x 2 or 2 x 4 waves");
-    static_assert(TN >= 1 && RA >= 1 && RB >= 1, "tile too small for this wave grid");
+    constexpr bool B3 = ARITH == 1;
+    constexpr int WR = B3 ? 4 : 2;                     // waves along M
+    constexpr int WC = NW / WR, NTHR = 64 * NW;        // waves along N; threads
+    constexpr int TM = BM / (32 * WR), TN = BN / (32 * WC);   // 32 x 32 MFMA tiles per wave
+    constexpr int BROW = B3 ? 48 : BK;                 // floats of LDS per B row and stage: 128 B of fp32, or 3 bf16 planes x 64 B
+    constexpr int RA = BM / (8 * NW), RB = BN * BROW / (256 * NW);   // 1 KiB DMA pieces per wave and stage (A: 8 rows each)
+    static_assert(NW == 4 || NW == 8, "2 x 2 / 2 x 4 waves, or 4 x 1 / 4 x 2 with ARITH = 1");
+    static_assert(TM >= 1 && TN >= 1 && RA >= 1 && RB >= 1 && RB * 256 * NW == BN * BROW, "tile too small for this wave grid");
+    static_assert(!B3 || !SEG, "bf16x3 arithmetic: plain rows only");
     constexpr int NDMA = RA + RB;                      // DMA instructions per wave per stage
     constexpr int RL = BM / 64;                        // tile rows per lane in the metadata pass (row r*64 + lane)
     constexpr int NJ = (SEG ? 7 : NT) * RL;            // code DMA instructions per tile (64 codes each)
@@ -465,8 +534,8 @@ __device__ __forceinline__ void conv_dma_body(
     constexpr bool IDENT = !SEG && NT == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);        // [3][BM*32]   3-stage ring
-    float* Bs = As + 3 * BM * BK;                      // [3][BN*32]
-    unsigned* otab = reinterpret_cast<unsigned*>(Bs + 3 * BN * BK);   // [2][7][BM] source byte offset of each row
+    float* Bs = As + 3 * BM * BK;                      // [3][BN*32]   (ARITH = 1: [3][3 planes][BN][32 bf16])
+    unsigned* otab = reinterpret_cast<unsigned*>(Bs + 3 * BN * BROW);   // [2][7][BM] source byte offset of each row
     unsigned* drow_s = otab + 2 * 7 * BM;              // [3][BM] destination row of each tile row (perm != null only)
     float* bias_s = reinterpret_cast<float*>(drow_s + (perm ? 3 * BM : 0));   // [3][BN] (bias != null only)
 
@@ -480,7 +549,7 @@ __device__ __forceinline__ void conv_dma_body(
 
     const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
     const auto rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src2 ? src2 : src), 0, src_bytes, 0x00020000);
-    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, T * N * K * 4, 0x00020000);
+    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, T * N * K * (B3 ? 6 : 4), 0x00020000);
     const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side ? side : src), 0, side ? side_bytes : 0u,
                                                           0x00020000);
     const auto rsrc_s2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(side2 ? side2 : src), 0, side2 ? side_bytes : 0u,
@@ -550,7 +619,8 @@ __device__ __forceinline__ void conv_dma_body(
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int row = 8 * (wave + NW * i) + rsub;
-        bconst[i] = (unsigned)row * (unsigned)K * 4u + 16u * (pc ^ swz(row));
+        bconst[i] = B3 ? (unsigned)((wave + NW * i) * 1024 + lane * 16)      // the bf16 image is stored as the stage wants it: a linear copy
+                       : (unsigned)row * (unsigned)K * 4u + 16u * (pc ^ swz(row));
     }
     // gather code of row (sample b) -> DMA byte offset
     auto row_offset = [&](int32_t c, int b) __attribute__((always_inline)) {
@@ -614,7 +684,7 @@ __device__ __forceinline__ void conv_dma_body(
     const int fl = swz(l31);
     f32x4 fa[2][TM], fb[2][TN];
     auto frag0 = [&](int ring) {                          // first fragments of a stage (issued before the DMA)
-        const float* a_base = As + ring * BM * BK + (wr * (BM / 2) + l31) * BK;
+        const float* a_base = As + ring * BM * BK + (wr * (BM / WR) + l31) * BK;
         const float* b_base = Bs + ring * BN * BK + (wc * (BN / WC) + l31) * BK;
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * BK + 4 * (h ^ fl));
@@ -622,7 +692,7 @@ __device__ __forceinline__ void conv_dma_body(
         for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * BK + 4 * (h ^ fl));
     };
     auto compute = [&](int ring) {
-        const float* a_base = As + ring * BM * BK + (wr * (BM / 2) + l31) * BK;
+        const float* a_base = As + ring * BM * BK + (wr * (BM / WR) + l31) * BK;
         const float* b_base = Bs + ring * BN * BK + (wc * (BN / WC) + l31) * BK;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -644,6 +714,58 @@ __device__ __forceinline__ void conv_dma_body(
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i][sidx], fb[kk & 1][j][sidx], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- ARITH = 1: fragments of one 16-wide k-block (kb = 0, 1 of a stage): per 32-row A tile 8 fp32 of row l31 (k = 16 kb + 8 h ..),
+    // per 32-column B tile and plane 8 bf16 of row l31 (one ds_read_b128; 64-byte rows, chunk q at q ^ ((row >> 2) & 3)).
+    // The K-step is ROTATED across its barrier: the six-MFMA groups of a stage's second k-block issue after the barrier, beside the
+    // reads and the split of the next stage's first k-block, so no wave sits through LDS latency + 44 VALU instructions with an
+    // empty matrix pipe; sched_group_barrier fixes the interleave (B3_LEAD MFMAs first, then one MFMA per B3_VPM VALU instructions).
+    f32x4 ra3[TM][2];
+    u32x4 rb3[2][TN][3];
+    Pieces3 pa3[2][TM];
+    constexpr int B3_NMF = TM * TN * 6, B3_LEAD = 3, B3_VPM = (44 * TM + (B3_NMF - B3_LEAD) - 1) / (B3_NMF - B3_LEAD);
+    auto b3_read = [&](int ring, int kb) __attribute__((always_inline)) {
+        const char* a_row = reinterpret_cast<const char*>(As + ring * BM * BK + (wr * (BM / WR) + l31) * BK);
+        const char* b_row = reinterpret_cast<const char*>(Bs + ring * BN * BROW) + (wc * (BN / WC) + l31) * 64;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ra3[i][0] = *reinterpret_cast<const f32x4*>(a_row + i * 32 * 128 + 16 * ((4 * kb + 2 * h) ^ fl));
+            ra3[i][1] = *reinterpret_cast<const f32x4*>(a_row + i * 32 * 128 + 16 * ((4 * kb + 2 * h + 1) ^ fl));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                rb3[kb][j][pl] = *reinterpret_cast<const u32x4*>(b_row + pl * BN * 64 + j * 32 * 64 + 16 * ((2 * kb + h) ^ ((l31 >> 2) & 3)));
+    };
+    auto b3_split = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) pa3[kb][i] = split_bf16x3(ra3[i][0], ra3[i][1]);
+    };
+#define ICN_MF16(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), c_, 0, 0, 0)
+    auto b3_mfmas = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = ICN_MF16(pa3[kb][i].p1, rb3[kb][j][2], c);
+                c = ICN_MF16(pa3[kb][i].p3, rb3[kb][j][0], c);
+                c = ICN_MF16(pa3[kb][i].p2, rb3[kb][j][1], c);
+                c = ICN_MF16(pa3[kb][i].p1, rb3[kb][j][1], c);
+                c = ICN_MF16(pa3[kb][i].p2, rb3[kb][j][0], c);
+                c = ICN_MF16(pa3[kb][i].p1, rb3[kb][j][0], c);
+                acc[i][j] = c;
+            }
+    };
+    auto b3_interleave = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_group_barrier(0x8, B3_LEAD, 0);
+#pragma unroll
+        for (int q = 0; q < B3_NMF - B3_LEAD; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x2, B3_VPM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
         }
     };
 
@@ -743,7 +865,8 @@ __device__ __forceinline__ void conv_dma_body(
             const int tn0 = __builtin_amdgcn_readfirstlane(i_own ? n0 : nn0); \
             const int sec_ = __builtin_amdgcn_readfirstlane(i_kc >= nk0);   /* k-chunk of the second source tensor */ \
             const int a_soff = __builtin_amdgcn_readfirstlane((sec_ ? i_kc - nk0 : i_kc) * (BK * 4)); \
-            const int b_soff = __builtin_amdgcn_readfirstlane(((i_t * N + tn0) * K + i_kc * BK) * 4); \
+            const int b_soff = __builtin_amdgcn_readfirstlane(B3 ? ((i_t * nk + i_kc) * ntn + tn0 / BN) * (BN * 192)   /* image block (tap, k-chunk, column tile) */ \
+                                                                  : ((i_t * N + tn0) * K + i_kc * BK) * 4); \
             const auto ra_ = sec_ ? rsrc_a2 : rsrc_a; \
             bool side_row = false; \
 _Pragma("unroll") \
@@ -769,7 +892,7 @@ _Pragma("unroll") \
             } \
 _Pragma("unroll") \
             for (int i = 0; i < RB; ++i) { \
-                float* lds_dst = Bs + __builtin_amdgcn_readfirstlane(i_ring * BN * BK + 8 * (wave + NW * i) * BK); \
+                float* lds_dst = Bs + __builtin_amdgcn_readfirstlane(i_ring * BN * BROW + 8 * (wave + NW * i) * BK); \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)lds_dst, 16, bconst[i], b_soff, 0, 0); \
             } \
             i_ring = i_ring == 2 ? 0 : i_ring + 1; \
@@ -870,13 +993,35 @@ _Pragma("unroll") \
         if (SK && trace && tr_split == 0 && (c_s0 > 0 || c_s1 < sk_S)) tr_split = __builtin_amdgcn_s_memrealtime();
         for (int step = 0; step < S; ++step) {
             const bool meta = !(ICN_EXP & 2) && step == 0 && has_next;      // wave-uniform
+            if constexpr (B3) {
+                b3_read(c_ring, 0);
+                if (meta) ICN_META_ISSUE();
+                ICN_ISSUE_STAGE();
+                __builtin_amdgcn_sched_barrier(0);
+                if (step > 0) {                           // the previous stage's second k-block beside this stage's first split
+                    b3_mfmas(1);
+                    b3_split(0);
+                    b3_interleave();
+                } else {
+                    b3_split(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                b3_read(c_ring, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                b3_mfmas(0);
+                b3_split(1);
+                b3_interleave();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
             frag0(c_ring);
             if (meta) ICN_META_ISSUE();                   // next tile's tables: consumed >= 2 K-steps from now
             ICN_ISSUE_STAGE();                            // stage s+2
             compute(c_ring);
+            }
             ICN_RETIRE_AND_PUBLISH(meta);                 // stage s+1 landed and visible
             c_ring = c_ring == 2 ? 0 : c_ring + 1;
         }
+        if constexpr (B3) b3_mfmas(1);                    // the segment's last k-block
         if (trace) tr_e0 = __builtin_amdgcn_s_memrealtime();          // K-steps of the segment done: epilogue + switch from here
         bool sk_store = true;
         if constexpr (SK) {
@@ -985,7 +1130,7 @@ _Pragma("unroll") \
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        dr[i][r] = drow_s[eslot * BM + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                        dr[i][r] = drow_s[eslot * BM + wr * (BM / WR) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -997,7 +1142,7 @@ _Pragma("unroll") \
                 const auto rd = second ? rsrc_d2 : rsrc_d;
                 const unsigned cb = (unsigned)(second ? col - N0 : col) * 4u;
                 if (!perm) {      // GEMM row m is output row m (also the dense one-tap GEMMs: one identity segment)
-                    const unsigned base = (unsigned)(m0 + wr * (BM / 2) + 4 * h) * rs + cb;  // (rows >= d_rows: >= num_records, dropped)
+                    const unsigned base = (unsigned)(m0 + wr * (BM / WR) + 4 * h) * rs + cb;  // (rows >= d_rows: >= num_records, dropped)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1065,6 +1210,7 @@ _Pragma("unroll") \
 #undef ICN_META_ISSUE
 #undef ICN_META_CONVERT
 #undef ICN_RETIRE_AND_PUBLISH
+#undef ICN_MF16
 #endif
 }
 
@@ -1137,6 +1283,37 @@ __global__ __launch_bounds__(256) void k_conv_dense_sk(const float* __restrict__
                                              src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
 }
 
+// ARITH = 1 forms (round 6; conv_dma_body's header): the stream-K kernel of the plain 7-tap convolutions (single or pair) and of the
+// dense one-tap GEMMs on the three-way bf16 split.  128-row tiles, waves 4 x NW/4, one workgroup per CU (3 x 40 KB ring at 128 x 128).
+template <int BM, int BN, int NW>
+__global__ __launch_bounds__(64 * NW) void k_conv_b3_sk(const float* __restrict__ src, const float* __restrict__ src2,
+                                                         const float* __restrict__ wt, const float* __restrict__ bias,
+                                                         float* __restrict__ dst, float* __restrict__ dst2,
+                                                         const int32_t* __restrict__ dcode, const float* __restrict__ side,
+                                                         const float* __restrict__ side2, const int32_t* __restrict__ perm, int M, int Ps,
+                                                         int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes,
+                                                         unsigned side_bytes, int ntiles, int T_arg, const RowSegs segs, int sk_mp,
+                                                         float* __restrict__ sk_part, int* __restrict__ sk_flag,
+                                                         int* __restrict__ sk_status, int sk_spin_limit,
+                                                         unsigned long long* __restrict__ trace, const int* __restrict__ sk_bnd) {
+    conv_dma_body<BM, BN, false, true, NW, 7, 1>(src, src2, wt, bias, dst, dst2, dcode, side, side2, nullptr, nullptr, M, Ps, Pd, K, N, N0, n_slots,
+                                                 src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
+}
+template <int BM, int BN, int NW>
+__global__ __launch_bounds__(64 * NW) void k_conv_b3_dense_sk(const float* __restrict__ src, const float* __restrict__ src2,
+                                                               const float* __restrict__ wt, const float* __restrict__ bias,
+                                                               float* __restrict__ dst, float* __restrict__ dst2,
+                                                               const int32_t* __restrict__ dcode, const float* __restrict__ side,
+                                                               const float* __restrict__ side2, const int32_t* __restrict__ perm, int M, int Ps,
+                                                               int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes,
+                                                               unsigned side_bytes, int ntiles, int T_arg, const RowSegs segs, int sk_mp,
+                                                               float* __restrict__ sk_part, int* __restrict__ sk_flag,
+                                                               int* __restrict__ sk_status, int sk_spin_limit,
+                                                               unsigned long long* __restrict__ trace, const int* __restrict__ sk_bnd) {
+    conv_dma_body<BM, BN, false, true, NW, 1, 1>(src, nullptr, wt, bias, dst, nullptr, dcode, nullptr, nullptr, nullptr, nullptr, M, Ps, Pd, K, N, N, 0,
+                                                 src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
+}
+
 // Eight waves per workgroup (2 x 4 waves of 32 x 32; round 5): the same tile, LDS image, ring and tables as the four-wave kernels, the
 // stage's DMA rows / metadata entries / epilogue columns dealt over twice the waves -- 3 instead of 6 DMA instructions and 16 instead
 // of 32 MFMAs per wave and K-step, four waves per SIMD at two workgroups per CU to cover each other's barriers and stage issues
@@ -1171,8 +1348,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_dma_sk8(const float* __restrict
 }
 
 // dynamic LDS of k_conv_dma: A/B rings, offset table, destination-row table (row permutation only), bias (bias only)
-static size_t conv_dma_lds(int bm, int bn, bool perm, bool bias) {
-    return (size_t)3 * (bm + bn) * BK * 4 + (size_t)2 * 7 * bm * 4 + (perm ? (size_t)3 * bm * 4 : 0) + (bias ? (size_t)3 * bn * 4 : 0) +
+static size_t conv_dma_lds(int bm, int bn, bool perm, bool bias, bool b3 = false) {
+    return (size_t)3 * (bm * 128 + bn * (b3 ? 192 : 128)) + (size_t)2 * 7 * bm * 4 + (perm ? (size_t)3 * bm * 4 : 0) + (bias ? (size_t)3 * bn * 4 : 0) +
            16;   // + the stream-K form's block-uniform "partner lost" word
 }
 
@@ -1419,6 +1596,79 @@ static void launch_conv_dma_sk(const GatherGemmArgs& a, int occ, hipStream_t s) 
     launch_conv_dma_sk_t<BM, BN, true, NW>(b, occ, s);
 }
 
+// ---- ARITH = 1 launches (round 6) ---------------------------------------------------------------------------------------------
+// Arithmetic of the channel-mixing contraction: 0 = exact fp32 MFMA (default), 1 = three-way bf16 split (conv_dma_body's header).
+// ICN_ARITH=f32|bf16x3 sets the process default; icn_set_arith (include/icn.h) changes it at run time (tests, A/B).
+unsigned build_flags() { return ((unsigned)ICN_EXP & 0xffffu) | ((unsigned)ICN_CONV_WAVES_DEFAULT << 16) | ((unsigned)ICN_CHAIN_PRIO << 24); }
+static std::atomic<int> g_arith{-1};
+int arith_mode() {
+    int v = g_arith.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("ICN_ARITH");
+        if (e == nullptr || e[0] == 0 || strcmp(e, "f32") == 0) v = 0;
+        else if (strcmp(e, "bf16x3") == 0) v = 1;
+        else throw std::invalid_argument("icn: ICN_ARITH must be f32 or bf16x3");
+        g_arith.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+int set_arith_mode(int mode) {
+    if (mode != 0 && mode != 1) throw std::invalid_argument("icn: arithmetic mode must be 0 (f32) or 1 (bf16x3)");
+    const int old = arith_mode();
+    g_arith.store(mode, std::memory_order_relaxed);
+    return old;
+}
+// Column tile of the bf16 image this launch would read (128 or 64), or 0: the launch stays on the fp32 kernels.  Covered: what the
+// stream-K kernels cover -- plain 7-tap convolutions (single / pair, forward and stride-1 data gradients) and the dense one-tap
+// GEMMs with identity rows.  The caller (icn_api.cpp) asks BEFORE the prologue so that the weights are packed to match.
+int conv_b3_bn(const GatherGemmArgs& a) {
+    if (arith_mode() != 1 || !conv_dma_usable(a) || !conv_sk_eligible(a)) return 0;
+    const bool dense = a.segs.nseg > 0;
+    if (dense && !conv_dense_plain(a)) return 0;
+    const int taps = dense ? 1 : 7;
+    if (a.N % 64 != 0 || a.K % BK != 0 || taps * (a.K / BK) < 4) return 0;
+    if ((size_t)taps * a.N * a.K * 6 >= ((size_t)1 << 31)) return 0;
+    return a.N % 128 == 0 ? 128 : 64;
+}
+
+template <int BM, int BN, int NW, bool DENSE>
+static void launch_conv_b3_sk_t(const GatherGemmArgs& a, hipStream_t s) {
+    constexpr auto kern = [] {
+        if constexpr (DENSE) return &k_conv_b3_dense_sk<BM, BN, NW>;
+        else return &k_conv_b3_sk<BM, BN, NW>;
+    }();
+    constexpr int occ = 1;
+    check_dma_ranges(a);
+    const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+    const int grid = 256 * occ;
+    if ((size_t)grid * BM * BN * sizeof(float) > conv_sk_part_bytes() || grid > CONV_SK_ERROR)
+        throw std::invalid_argument("icn: stream-K grid beyond its scratch");
+    const size_t lds = conv_dma_lds(BM, BN, false, a.bias != nullptr, true);
+    static std::atomic<uint64_t> attr_devices{0};
+    if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
+    }
+    const int Ks = a.src2 ? a.K / 2 : a.K;
+    const size_t nb = (size_t)(a.M / a.Pd);
+    const unsigned src_bytes = (unsigned)(nb * a.Ps * Ks * 4), side_bytes = (unsigned)(nb * a.n_slots * Ks * 4);
+    prof_mark_begin((DENSE ? PROF_B3DENSEK_128x128 : PROF_B3K_128x128) + (BN == 128 ? 0 : 1), a.algo_flops, s);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,
+                       a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.M, a.Ps, a.Pd, a.K,
+                       a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, DENSE ? 1 : 7, RowSegs{}, CONV_SK_MIN_PIECE,
+                       a.sk_part, a.sk_flag, device_status_word(), (dbg_flags() & 256) ? -1 : ((1 << 22) | ((dbg_flags() & 8192) ? (1 << 28) : 0)),
+                       g_trace_cap >= (size_t)grid * 8 ? g_trace : nullptr,
+                       sk_boundary_tables(ntiles, grid, DENSE ? a.K / BK : 7 * (a.K / BK), occ));
+    prof_mark_end(s);
+}
+static void launch_conv_b3(const GatherGemmArgs& a, hipStream_t s) {
+    const int bn = conv_b3_bn(a);
+    if (bn == 0 || bn != a.arith_bn) throw std::invalid_argument("icn: bf16x3 launch whose weights were packed for another tile");
+    const bool dense = a.segs.nseg > 0;
+    if (bn == 128) return dense ? launch_conv_b3_sk_t<128, 128, 8, true>(a, s) : launch_conv_b3_sk_t<128, 128, 8, false>(a, s);
+    return dense ? launch_conv_b3_sk_t<128, 64, 4, true>(a, s) : launch_conv_b3_sk_t<128, 64, 4, false>(a, s);
+}
+
 // Waves per workgroup of the 64 x 128 tile's launches: 8 (2 x 4 waves of 32 x 32: k_conv_dma8 / k_conv_dma_sk8) or 4 (2 x 2 waves
 // of 32 x 64); the other tiles have the four-wave form only.  Default 4: measured in round 5 (profiles/r05_ladder_production_rungs.txt)
 // the eight-wave form is +1 % on the dominant class alone, -2 % on the decoder heads' dense GEMMs and -0.9 % in the training step.
@@ -1528,6 +1778,7 @@ static int pick_tile(int M, int N, int E) {
 }
 
 void launch_gather_gemm_auto(const GatherGemmArgs& a, hipStream_t s) {
+    if (a.arith_bn != 0) return launch_conv_b3(a, s);      // (set by the caller from conv_b3_bn, with weights packed to match)
     if (conv_dma_usable(a)) return launch_conv_dma_auto(a, s);
     if (a.src2 || a.dst2) throw std::invalid_argument("icn: pair gather-GEMM outside the LDS-DMA kernel's limits");
     if (a.segs.nseg > 0 || a.T > 7) throw std::invalid_argument("icn: composite gather-GEMM outside the LDS-DMA kernel's limits");
@@ -3117,7 +3368,8 @@ void launch_upconv_prologue(const UpconvPrologueArgs& a, hipStream_t s) {
 }
 
 void launch_conv_prologue(const PrologueArgs& a, hipStream_t s) {
-    const int npack = a.w ? std::min(2048, ((a.Cout + a.Cout2) * a.Cin * 7 + 255) / 256) : 0;
+    if (a.packed_b3 && a.b3_bn != 64 && a.b3_bn != 128) throw std::invalid_argument("icn: bf16 weight image needs a column tile of 64 or 128");
+    const int npack = (a.w && (a.packed || a.packed_b3)) ? std::min(2048, ((a.Cout + a.Cout2) * a.Cin * 7 + 255) / 256) : 0;
     const int nside = (a.side && a.n_slots > 0) ? a.B * a.n_slots * (a.src2 ? 2 : 1) : 0;
     if (npack + nside == 0 && !a.zero) return;
     hipLaunchKernelGGL(k_conv_prologue, dim3(std::max(1, npack + nside)), dim3(256), 0, s, a, npack);

@@ -45,7 +45,14 @@ struct GatherGemmArgs {
     RowSegs segs;           // nseg > 0: class-major rows (M = padded row count, perm = list position -> dst pixel)
     float* sk_part;         // stream-K scratch: conv_sk_part_bytes() bytes, or null (no stream-K)
     int* sk_flag;           // CONV_SK_FLAGS ints zeroed before the launch (PrologueArgs::zero), with sk_part
+    int arith_bn;           // 0: fp32 arithmetic, wt = [T][N][K] fp32.  64 / 128 (= conv_b3_bn(args) asked BEFORE the prologue): the
+                            // three-way bf16 split, wt = the prologue's bf16 image for that column tile (PrologueArgs::packed_b3)
 };
+// arithmetic of the channel-mixing contraction (icn_kernels.hip): 0 exact fp32, 1 three-way bf16 split; process default ICN_ARITH
+int arith_mode();
+int set_arith_mode(int mode);
+unsigned build_flags();     // ICN_EXP | ICN_CONV_WAVES_DEFAULT << 16 | ICN_CHAIN_PRIO << 24 of this build (icn_build_flags)
+int conv_b3_bn(const GatherGemmArgs& a);
 constexpr int CONV_SK_ERROR = 1024;                        // flag words: [0, 1024) one per block (the grid's upper bound)
 constexpr int CONV_SK_FLAGS = 1032;
 // The device's asynchronous failure word (pinned host memory mapped to the device; bit 0: a stream-K partner never arrived)
@@ -147,6 +154,9 @@ struct PrologueArgs {
     const float* bias; const float* bias2; float* bias_cat;
     const float* src; const float* src2; const int32_t* slots; float* side; float* side2; int n_slots, E, B, Ps, K, ns;
     int* zero; int n_zero;  // words to clear (the stream-K flags of the GEMM this prologue precedes), or null
+    int b3_flat_n;                // transpose 0 only: the image is ONE tap of N = 7 * (Cout + Cout2) columns (icn_upconv_fwd's dense GEMM)
+    void* packed_b3; int b3_bn;   // bf16 x 3 image of the same B operand for column tile b3_bn (6 bytes per weight), or null; `packed`
+                                  // may then be null (no fp32 copy wanted)
 };
 void launch_conv_prologue(const PrologueArgs& a, hipStream_t s);
 
@@ -221,6 +231,7 @@ enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA
                 PROF_DENSEK_64x128, PROF_DENSEK_64x64,       // k_conv_dense_sk: one-tap dense GEMMs on the plain path
                 PROF_SINGLEK_64x128, PROF_SINGLEK_64x64,     // k_conv_single_sk: single convolutions (no second tensors)
                 PROF_WGDENSE_128x128, PROF_WGDENSE_128x64, PROF_WGDENSE_64x128, PROF_WGDENSE_64x64,   // k_wgrad_dense: the heads' dW = x^T g
+                PROF_B3K_128x128, PROF_B3K_128x64, PROF_B3DENSEK_128x128, PROF_B3DENSEK_128x64,       // ARITH = 1 forms (round 6)
                 PROF_KINDS };
 extern const char* const PROF_NAMES[PROF_KINDS];
 void prof_mark_begin(int kind, double flops, hipStream_t s);   // no-ops unless profiling is on

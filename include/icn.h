@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ICN_ABI_VERSION 6
+#define ICN_ABI_VERSION 7
 
 #define ICN_CORNER_ZEROS 0
 #define ICN_CORNER_AVERAGE 1
@@ -305,6 +305,23 @@ long icn_host_selfcheck(int r, int corner_mode);
 
 #define ICN_STATUS_STREAMK_LOST 1
 int icn_device_status(int clear);
+
+/* Arithmetic of the channel-mixing contraction (ABI 7; the reference computes in fp32 on PyTorch, models.py / run.py have no
+ * autocast -- SURVEY F1).  ICN_ARITH_F32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32; the default).  ICN_ARITH_BF16X3: every fp32 operand
+ * is cut into three bf16 pieces (24 significand bits, exact) and the product is six bf16 MFMAs with fp32 accumulation -- fp32-grade
+ * results (1.2 x the exact kernel's rounding error against float64, tests/test_gpu_arith.py) at 2.67 x less matrix-pipe time; used
+ * by the stream-K forms of the plain convolutions and the dense GEMMs, everything else stays on the exact kernels.  The process
+ * default comes from the environment (ICN_ARITH=f32|bf16x3).  icn_set_arith returns the previous mode, or -1 (icn_last_error). */
+#define ICN_ARITH_F32 0
+#define ICN_ARITH_BF16X3 1
+int icn_get_arith(void);
+int icn_set_arith(int mode);
+
+/* Build switches of the loaded library (ABI 7): bits 0..15 = ICN_EXP (pricing builds that leave a feature of the convolution kernel
+ * out -- THEIR RESULTS ARE WRONG BY DESIGN, only launch times are read; 0 = the product), bits 16..23 = the default wave count of
+ * the 64 x 128 tile (ICN_CONV_WAVES_DEFAULT), bits 24..27 = ICN_CHAIN_PRIO.  geniconet_amd._lib refuses a library whose ICN_EXP bits
+ * are non-zero unless ICN_ALLOW_EXP=1. */
+unsigned icn_build_flags(void);
 
 #ifdef __cplusplus
 }
