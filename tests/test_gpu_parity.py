@@ -15,6 +15,16 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+@pytest.fixture
+def exact_arith():
+    """Tests that compare two SCHEDULES of the exact-fp32 kernels bit for bit (stream-K vs whole tiles, wave counts, wrappers) name
+    those kernels: they pin the arithmetic to f32 whatever ICN_ARITH says (the split kernels have their own file, test_gpu_arith.py)."""
+    from geniconet_amd import _lib
+    prev = _lib.set_arith('f32')
+    yield
+    _lib.set_arith(prev)
+
+
 def conv_both(r, stride, cin, cout, B, mode, seed, bias=True):
     from geniconet_amd.ico_conv import ico_conv
     g = torch.Generator().manual_seed(seed)
@@ -185,7 +195,7 @@ def test_all_taps_weight_gradient_kernel_equals_the_per_tap_kernel(case):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
 
 
-def test_tensors_beyond_2gib_take_the_fallback_kernels_and_agree_with_half_batches():
+def test_tensors_beyond_2gib_take_the_fallback_kernels_and_agree_with_half_batches(exact_arith):
     """Maximum sizes: the LDS-DMA kernels address their operands through 32-bit buffer offsets, so a tensor of 2 GiB or
     more is routed to the register-staged kernels (per pass: what counts is the tensor that pass gathers from -- x for the
     forward and the weight gradient, dy for the input gradient).  r = 7, 128 -> 128 channels, batch 36: 3.0 GB each; a
@@ -254,7 +264,7 @@ SK_CASES = [(4, 128, 128, 36, False), (2, 256, 256, 36, False), (3, 128, 128, 36
 
 
 @pytest.mark.parametrize('r,cin,cout,B,pair', SK_CASES, ids=lambda v: str(v))
-def test_stream_k_equals_whole_tile_schedule(r, cin, cout, B, pair):
+def test_stream_k_equals_whole_tile_schedule(r, cin, cout, B, pair, exact_arith):
     from geniconet_amd import _lib
     from geniconet_amd.ico_conv import ico_conv, ico_conv_pair
     g = torch.Generator().manual_seed(r * 100 + cin)
@@ -306,7 +316,7 @@ def test_stream_k_equals_whole_tile_schedule(r, cin, cout, B, pair):
 
 
 @pytest.mark.parametrize('r,cin,cout,B', [(2, 256, 256, 36), (3, 256, 128, 36), (4, 128, 64, 9)])
-def test_stream_k_in_the_decoder_heads_dense_gemms(r, cin, cout, B):
+def test_stream_k_in_the_decoder_heads_dense_gemms(r, cin, cout, B, exact_arith):
     """The one-tap dense GEMMs of icn_upconv_fwd / icn_upconv_bwd in their stream-K form -- since round 5 on the plain code path
     (k_conv_dense_sk: SEG = false with one tap), under debug flag 32768 on the class-major one (k_conv_dma_sk<.., true>) -- against
     the whole-tile schedule (flag 128: k_conv_dma<.., true>), new data each trial."""
@@ -453,7 +463,7 @@ def test_lds_staged_sparse_passes_equal_the_row_per_thread_kernels(r, cin, cout,
         assert bool(torch.isfinite(a).all())
 
 
-def test_the_single_convolution_wrapper_equals_the_general_stream_k_kernel():
+def test_the_single_convolution_wrapper_equals_the_general_stream_k_kernel(exact_arith):
     """k_conv_single_sk (round 5: src2 = dst2 = side2 = null known at compile time) against k_conv_dma_sk<.., false> (debug flag
     65536): the same instructions minus the pair forms' selects -- forward and data gradient bit-identical."""
     from geniconet_amd import _lib
@@ -483,7 +493,7 @@ EIGHT_WAVE_CASES = [(4, 128, 128, 36, False), (3, 256, 256, 7, False), (2, 256, 
 
 
 @pytest.mark.parametrize('r,cin,cout,B,pair', EIGHT_WAVE_CASES, ids=lambda v: str(v))
-def test_eight_wave_kernels_equal_the_four_wave_kernels(r, cin, cout, B, pair):
+def test_eight_wave_kernels_equal_the_four_wave_kernels(r, cin, cout, B, pair, exact_arith):
     """k_conv_dma8 / k_conv_dma_sk8 (the 64 x 128 tile on 2 x 4 waves of 32 x 32, built, measured and left
     off by default) against the production four-wave kernels: every output element is accumulated by one wave over the same
     K-steps in the same order, and the stream-K plan is the same, so forward outputs and data gradients are BIT-identical --
@@ -1035,7 +1045,7 @@ def test_upconv_pair_matches_oracle_upsample_then_convs(case):
     _lib.profile_start(64)
     yg = ico_upconv_pair(xg, wg[0], bg[0], wg[1], bg[1], r, mode)
     prof = _lib.profile_stop()
-    assert sum(e['launches'] for e in prof) == 1 and (prof[0]['kernel'].startswith('k_conv_dense') or
+    assert sum(e['launches'] for e in prof) == 1 and (prof[0]['kernel'].startswith(('k_conv_dense', 'k_conv_b3_dense')) or
                                                       (prof[0]['kernel'].startswith('k_conv_dma') and 'true' in prof[0]['kernel'])), prof
     torch.autograd.backward(yg, [gy.cuda() for gy in gys])
     pairs = {'y0': (yg[0], yr[0]), 'y1': (yg[1], yr[1]), 'dx': (xg.grad, xr.grad), 'dw0': (wg[0].grad, wr[0].grad),
