@@ -744,6 +744,14 @@ __device__ __forceinline__ void conv_dma_body(
 #pragma unroll
         for (int i = 0; i < TM; ++i) pa3[kb][i] = split_bf16x3(ra3[i][0], ra3[i][1]);
     };
+    // the pieces are consumed a barrier later: without a use HERE hipcc sinks the whole split below the step's MFMAs and waits
+    auto b3_pin = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                asm volatile("" : "+v"(pa3[kb][i].p1[m]), "+v"(pa3[kb][i].p2[m]), "+v"(pa3[kb][i].p3[m]));
+    };
 #define ICN_MF16(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), c_, 0, 0, 0)
     auto b3_mfmas = [&](int kb) __attribute__((always_inline)) {
 #pragma unroll
@@ -1001,6 +1009,7 @@ _Pragma("unroll") \
                 if (step > 0) {                           // the previous stage's second k-block beside this stage's first split
                     b3_mfmas(1);
                     b3_split(0);
+                    b3_pin(0);
                     b3_interleave();
                 } else {
                     b3_split(0);
@@ -1010,6 +1019,7 @@ _Pragma("unroll") \
                 __builtin_amdgcn_sched_barrier(0);
                 b3_mfmas(0);
                 b3_split(1);
+                b3_pin(1);
                 b3_interleave();
                 __builtin_amdgcn_sched_barrier(0);
             } else {
