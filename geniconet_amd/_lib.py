@@ -64,6 +64,7 @@ SIGNATURES = {
     'icn_reparam_fwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_size_t] + [_c_float_p] + [ctypes.c_void_p]),
     'icn_reparam_bwd': (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_size_t] + [_c_float_p] * 2 + [ctypes.c_void_p]),
     'icn_adam_step': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_double] * 4 + [ctypes.c_void_p]),
+    'icn_adam_step_dev': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_double] * 4 + [ctypes.c_void_p]),
     'icn_table_stream_k': (ctypes.c_long, [ctypes.c_int] * 4 + [_i32p, ctypes.c_size_t]),
     'icn_table_tile_lists': (ctypes.c_long, [ctypes.c_int] * 7 + [_i32p, ctypes.c_size_t]),
     'icn_set_debug_flags': (ctypes.c_int, [ctypes.c_int]),

@@ -1332,6 +1332,28 @@ int icn_adam_step(int count, float* const* params, const float* const* grads, fl
     }
 }
 
+int icn_adam_step_dev(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                      const size_t* numel, const float* scalars_dev, double beta1, double beta2, double eps, double weight_decay,
+                      void* stream) {
+    try {
+        if (count < 0 || (count > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)) || !scalars_dev)
+            throw std::invalid_argument("icn_adam_step_dev: bad arguments");
+        for (int i = 0; i < count; ++i)
+            if (numel[i] > 0 && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]))
+                throw std::invalid_argument("icn_adam_step_dev: null tensor pointer");
+        if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0))
+            throw std::invalid_argument("icn_adam_step_dev: betas must lie in [0, 1), eps must not be negative");
+        if (count == 0) return 0;
+        std::vector<float> same(count, 0.f);              // one step count for all tensors: one group of launches
+        icn::launch_adam(count, params, grads, exp_avg, exp_avg_sq, numel, same.data(), same.data(), beta1, beta2, eps, weight_decay,
+                         static_cast<hipStream_t>(stream), scalars_dev);
+        ICN_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e.what());
+    }
+}
+
 long icn_table_stream_k(int ntiles, int grid, int nk, int ku, int32_t* out, size_t cap) {
     try {
         if (ntiles < 1 || grid < 8 || grid % 8 != 0 || nk < 1 || ku < 1)

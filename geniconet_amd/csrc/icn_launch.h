@@ -240,6 +240,7 @@ void prof_mark_end(hipStream_t s);
 // icn_optim.hip: Adam over a list of tensors, one launch per ADAM_MAX_TENSORS of them with equal step counts (table in the kernel arguments)
 constexpr int ADAM_MAX_TENSORS = 96;
 void launch_adam(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const size_t* numel,
-                 const float* step_size, const float* bc2_sqrt, double beta1, double beta2, double eps, double weight_decay, hipStream_t s);
+                 const float* step_size, const float* bc2_sqrt, double beta1, double beta2, double eps, double weight_decay, hipStream_t s,
+                 const float* scal_dev = nullptr);   // scal_dev: device {step_size, bc2_sqrt} for ALL tensors (graph capture)
 
 }  // namespace icn

@@ -30,6 +30,9 @@ struct AdamTable {
     unsigned first_block[ADAM_MAX_TENSORS + 1];   // prefix sums of the tensors' chunk counts
     int count;
     float step_size, bc2_sqrt;                    // one launch = tensors with the same step count
+    const float* scal;                            // device copy of {step_size, bc2_sqrt} read instead of the two above when non-null:
+                                                  // a launch recorded into a HIP graph must not carry the step's scalars in its
+                                                  // arguments (icn_adam_step_dev)
 };
 static_assert(sizeof(AdamTable) <= 4000, "kernel arguments are limited to 4 KB");
 
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void k_adam(const AdamTable t, float b1c, floa
     const float* __restrict__ g = t.g[lo];
     float* __restrict__ m = t.m[lo];
     float* __restrict__ v = t.v[lo];
-    const float ss = t.step_size, bc = t.bc2_sqrt;
+    const float ss = t.scal ? t.scal[0] : t.step_size, bc = t.scal ? t.scal[1] : t.bc2_sqrt;
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                        reinterpret_cast<uintptr_t>(v)) & 15) == 0;
 #pragma unroll
@@ -90,7 +93,8 @@ __global__ __launch_bounds__(256) void k_adam(const AdamTable t, float b1c, floa
 }
 
 void launch_adam(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const size_t* numel,
-                 const float* step_size, const float* bc2_sqrt, double beta1, double beta2, double eps, double weight_decay, hipStream_t s) {
+                 const float* step_size, const float* bc2_sqrt, double beta1, double beta2, double eps, double weight_decay, hipStream_t s,
+                 const float* scal_dev) {
     // one launch per group of tensors that share (step_size, bc2_sqrt), i.e. the step count -- normally all of them
     std::vector<char> done(count, 0);
     for (int lead = 0; lead < count; ++lead) {
@@ -98,6 +102,7 @@ void launch_adam(int count, float* const* p, const float* const* g, float* const
         AdamTable t{};
         t.step_size = step_size[lead];
         t.bc2_sqrt = bc2_sqrt[lead];
+        t.scal = scal_dev;
         unsigned blocks = 0;
         auto flush = [&]() {
             t.first_block[t.count] = blocks;

@@ -86,3 +86,50 @@ class Adam(torch.optim.Adam):
                                          float(group['weight_decay']), torch.cuda.current_stream(dev).cuda_stream)
                 _lib.check(rc, 'icn_adam_step')
         return loss
+
+    # ---- the step as part of a HIP graph (Trainer, ICN_GRAPH=1) ---------------------------------------------------------------
+    def graph_ready(self):
+        """One parameter group the HIP step covers, every tensor on one device with one step count: what step_captured needs."""
+        groups = self._hip_groups()
+        if groups is None or len(groups) != 1 or not groups[0][1]:
+            return False
+        ps = groups[0][1]
+        if len({p.device for p in ps}) != 1 or any(not p.grad.is_contiguous() for p in ps):
+            return False
+        steps = {float(self.state[p]['step']) if self.state.get(p) else 0.0 for p in ps}
+        return len(steps) == 1
+
+    @torch.no_grad()
+    def step_captured(self, scalars_dev):
+        """Launch the step with step_size / bc2_sqrt read from `scalars_dev` (2 floats on the device): called ONCE, inside the
+        capture of the training step.  The step counts are NOT advanced here (host state): advance_host does that per replay."""
+        (group, ps), = self._hip_groups()
+        for p in ps:
+            st = self.state[p]
+            if len(st) == 0:
+                st['step'] = torch.tensor(0.0, dtype=torch.float32)
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        n = len(ps)
+        vp = ctypes.c_void_p * n
+        beta1, beta2 = group['betas']
+        numel = (ctypes.c_size_t * n)(*[p.numel() for p in ps])
+        pa = vp(*[p.data_ptr() for p in ps])
+        ga = vp(*[p.grad.data_ptr() for p in ps])
+        ma = vp(*[self.state[p]['exp_avg'].data_ptr() for p in ps])
+        va = vp(*[self.state[p]['exp_avg_sq'].data_ptr() for p in ps])
+        dev = ps[0].device
+        with torch.cuda.device(dev):
+            rc = _lib.lib().icn_adam_step_dev(n, pa, ga, ma, va, numel, scalars_dev.data_ptr(), float(beta1), float(beta2),
+                                              float(group['eps']), float(group['weight_decay']),
+                                              torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, 'icn_adam_step_dev')
+        self._captured = [self.state[p]['step'] for p in ps]
+
+    def advance_host(self):
+        """Per replay: step counts + 1 (host tensors, as step() does) -> (step_size, bc2_sqrt) as step() would have passed them."""
+        group = self.param_groups[0]
+        beta1, beta2 = group['betas']
+        torch._foreach_add_(self._captured, 1.0)
+        k = float(self._captured[0])
+        return float(group['lr']) / (1.0 - beta1 ** k), (1.0 - beta2 ** k) ** 0.5

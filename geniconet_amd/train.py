@@ -86,7 +86,7 @@ def build_criterion(params, device):
 
 class Trainer:
     def __init__(self, params, device, model=None, criterion=None, seed=0, anomaly=False, channels_last=True, force_ddp=None,
-                 check_device_status=None):
+                 check_device_status=None, graph=None):
         self.params, self.device, self.anomaly = params, torch.device(device), anomaly
         # debug mode: after every step, synchronise and raise if a kernel reported a failure (icn_device_status)
         self.check_device_status = (os.environ.get('ICN_CHECK', '') == '1') if check_device_status is None else check_device_status
@@ -147,6 +147,11 @@ class Trainer:
         self.last_output = None
         if not hasattr(self, '_grads_in_buckets'):
             self._grads_in_buckets = False
+        # The step as ONE HIP graph (the loop body of run.py:244-254): ICN_GRAPH=1 / graph=True.  Replayed from the
+        # third step on (the first two run eagerly: tables, caches and the allocator settle); see _step_graph for what it covers.
+        self.graph = (os.environ.get('ICN_GRAPH', '') == '1') if graph is None else bool(graph)
+        self._g = None
+        self._eager_steps = {}                             # (img shape, lbl shape) -> eager steps run on it
 
     def _broadcast_initial_state_via_host(self):
         """Rank 0's parameters and buffers to every rank through CPU tensors (what DDP's init_sync does on the device)."""
@@ -185,9 +190,92 @@ class Trainer:
         else:
             self._bucket_of, self._bucket_sig = None, sig
 
+    # ---- the step as a HIP graph ----------------------------------------------------------------------------------------------
+    GRAPH_SCALAR_SLOTS = 8          # pinned {step_size, bc2_sqrt} slots: the host may run this many replays ahead of the device
+
+    def graph_usable(self, img=None, keep_output=False):
+        """Why the graph path cannot take this step (a string), or None.  Covered: the plain trainer on one device -- forward, loss,
+        backward with the weight gradients on their side stream (forked from and joined to the capture stream inside the graph),
+        Adam, with CyclicLR's learning rate and Adam's bias corrections as device scalars.  Not covered (stay eager, said here):
+        DistributedDataParallel (its reducer's hooks and bucket rebuilds are host logic per step), detect_anomaly, models that draw
+        random numbers per step (ico2ico_vae's reparameterisation) or whose loss carries a host-side factor that changes
+        (P2PKLD_Loss.update_factor), keep_output, the per-step status check."""
+        if self.device.type != 'cuda':
+            return 'not on a ROCm device'
+        if self.net is not self.model:
+            return 'DistributedDataParallel stays eager'
+        if self.anomaly or self.check_device_status or keep_output:
+            return 'detect_anomaly / per-step status check / keep_output need the eager step'
+        if self.params[self.params['model_name']]['loss'] != 'p2p':
+            return 'a loss with per-step host state (KL factor) or a model with per-step random numbers stays eager'
+        if not isinstance(self.optimizer, optim.Adam):
+            return 'optimizer without a capturable step'
+        return None
+
+    def _capture(self, img, lbl):
+        g = {'shape': (tuple(img.shape), tuple(lbl.shape))}
+        g['img'] = torch.empty_like(img)                  # static inputs: every replay reads these addresses
+        g['lbl'] = torch.empty_like(lbl)
+        g['img'].copy_(img)
+        g['lbl'].copy_(lbl)
+        g['scal'] = torch.zeros(2, dtype=torch.float32, device=self.device)
+        g['pinned'] = [torch.zeros(2, dtype=torch.float32).pin_memory() for _ in range(self.GRAPH_SCALAR_SLOTS)]
+        g['events'] = [None] * self.GRAPH_SCALAR_SLOTS
+        g['n'] = 0
+        # Nothing may keep an earlier step's autograd graph alive: its AccumulateGrad nodes belong to the stream that step ran on, and
+        # the engine would order the captured backward after that stream -- a dependency outside the capture (ends in a crash in
+        # hipStreamEndCapture).  The Trainer's own reference is last_output (keep_output=True).
+        self.last_output = None
+        self.optimizer.zero_grad(set_to_none=True)         # gradients are allocated inside the capture: static addresses
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            output = self.net(g['img'])
+            loss = self.criterion(output, g['lbl'])
+            prev = set_weight_gradient_stream(*self._weight_gradient_mode())
+            try:
+                loss.backward()
+            finally:
+                set_weight_gradient_stream(*prev)
+            if not self.optimizer.graph_ready():
+                raise RuntimeError('Trainer: the optimizer state does not fit the captured Adam step')
+            self.optimizer.step_captured(g['scal'])
+            g['loss'] = loss.detach()
+        g['graph'] = graph
+        return g
+
+    def _step_graph(self, img, lbl):
+        g = self._g
+        if g is None or g['shape'] != (tuple(img.shape), tuple(lbl.shape)):
+            g = self._g = self._capture(img, lbl)
+        slot = g['n'] % self.GRAPH_SCALAR_SLOTS
+        g['n'] += 1
+        if g['events'][slot] is not None:
+            g['events'][slot].synchronize()               # (only when the host is GRAPH_SCALAR_SLOTS replays ahead)
+        ss, bc = self.optimizer.advance_host()
+        g['pinned'][slot][0] = ss
+        g['pinned'][slot][1] = bc
+        g['img'].copy_(img, non_blocking=True)
+        g['lbl'].copy_(lbl, non_blocking=True)
+        g['scal'].copy_(g['pinned'][slot], non_blocking=True)
+        ev = g['events'][slot] = g['events'][slot] or torch.cuda.Event()
+        ev.record()
+        g['graph'].replay()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return g['loss']
+
     def step(self, img, lbl, keep_output=False):
         """One batch of run.py:244-254.  Returns the loss tensor (no host sync).  keep_output: leave the model's output
-        of this batch in self.last_output (the reference's train() keeps the last one for the VAE `misc`, run.py:274-276)."""
+        of this batch in self.last_output (the reference's train() keeps the last one for the VAE `misc`, run.py:274-276).
+        With the graph path on, the returned tensor is the graph's loss buffer: read it before the next step."""
+        if self.graph:
+            # a shape's first two steps run eagerly (they build the launch tables, caches and workspaces of that shape -- host-side
+            # allocations and copies that must not happen inside a capture)
+            key = (tuple(img.shape), tuple(lbl.shape))
+            if self._eager_steps.get(key, 0) >= 2 and self.graph_usable(img, keep_output) is None:
+                return self._step_graph(img, lbl)
+            self._eager_steps[key] = self._eager_steps.get(key, 0) + 1
         ctx = torch.autograd.detect_anomaly() if self.anomaly else contextlib.nullcontext()
         with ctx:
             output = self.net(img)

@@ -220,6 +220,14 @@ int icn_adam_step(int count, float* const* params, const float* const* grads, fl
                   const size_t* numel, const float* step_size, const float* bc2_sqrt, double beta1, double beta2, double eps,
                   double weight_decay, void* stream);
 
+/* The same step with its two per-step scalars read from DEVICE memory (ABI 7): scalars_dev[0] = step_size, scalars_dev[1] = bc2_sqrt,
+ * shared by all `count` tensors (they have one step count).  For a training step recorded into a HIP graph (SURVEY 7 step 7,
+ * the loop of run.py:240-254): kernel arguments are frozen at capture, so the host writes the step's scalars into that buffer
+ * before each replay (geniconet_amd.train.Trainer, ICN_GRAPH=1).  Same arithmetic, bit-identical results. */
+int icn_adam_step_dev(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                      const size_t* numel, const float* scalars_dev, double beta1, double beta2, double eps, double weight_decay,
+                      void* stream);
+
 /* Host-side introspection (no device needed).  Each writes at most `cap` elements and returns the element
  * count required (negative on error). */
 long icn_table_conv_fwd(int r_in, int stride, int corner_mode, int32_t* out, size_t cap);      /* [7][P_out]     */
