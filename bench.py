@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 # start its children before anything in this process could touch the GPU, and needs the standard library only.
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # same guide: dense bf16 MFMA (16 x the f32-input rate; the 5 PF headline figure is 2:1 sparsity)
+B3_PRODUCTS = 6                        # bf16 MFMA products per fp32 product of the three-way split (csrc/icn_kernels.hip, ARITH = 1)
 # algorithmic work per mesh per TRAINING step (SURVEY.md 8d / BASELINE.md): 3 x forward conv FLOPs
 TRAIN_GFLOP_PER_MESH = {('ico2ico', 5): 31.49, ('ico2ico_vae', 5): 35.46, ('ico2ico', 6): 125.96}
 # fused-ideal HBM bytes per mesh per training step: every conv reads its input and writes its output once
@@ -135,8 +137,20 @@ def launch_ranks(args, argv):
         env.setdefault('OMP_NUM_THREADS', '1')                   # as torch.distributed.run sets it
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc, live = 0, list(procs)
+    # A SIGTERM / SIGHUP to the launcher alone (a driver's timeout kills just this pid) must not leave N ranks holding their GPUs
+    # inside an RCCL collective: the handlers only set the exit code; the loop below then stops the exact child PIDs.
+    stop = {'sig': 0}
+
+    def on_signal(signum, _frame):
+        stop['sig'] = signum
+    for sg in (signal.SIGTERM, signal.SIGHUP):
+        signal.signal(sg, on_signal)
     try:
         while live and rc == 0:
+            if stop['sig']:
+                rc = 128 + stop['sig']
+                sys.stderr.write('bench.py: launcher got signal %d; stopping %d rank(s)\n' % (stop['sig'], len(live)))
+                break
             time.sleep(0.2)
             for q in list(live):
                 code = q.poll()
@@ -159,10 +173,25 @@ def launch_ranks(args, argv):
     return rc
 
 
-def measure(cfg, args, ctx, headline):
+def measure(cfg, args, ctx, headline, arith=None):
     """W warm-up steps, (survey steps), then EXACTLY K timed steps of configuration `cfg` between barrier + synchronize on both
     sides; MAX over ranks.  Returns the fields of the bench line that depend on the measurement.  headline=False (the `also`
-    entries) skips the two extra overlapped steps that only feed avg_launch_us_overlapped."""
+    entries) skips the two extra overlapped steps that only feed avg_launch_us_overlapped.  arith: 'f32' / 'bf16x3' for this
+    measurement only (the library's mode is restored)."""
+    import torch
+    import torch.distributed as dist
+    from geniconet_amd import _lib, data, models
+    from geniconet_amd.train import Trainer
+    device, rank, world, group, rehearsal, local = (ctx[k] for k in ('device', 'rank', 'world', 'group', 'rehearsal', 'local'))
+    prev_arith = _lib.set_arith(arith) if arith else None
+    try:
+        return _measure(cfg, args, ctx, headline)
+    finally:
+        if prev_arith:
+            _lib.set_arith(prev_arith)
+
+
+def _measure(cfg, args, ctx, headline):
     import torch
     import torch.distributed as dist
     from geniconet_amd import _lib, data, models
@@ -267,12 +296,28 @@ def measure(cfg, args, ctx, headline):
         # overlapped run: the kernel's own rate comes from the survey steps (one stream); else from the timed region
         src = iso if (overlapped or not timed) else timed
         per_launch_ms = src['total_ms'] / src['launches']
-        achieved = src['total_flops'] / (src['total_ms'] * 1e-3) / 1e12
+        equiv = src['total_flops'] / (src['total_ms'] * 1e-3) / 1e12       # fp32 multiply-adds of the operator per second
+        # A launch on the three-way bf16 split executes B3_PRODUCTS bf16 MFMA products per fp32 product: its roofline is the bf16
+        # MFMA peak and what it achieves there is the EXECUTED bf16 FLOP rate; the fp32-equivalent rate is reported beside it.
+        split = is_split_kernel(dom_name)
+        achieved = equiv * B3_PRODUCTS if split else equiv
+        peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
         traffic, traffic_source = committed_traffic(dom_name)
+        step_bytes, step_bytes_source = committed_step_traffic()
+        ideal_bytes = TRAIN_MB_PER_MESH[key] * 1e6 * cfg['batch']
         mfma_ms = sum(e['total_ms'] for e in survey)
+        # executed FLOPs of one step by arithmetic: fp32-equivalent FLOPs of the split launches run as 6 x as many bf16 FLOPs
+        ex_split = sum(e['total_flops'] for e in survey if is_split_kernel(e['kernel'])) / n_survey
+        ex_exact = sum(e['total_flops'] for e in survey if not is_split_kernel(e['kernel'])) / n_survey
+        step_s = elapsed / args.steps
         roofline = {
-            'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+            'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+            'arithmetic': ('bf16x3 split: %d v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulate; achieved / peak count '
+                           'EXECUTED bf16 FLOPs against the dense bf16 MFMA peak' % B3_PRODUCTS) if split
+                          else 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)',
+            'fp32_equivalent_tflops': round(equiv, 2),
+            'fp32_equivalent_frac_of_fp32_mfma_peak': round(equiv / PEAK_FP32_MFMA_TFLOPS, 4),
             'kernel': dom_name, 'launches_per_step': iso['launches'] / n_survey,
             'avg_launch_us': round(per_launch_ms * 1e3, 2),
             'measured': ('one stream: HIP events around the %d launches of this kernel in the %d survey steps, which run the weight '
@@ -293,7 +338,19 @@ def measure(cfg, args, ctx, headline):
                                   'tflops': round(e['total_flops'] / (e['total_ms'] * 1e-3) / 1e12, 2)} for e in survey],
             'mfma_kernels_ms_per_step': round(mfma_ms / n_survey, 3),
             'step_tflops': round(value * TRAIN_GFLOP_PER_MESH[key] / 1e3, 2),
-            'step_frac_of_mfma_peak': round(value * TRAIN_GFLOP_PER_MESH[key] / 1e3 / PEAK_FP32_MFMA_TFLOPS / world, 4),
+            # algorithmic fp32 FLOPs of the reference's operator graph over the fp32 MFMA peak: an ALGORITHMIC ratio (this build executes
+            # 57 % of those FLOPs, part of them as bf16 products), > 1 is possible and is not a roofline fraction -- the next one is
+            'step_algorithmic_over_fp32_mfma_peak': round(value * TRAIN_GFLOP_PER_MESH[key] / 1e3 / PEAK_FP32_MFMA_TFLOPS / world, 4),
+            # time the step's EXECUTED matrix work would take at the peaks (bf16 products at the bf16 peak, exact products at the fp32
+            # peak) over the step's time: the whole-step MFMA roofline fraction, <= 1 by construction
+            'step_frac_of_mfma_peak': round((ex_split * B3_PRODUCTS / (PEAK_BF16_MFMA_TFLOPS * 1e12) + ex_exact / (PEAK_FP32_MFMA_TFLOPS * 1e12)) / step_s, 4),
+            'step_executed_bf16_tflops': round(ex_split * B3_PRODUCTS / step_s / 1e12, 2),
+            'step_executed_exact_fp32_tflops': round(ex_exact / step_s / 1e12, 2),
+            # HBM bytes of ONE step from the counters (sum over every kernel of bytes per launch x launches per step in the committed,
+            # hash-matched PMC passes) against SURVEY 8(d)'s fused-ideal bytes: the wasted-traffic ratio
+            'step_hbm_bytes_counters': step_bytes, 'step_hbm_bytes_fused_ideal': round(ideal_bytes),
+            'step_hbm_traffic_over_ideal': round(step_bytes / ideal_bytes, 2) if step_bytes else None,
+            'step_hbm_bytes_source': step_bytes_source,
             # step_tflops is ALGORITHMIC (3 x forward conv FLOPs of the reference's operator graph);
             # the MFMA launches of this implementation execute fewer (composite decoder blocks):
             'step_executed_tflops': round(sum(e['total_flops'] for e in survey) / n_survey / (elapsed / args.steps) / 1e12, 2),
@@ -308,23 +365,57 @@ def measure(cfg, args, ctx, headline):
             'rank_ms_per_step': {'min': round(min(per_rank) / args.steps * 1e3, 3), 'max': round(max(per_rank) / args.steps * 1e3, 3)}}
 
 
+def is_split_kernel(name):
+    """Kernels of the three-way bf16 split (ARITH = 1 instantiations of conv_dma_body)."""
+    return name.startswith('k_conv_b3')
+
+
+def _latest_pmc_summary():
+    """(summary dict, relative path, reason-or-None): the newest committed profiles/r*_pmc_per_kernel.json, usable only when it was
+    measured on THESE kernel sources with the in-tree library."""
+    import glob
+    from geniconet_amd import _lib
+    if _lib.build_info()['overridden']:
+        return None, None, 'not reported: ICN_LIB_PATH overrides the in-tree library, the committed counters belong to the in-tree build'
+    try:
+        latest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel.json')))[-1]
+        summary = json.load(open(latest))
+    except (IndexError, OSError, ValueError):
+        return None, None, 'no committed profiles/r*_pmc_per_kernel.json'
+    rel = os.path.relpath(latest, ROOT)
+    have, want = summary.get('_kernel_sources_sha256'), _lib.source_sha256()
+    if have != want:
+        return None, rel, ('not reported: %s was measured on kernel sources %s, this tree has %s -- re-run tools/profile_round.sh'
+                           % (rel, (have or 'unrecorded')[:16], want[:16]))
+    return summary, rel, None
+
+
+def committed_step_traffic():
+    """HBM bytes of one training step of the headline configuration from the committed counter passes (tools/profile_summary.py:
+    `_step_hbm_bytes` = sum over kernels of hbm_bytes_per_launch x calls per step, under the arithmetic recorded in `_arith`), or
+    (None, reason) -- same rule as committed_traffic."""
+    from geniconet_amd import _lib
+    summary, rel, why = _latest_pmc_summary()
+    if summary is None:
+        return None, why
+    if '_step_hbm_bytes' not in summary:
+        return None, rel + ' carries no step total'
+    if summary.get('_arith') and summary['_arith'] != _lib.get_arith():
+        return None, 'not reported: %s was measured under arithmetic %s' % (rel, summary['_arith'])
+    return round(summary['_step_hbm_bytes']), ('not measured by this run: committed ' + rel + ' (separate rocprofv3 --pmc FETCH_SIZE / '
+                                                'WRITE_SIZE passes of `bench.py --steps 4 --warmup 2`, one stream)')
+
+
 def committed_traffic(kernel):
     """HBM bytes per launch of `kernel` from the latest committed PMC passes (tools/profile_round.sh: separate --pmc FETCH_SIZE /
     WRITE_SIZE runs of this same command, FETCH doubled per the gfx950 note) -- but only when that profile was taken on THESE
     kernel sources: tools/profile_summary.py records the sha256 of geniconet_amd/csrc/ in the summary, and a summary of other
     sources yields traffic = None with the reason (a kernel change without a re-profile must not report stale bytes)."""
-    import glob
     from geniconet_amd import _lib
-    try:
-        latest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_per_kernel.json')))[-1]
-        summary = json.load(open(latest))
-    except (IndexError, OSError, ValueError):
-        return None, 'no committed profiles/r*_pmc_per_kernel.json'
-    rel = os.path.relpath(latest, ROOT)
-    have, want = summary.get('_kernel_sources_sha256'), _lib.source_sha256()
-    if have != want:
-        return None, ('not reported: %s was measured on kernel sources %s, this tree has %s -- re-run tools/profile_round.sh'
-                      % (rel, (have or 'unrecorded')[:16], want[:16]))
+    summary, rel, why = _latest_pmc_summary()
+    if summary is None:
+        return None, why
+    want = _lib.source_sha256()
     traffic = summary.get('icn::' + kernel, {}).get('hbm_bytes_per_launch')
     if traffic is None:
         return None, 'kernel not in ' + rel
@@ -374,6 +465,9 @@ def run(args):
         else:
             dist.init_process_group('nccl', device_id=device)      # RCCL over xGMI
     _lib.lib()
+    if args.arith:
+        _lib.set_arith(args.arith)
+    arith = _lib.get_arith()
     ctx = dict(device=device, rank=rank, world=world, group=group, rehearsal=rehearsal, local=local)
     head = measure(cfg, args, ctx, headline=True)
 
@@ -385,6 +479,12 @@ def run(args):
             'value': head['value'], 'unit': 'meshes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            # tensors, accumulation and results are fp32 in both modes; 'bf16x3' forms every fp32 product of the stream-K convolution /
+            # dense GEMM launches from three bf16 pieces per operand (24 significand bits, exact) -- fp32-grade: its error against
+            # float64 is within 2 x the exact kernels' (tests/test_gpu_arith.py); the exact-fp32 run of the same step is in also[]
+            'arithmetic': ('bf16x3 split (%d bf16 MFMA products per fp32 product), fp32 accumulate; weight gradients and stride-2 data '
+                           'gradients on exact fp32 MFMA' % B3_PRODUCTS) if arith == 'bf16x3' else 'exact fp32 MFMA',
+            'library': _lib.build_info(),
             'config': {'workload': cfg['workload'], 'per_gpu_batch': cfg['batch'], 'global_batch': cfg['batch'] * world,
                        'subdivisions': cfg['R'], 'parallelism': 'dp%d' % world + (' (DDP over RCCL forced at world size 1)' if forced else ''),
                        'final_loss': head['final_loss']},
@@ -403,6 +503,16 @@ def run(args):
     if world == 1 and not forced and args.config == 'ae' and not args.no_also:
         try:
             also = []
+            if arith != 'f32':
+                # the headline step on the exact fp32 kernels (ICN_ARITH=f32), same process, same steps
+                m = measure(cfg, args, ctx, headline=False, arith='f32')
+                r = m['roofline'] or {}
+                also.append({'workload': cfg['workload'] + ' -- exact fp32 MFMA arithmetic (ICN_ARITH=f32)', 'value': m['value'], 'unit': 'meshes/s',
+                             'ms_per_step': m['ms_per_step'],
+                             'roofline': {'kernel': r.get('kernel'), 'frac': r.get('frac'), 'achieved': r.get('achieved'), 'peak': r.get('peak'),
+                                          'avg_launch_us': r.get('avg_launch_us')},
+                             'step_executed_tflops': r.get('step_executed_tflops'), 'step_tflops': r.get('step_tflops'),
+                             'final_loss': m['final_loss']})
             for name in ('vae', 'i6'):
                 c = CONFIGS[name]
                 m = measure(c, args, ctx, headline=False)
@@ -411,15 +521,15 @@ def run(args):
                 # time per step (survey) is a floor of the step; a timed region far above it means something other than the device held
                 # the steps up (round 5: the host, blocked in the allocator after an empty_cache() between configurations -- removed,
                 # see measure()).  Such a region is measured a second time and BOTH are reported.
-                runs = [m['ms_per_step']]
+                # The entry's value is ALWAYS the first measurement (timed once, like the headline); a second one is reported beside
+                # it, flagged, never substituted (a best-of-two for guarded entries only would bias them).
+                runs, suspect = [m['ms_per_step']], False
                 if r.get('mfma_kernels_ms_per_step') and m['ms_per_step'] > 1.8 * r['mfma_kernels_ms_per_step']:
-                    m2 = measure(c, args, ctx, headline=False)
-                    runs.append(m2['ms_per_step'])
-                    if m2['ms_per_step'] < m['ms_per_step']:
-                        m, r = m2, (m2['roofline'] or {})
+                    suspect = True
+                    runs.append(measure(c, args, ctx, headline=False)['ms_per_step'])
                 also.append({'workload': c['workload'], 'value': m['value'], 'unit': 'meshes/s', 'ms_per_step': m['ms_per_step'],
-                             'timed_regions_ms_per_step': runs,
-                             'roofline': {'kernel': r.get('kernel'), 'frac': r.get('frac'), 'achieved': r.get('achieved'),
+                             'timed_regions_ms_per_step': runs, 'suspect_first_region': suspect,
+                             'roofline': {'kernel': r.get('kernel'), 'frac': r.get('frac'), 'achieved': r.get('achieved'), 'peak': r.get('peak'),
                                           'avg_launch_us': r.get('avg_launch_us')},
                              'step_executed_tflops': r.get('step_executed_tflops'), 'step_tflops': r.get('step_tflops'),
                              'final_loss': m['final_loss']})
@@ -447,6 +557,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
     ap.add_argument('--no-also', action='store_true', help='skip the vae / i6 configurations behind the headline (N = 1)')
+    ap.add_argument('--arith', choices=['f32', 'bf16x3'], default=None,
+                    help="arithmetic of the channel-mixing contraction (default: the library's, i.e. ICN_ARITH or bf16x3)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit('bench.py: --gpus must be >= 1')

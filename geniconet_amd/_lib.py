@@ -115,12 +115,20 @@ def lib():
         if handle.icn_abi_version() != ABI_VERSION:
             raise RuntimeError('geniconet_amd: libicn.so ABI %d != binding ABI %d; rebuild'
                                % (handle.icn_abi_version(), ABI_VERSION))
-        exp = handle.icn_build_flags() & 0xffff
-        if exp and os.environ.get('ICN_ALLOW_EXP') != '1':
-            raise RuntimeError('geniconet_amd: %s is a pricing build (ICN_EXP=%d: a feature of the convolution kernel is compiled '
-                               'out, its RESULTS ARE WRONG by design); set ICN_ALLOW_EXP=1 to time it' % (LIB_PATH, exp))
+        refuse_pricing_build(handle.icn_build_flags(), LIB_PATH)
         _lib = handle
     return _lib
+
+
+def refuse_pricing_build(flags, path, allow=None):
+    """A library built with -DICN_EXP=<bits> (tools/build_exp.sh) leaves a feature of the convolution kernel out: RESULTS ARE WRONG
+    by design, only launch times are read.  It loads through the ordinary ICN_LIB_PATH override, so it is refused here unless
+    ICN_ALLOW_EXP=1 says the caller knows."""
+    exp = flags & 0xffff
+    allow = os.environ.get('ICN_ALLOW_EXP') == '1' if allow is None else allow
+    if exp and not allow:
+        raise RuntimeError('geniconet_amd: %s is a pricing build (ICN_EXP=%d: a feature of the convolution kernel is compiled out, '
+                           'its RESULTS ARE WRONG by design); set ICN_ALLOW_EXP=1 to time it' % (path, exp))
 
 
 def build_info():

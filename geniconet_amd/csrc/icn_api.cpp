@@ -1170,7 +1170,7 @@ int icn_upconv_bwd_streams(const float* x, const float* dy0, const float* dy1, c
         if (dw0) {
             // 3. dW_t = sum_{b, s} x[b, s, :]^T g[b, s, t, :]   (+ dbias = sum g_0)
             icn::WgradArgs a{};
-            a.x = x; a.dy = g; a.dy2 = nullptr; a.Cout0 = Cout1 ? Cout0 : C; a.dcode = t.iota; a.n_slots = 0; a.y_taps = 7;
+            a.x = x; a.dy = g; a.dy2 = nullptr; a.Cout0 = Cout1 ? Cout0 : C; a.dcode = t.iota; a.identity_rows = 1; a.n_slots = 0; a.y_taps = 7;
             a.partial = reinterpret_cast<float*>(at(ws, wo.partial));
             a.bias_partial = (dbias0 || dbias1) ? reinterpret_cast<float*>(at(ws, wo.bpart)) : nullptr;
             a.dw = dw0; a.dbias = dbias0; a.dw2 = dw1; a.dbias2 = dbias1;

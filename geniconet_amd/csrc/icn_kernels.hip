@@ -1607,7 +1607,7 @@ static void launch_conv_dma_sk(const GatherGemmArgs& a, int occ, hipStream_t s) 
 }
 
 // ---- ARITH = 1 launches (round 6) ---------------------------------------------------------------------------------------------
-// Arithmetic of the channel-mixing contraction: 0 = exact fp32 MFMA (default), 1 = three-way bf16 split (conv_dma_body's header).
+// Arithmetic of the channel-mixing contraction: 0 = exact fp32 MFMA, 1 = three-way bf16 split (conv_dma_body's header; the default).
 // ICN_ARITH=f32|bf16x3 sets the process default; icn_set_arith (include/icn.h) changes it at run time (tests, A/B).
 unsigned build_flags() { return ((unsigned)ICN_EXP & 0xffffu) | ((unsigned)ICN_CONV_WAVES_DEFAULT << 16) | ((unsigned)ICN_CHAIN_PRIO << 24); }
 static std::atomic<int> g_arith{-1};
@@ -1615,8 +1615,8 @@ int arith_mode() {
     int v = g_arith.load(std::memory_order_relaxed);
     if (v < 0) {
         const char* e = getenv("ICN_ARITH");
-        if (e == nullptr || e[0] == 0 || strcmp(e, "f32") == 0) v = 0;
-        else if (strcmp(e, "bf16x3") == 0) v = 1;
+        if (e == nullptr || e[0] == 0 || strcmp(e, "bf16x3") == 0) v = 1;    // default since round 6: fp32-grade (tests/test_gpu_arith.py), 1.45x the exact kernels
+        else if (strcmp(e, "f32") == 0) v = 0;
         else throw std::invalid_argument("icn: ICN_ARITH must be f32 or bf16x3");
         g_arith.store(v, std::memory_order_relaxed);
     }
@@ -2785,7 +2785,7 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         const size_t lds_dma = std::max(wgrad_lds(BI, BJ, true), occ_cap == 2 ? (size_t)(160 * 1024 / 3 + 1024) : (size_t)0);
         // the decoder heads' dense dW (identity rows, tap-major g, no pole means): the body with the gather compiled away
         static const bool dense_env = !(getenv("ICN_WG_DENSE") && atoi(getenv("ICN_WG_DENSE")) == 0);   // developer A/B
-        const bool dense = dense_env && dma && a.y_taps == 7 && a.n_slots == 0 && a.Ps == a.Pd && a.dy2 == nullptr && !(dbg_flags() & 32768);
+        const bool dense = dense_env && dma && a.y_taps == 7 && a.identity_rows && a.n_slots == 0 && a.Ps == a.Pd && a.dy2 == nullptr && !(dbg_flags() & 32768);   // identity_rows: k_wgrad_dense never reads dcode
 #define ICN_WG(I, J)                                                                                                       \
     do {                                                                                                                   \
         if (dense)                                                                                                         \

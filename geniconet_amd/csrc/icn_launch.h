@@ -90,6 +90,8 @@ struct WgradArgs {
     int M, Ps, Pd, Cin, Cout, ns;
     double algo_flops;
     int y_taps;             // 7: dy is the tap-major aggregate g (M, 7, Cout) of icn_upconv_bwd and dcode one table [Pd]; else 0
+    int identity_rows;      // the caller GUARANTEES dcode is the identity (row m reads x row m): only then may the launcher take k_wgrad_dense,
+                            // which compiles the gather away; 0 with y_taps: the general per-tap kernel walks dcode
     const int32_t* w7_rows; // patch form of dcode for the all-taps kernel k_wgrad7 (icn_geometry.h: Wg7Table), or null
     const uint16_t* w7_pos;
     int w7_U;

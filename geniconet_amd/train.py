@@ -310,6 +310,25 @@ class Trainer:
             from . import _lib
             _lib.raise_on_device_status(self.device, synchronize=synchronize)
 
+    def check_status_collective(self, synchronize=True):
+        """check_status on EVERY rank with one verdict for all: each rank checks its own device, the flags are
+        all-reduced (MAX), and every rank raises together -- a rank that raised alone would leave the others blocked in their next
+        collective until the watchdog fires.  Call it on all ranks at the same point (fit(): once per epoch, before any
+        checkpoint is written).  World size 1: plain check_status."""
+        failure = None
+        try:
+            self.check_status(synchronize=synchronize)
+        except RuntimeError as e:
+            failure = e
+        if self.world > 1:
+            on_host = dist.get_backend() == 'gloo'
+            flag = torch.tensor([1.0 if failure else 0.0], device='cpu' if on_host else self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if float(flag) and failure is None:
+                failure = RuntimeError('libicn: another rank reported an asynchronous kernel failure')
+        if failure is not None:
+            raise failure
+
     @torch.no_grad()
     def evaluate(self, img, lbl):
         """Forward + loss with the module in eval mode (run.py:280-296), restoring train mode after."""
@@ -346,9 +365,18 @@ def save_checkpoint(trainer, log_dir, epoch, val_loss=None, misc=None, model_nam
         return None
     os.makedirs(os.path.dirname(path), exist_ok=True)
     # Check BEFORE anything reaches the disk: a kernel-side failure (a lost stream-K partner turns its tile into NaNs)
-    # must raise here, not after a poisoned file has been written that a later --resume would load.  And the file appears under
-    # its name only when it is complete.
+    # must raise here, not after a poisoned file has been written that a later --resume would load.  Under DDP this is rank 0's
+    # own device only and a raise here would leave the other ranks walking into their next collective: callers there run
+    # Trainer.check_status_collective() on ALL ranks first (fit() does, once per epoch before it saves), after which this check
+    # cannot fail.
     trainer.check_status(synchronize=True)
+    # The file appears under its name only when it is complete; leftovers of a writer that was killed mid-save ('<name>.pt.tmp<pid>'
+    # of another pid) are removed here.
+    for stale in glob.glob(path + '.tmp*'):
+        try:
+            os.remove(stale)
+        except OSError:
+            pass
     tmp = path + '.tmp%d' % os.getpid()
     try:
         torch.save({'model_state_dict': trainer.model.state_dict(), 'optimizer_state_dict': trainer.optimizer.state_dict(),
@@ -432,6 +460,8 @@ def fit(trainer, trn, val, epochs, batch_size, log_dir=None, model_name=None, se
         trainer.check_status()                # (the float() synchronised: covers the epoch's kernels)
         misc = got or None
         val_loss = validate(trainer, val, batch_size)
+        if trainer.world > 1:
+            trainer.check_status_collective(synchronize=False)      # (validate's float() synchronised this rank's device)
         history.append((epoch, trn_loss, val_loss))
         if log_dir is not None and val_loss <= best_loss:
             if trainer.world == 1 or dist.get_rank() == 0:

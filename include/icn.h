@@ -315,11 +315,12 @@ long icn_host_selfcheck(int r, int corner_mode);
 int icn_device_status(int clear);
 
 /* Arithmetic of the channel-mixing contraction (ABI 7; the reference computes in fp32 on PyTorch, models.py / run.py have no
- * autocast -- SURVEY F1).  ICN_ARITH_F32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32; the default).  ICN_ARITH_BF16X3: every fp32 operand
+ * autocast -- SURVEY F1).  ICN_ARITH_F32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  ICN_ARITH_BF16X3 (the default): every fp32 operand
  * is cut into three bf16 pieces (24 significand bits, exact) and the product is six bf16 MFMAs with fp32 accumulation -- fp32-grade
  * results (1.2 x the exact kernel's rounding error against float64, tests/test_gpu_arith.py) at 2.67 x less matrix-pipe time; used
  * by the stream-K forms of the plain convolutions and the dense GEMMs, everything else stays on the exact kernels.  The process
- * default comes from the environment (ICN_ARITH=f32|bf16x3).  icn_set_arith returns the previous mode, or -1 (icn_last_error). */
+ * default is ICN_ARITH_BF16X3; the environment overrides it (ICN_ARITH=f32|bf16x3).  icn_set_arith returns the previous mode, or -1
+ * (icn_last_error). */
 #define ICN_ARITH_F32 0
 #define ICN_ARITH_BF16X3 1
 int icn_get_arith(void);

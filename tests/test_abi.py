@@ -36,7 +36,8 @@ def test_workspace_query_is_host_only():
     # (bwd-weight) are bounded
     # ... + the stream-K scratch (flag words and 512 partial 64x128 tiles, include/icn.h)
     sk = (1032 * 4 + 255) // 256 * 256 + 512 * 64 * 128 * 4
-    assert L.icn_conv_workspace_bytes(_lib.OP_CONV_FWD, 36, 128, 64, 5, 1) == 7 * 128 * 64 * 4 + 36 * 2 * 128 * 4 + sk
+    # packed weights: the fp32 operand AND its bf16 x 3 image (6 bytes per weight, ABI 7) are both reserved, whatever the arithmetic mode
+    assert L.icn_conv_workspace_bytes(_lib.OP_CONV_FWD, 36, 128, 64, 5, 1) == 7 * 128 * 64 * (4 + 6) + 36 * 2 * 128 * 4 + sk
     assert L.icn_conv_workspace_bytes(_lib.OP_CONV_FWD, 36, 3, 64, 5, 1) == 0
     assert 0 < L.icn_conv_workspace_bytes(_lib.OP_CONV_BWD_WEIGHT, 36, 256, 256, 3, 1) < 256 << 20
     assert L.icn_conv_workspace_bytes(7, 36, 256, 256, 3, 1) == 0
@@ -59,3 +60,19 @@ def test_adam_step_rejects_bad_arguments_before_touching_a_device():
     assert L.icn_adam_step(1, one, one, one, one, n1, f1, f1, 0.9, 0.999, -1.0, 0.0, None) != 0            # eps >= 0
     assert b'betas' in L.icn_last_error()
 
+
+
+def test_arithmetic_mode_and_build_flags_are_host_only():
+    """ABI 7: icn_get_arith / icn_set_arith / icn_build_flags need no device; a bad mode is an error with a message."""
+    L = _lib.lib()
+    prev = L.icn_get_arith()
+    assert prev in (0, 1)
+    assert L.icn_set_arith(1) == prev and L.icn_get_arith() == 1
+    assert L.icn_set_arith(0) == 1 and L.icn_get_arith() == 0
+    assert L.icn_set_arith(2) == -1 and b'arithmetic mode' in L.icn_last_error() and L.icn_get_arith() == 0
+    L.icn_set_arith(prev)
+    assert L.icn_build_flags() & 0xffff == 0                       # the in-tree library is the product, not a pricing build
+    import ctypes
+    one, n1 = (ctypes.c_void_p * 1)(0x1000), (ctypes.c_size_t * 1)(4)
+    assert L.icn_adam_step_dev(0, None, None, None, None, None, 0x1000, 0.9, 0.999, 1e-8, 0.0, None) == 0
+    assert L.icn_adam_step_dev(1, one, one, one, one, n1, None, 0.9, 0.999, 1e-8, 0.0, None) != 0       # no scalar buffer

@@ -92,6 +92,21 @@ for k, cs in pmc.items():
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in cs and 'GRBM_GUI_ACTIVE' in cs:
         e['mfma_pipe_busy_frac'] = round(cs['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (cs['GRBM_GUI_ACTIVE'] / 8), 4)
     out[k] = e
+# HBM bytes of ONE training step from the counters: sum over kernels of bytes per launch x launches per step (the counter passes run
+# `bench.py --steps 4 --warmup 2 --no-kernel-events` on one stream: no survey steps, so every step launches the same kernels)
+try:
+    pb = json.loads([l for l in open(os.path.join(src, 'pmc_FETCH_SIZE.json')).read().strip().splitlines() if l.startswith('{')][-1])
+    pmc_steps = pb['steps'] + pb['warmup']
+    total = 0.0
+    for k, e in out.items():
+        if 'hbm_bytes_per_launch' in e and 'dispatches_FETCH_SIZE' in e:
+            e['calls_per_step'] = round(e['dispatches_FETCH_SIZE'] / pmc_steps, 3)
+            total += e['hbm_bytes_per_launch'] * e['dispatches_FETCH_SIZE'] / pmc_steps
+    out['_step_hbm_bytes'] = total
+    out['_steps_under_pmc'] = pmc_steps
+    out['_arith'] = 'bf16x3' if str(pb.get('arithmetic', '')).startswith('bf16x3') else 'f32'
+except (OSError, IndexError, KeyError, ValueError) as e:
+    print('no step total:', e)
 # the kernel sources these counters were measured on (bench.py reports roofline.traffic only when the tree it runs from has the
 # same hash: a kernel change without a re-profile must not report stale bytes)
 sys.path.insert(0, root)
