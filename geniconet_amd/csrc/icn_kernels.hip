@@ -1940,7 +1940,9 @@ __global__ __launch_bounds__(256) void k_wgrad(
 // ---------------------------------------------------------------------------------------------------------
 constexpr int WG_RS = 16;   // rows per stage
 
-template <int BI, int BJ, bool DENSE>
+// ARITH = 1 (round 6): a stage's WG_RS = 16 rows are one k-block of v_mfma_f32_32x32x16_bf16; a lane holds rows 8h .. 8h + 7 of its
+// channel of x and of dy, both cut into three bf16 pieces in registers (split_bf16x3), six products per 32 x 32 block.
+template <int BI, int BJ, bool DENSE, int ARITH = 0>
 __device__ __forceinline__ void wgrad_dma_body(
     const float* __restrict__ x,        // (B, Ps, Cin)
     const float* __restrict__ dy,       // (B, Pd, Cout0)
@@ -2120,6 +2122,39 @@ __device__ __forceinline__ void wgrad_dma_body(
         ICN_WG_ISSUE();
         const float* xa = Xs + c_ring * WG_RS * BI + wr * (BI / 2) + l31;
         const float* yb = Ys + c_ring * WG_RS * BJ + wc * (BJ / 2) + l31;
+        if constexpr (ARITH == 1) {
+            static_assert(WG_RS == 16, "one bf16 k-block per stage");
+            Pieces3 pa[TI], pb[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lo[j] = xa[(8 * h + j) * BI + i * 32]; hi[j] = xa[(8 * h + 4 + j) * BI + i * 32]; }
+                pa[i] = split_bf16x3(lo, hi);
+            }
+#pragma unroll
+            for (int j2 = 0; j2 < TJ; ++j2) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lo[j] = yb[(8 * h + j) * BJ + j2 * 32]; hi[j] = yb[(8 * h + 4 + j) * BJ + j2 * 32]; }
+                pb[j2] = split_bf16x3(lo, hi);
+            }
+#define ICN_MF16W(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), c_, 0, 0, 0)
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = ICN_MF16W(pa[i].p1, pb[j].p3, c);
+                    c = ICN_MF16W(pa[i].p3, pb[j].p1, c);
+                    c = ICN_MF16W(pa[i].p2, pb[j].p2, c);
+                    c = ICN_MF16W(pa[i].p1, pb[j].p2, c);
+                    c = ICN_MF16W(pa[i].p2, pb[j].p1, c);
+                    c = ICN_MF16W(pa[i].p1, pb[j].p1, c);
+                    acc[i][j] = c;
+                }
+#undef ICN_MF16W
+        } else
 #pragma unroll
         for (int k2 = 0; k2 < WG_RS / 2; ++k2) {
             const int k = 2 * k2 + h;
@@ -2168,25 +2203,25 @@ __device__ __forceinline__ void wgrad_dma_body(
 #endif
 }
 
-template <int BI, int BJ>
+template <int BI, int BJ, int ARITH = 0>
 __global__ __launch_bounds__(256) void k_wgrad_dma(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ dy2,
                                                    const int32_t* __restrict__ dcode, const float* __restrict__ side,
                                                    float* __restrict__ partial, float* __restrict__ bias_partial, int M, int Ps, int Pd,
                                                    int Cin, int Cout, int Cout0, int n_slots, int rows_per_split, int n_splits,
                                                    unsigned x_bytes, unsigned side_bytes, int y_taps, unsigned long long* __restrict__ trace) {
-    wgrad_dma_body<BI, BJ, false>(x, dy, dy2, dcode, side, partial, bias_partial, M, Ps, Pd, Cin, Cout, Cout0, n_slots, rows_per_split,
-                                  n_splits, x_bytes, side_bytes, y_taps, trace);
+    wgrad_dma_body<BI, BJ, false, ARITH>(x, dy, dy2, dcode, side, partial, bias_partial, M, Ps, Pd, Cin, Cout, Cout0, n_slots, rows_per_split,
+                                         n_splits, x_bytes, side_bytes, y_taps, trace);
 }
 
 // k_wgrad_dense: the decoder heads' dW_t = sum_s x[s]^T g_t[s] (y_taps = 7, identity rows, no pole means) through the same body with
 // the gather compiled away: row offsets are arithmetic, so the code DMAs, their LDS read-back and the side-row vote are gone.
-template <int BI, int BJ>
+template <int BI, int BJ, int ARITH = 0>
 __global__ __launch_bounds__(256) void k_wgrad_dense(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial,
                                                      float* __restrict__ bias_partial, int M, int P, int Cin, int Cout, int Cout0,
                                                      int rows_per_split, int n_splits, unsigned x_bytes,
                                                      unsigned long long* __restrict__ trace) {
-    wgrad_dma_body<BI, BJ, true>(x, g, nullptr, nullptr, nullptr, partial, bias_partial, M, P, P, Cin, Cout, Cout0, 0, rows_per_split,
-                                 n_splits, x_bytes, 0u, 7, trace);
+    wgrad_dma_body<BI, BJ, true, ARITH>(x, g, nullptr, nullptr, nullptr, partial, bias_partial, M, P, P, Cin, Cout, Cout0, 0, rows_per_split,
+                                        n_splits, x_bytes, 0u, 7, trace);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2210,7 +2245,11 @@ constexpr int W7_ROWF = 64;                  // floats per staged row (the tile'
 // U: union rows per patch, a multiple of 4 (a DMA instruction brings 4 rows; ceil(U / 16) instructions per wave and stage);
 // NST: ring stages (3: the DMA pointer two steps ahead, counted waits; 2: one step ahead -- the step's 56 MFMAs per wave cover
 // the latency -- and a third less LDS)
-template <int U, int NST>
+// ARITH = 1 (round 6): the stage's 16 pixels are ONE k-block of v_mfma_f32_32x32x16_bf16 -- a lane holds pixels 8h .. 8h + 7 of its
+// channel: the same 56 indirect ds_read_b32 per stage, every value cut into three bf16 pieces in registers (split_bf16x3; x AND dy are
+// activations, so both operands are split here), six products per tap on the shared dy pieces: 42 MFMAs of 32 cycles instead of 56 of
+// 64 per wave and stage, beside 352 VALU instructions (the split is then what bounds the stage, at about half the exact form's time).
+template <int U, int NST, int ARITH = 0>
 __global__ __launch_bounds__(256, 2) void k_wgrad7(
     const float* __restrict__ x,        // (B, Ps, Cin)
     const float* __restrict__ dy,       // (B, Pd, Cout0)
@@ -2379,6 +2418,42 @@ __global__ __launch_bounds__(256, 2) void k_wgrad7(
         const char* xa = reinterpret_cast<const char*>(slot) + (wr * 32 + l31) * 4;
         const float* yb = slot + U * W7_ROWF + wc * 32 + l31;
         const u32x4* pp = reinterpret_cast<const u32x4*>(slot + U * W7_ROWF + W7_PX * 64);
+        if constexpr (ARITH == 1) {
+            // this lane's 8 pixels: k = 8 h + j
+            u32x4 pk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = pp[8 * h + j];
+            f32x4 yl, yh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { yl[j] = yb[(8 * h + j) * 64]; yh[j] = yb[(8 * h + 4 + j) * 64]; }
+            f32x4 xl[2], xh[2];
+            auto fetch = [&](int buf, int t) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned o0 = (t & 1) ? pk[j][t >> 1] >> 16 : pk[j][t >> 1] & 0xFFFFu;
+                    const unsigned o1 = (t & 1) ? pk[4 + j][t >> 1] >> 16 : pk[4 + j][t >> 1] & 0xFFFFu;
+                    xl[buf][j] = *reinterpret_cast<const float*>(xa + o0);
+                    xh[buf][j] = *reinterpret_cast<const float*>(xa + o1);
+                }
+            };
+            fetch(0, 0);
+            const Pieces3 pb = split_bf16x3(yl, yh);
+#define ICN_MF16W(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), c_, 0, 0, 0)
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                if (t + 1 < 7) fetch((t + 1) & 1, t + 1);
+                const Pieces3 pa = split_bf16x3(xl[t & 1], xh[t & 1]);
+                f32x16 c = acc[t];
+                c = ICN_MF16W(pa.p1, pb.p3, c);
+                c = ICN_MF16W(pa.p3, pb.p1, c);
+                c = ICN_MF16W(pa.p2, pb.p2, c);
+                c = ICN_MF16W(pa.p1, pb.p2, c);
+                c = ICN_MF16W(pa.p2, pb.p1, c);
+                c = ICN_MF16W(pa.p1, pb.p1, c);
+                acc[t] = c;
+            }
+#undef ICN_MF16W
+        } else {
         // positions of this lane's 8 pixels (k = 2 * k2 + h), then the operands of pixel pair k2 + 1 are fetched ahead of the
         // seven MFMAs of pair k2 (register double buffer, as the conv kernel's fragments)
         u32x4 pk[W7_PX / 2];
@@ -2404,6 +2479,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad7(
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef ICN_W7_OPERANDS
+        }
         if (do_bias && tid < 64) {
 #pragma unroll
             for (int k = 0; k < W7_PX; ++k) bsum += slot[U * W7_ROWF + k * 64 + tid];
@@ -2746,15 +2822,23 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         (void)occ;
         const dim3 grid((unsigned)w7.tiles * (unsigned)((S + 7) / 8 * 8));
         const unsigned side_bytes7 = (unsigned)((size_t)(a.M / a.Pd) * a.n_slots * a.Cin * 4);
-        prof_mark_begin(PROF_WG7, a.algo_flops, s);
+        const bool b3_ = arith_mode() == 1 && !(dbg_flags() & 131072);   // debug flag 131072: weight gradients stay exact under bf16x3
+        prof_mark_begin(b3_ ? PROF_WG7_B3 : PROF_WG7, a.algo_flops, s);
 #define ICN_W7(U_, NST_)                                                                                                       \
     do {                                                                                                                       \
         static std::atomic<uint64_t> attr_devices{0};                                                                          \
         if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {                                   \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad7<U_, NST_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       160 * 1024);                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad7<U_, NST_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                             \
             attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);                             \
         }                                                                                                                      \
+        if (b3_)                                                                                                               \
+            hipLaunchKernelGGL((k_wgrad7<U_, NST_, 1>), grid, dim3(256), wgrad7_lds(U_, NST_), s, a.x, a.dy, a.dy2, a.w7_rows, a.w7_pos, \
+                               a.n_slots > 0 ? a.side : nullptr, a.partial, a.bias_partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout, Cout0,   \
+                               a.n_slots, w7.pps, S, (unsigned)x_bytes7, side_bytes7, g_trace_cap >= (size_t)grid.x * 8 ? g_trace : nullptr); \
+        else                                                                                                                   \
         hipLaunchKernelGGL((k_wgrad7<U_, NST_>), grid, dim3(256), wgrad7_lds(U_, NST_), s, a.x, a.dy, a.dy2, a.w7_rows, a.w7_pos, \
                            a.n_slots > 0 ? a.side : nullptr, a.partial, a.bias_partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout, Cout0,   \
                            a.n_slots, w7.pps, S, (unsigned)x_bytes7, side_bytes7, g_trace_cap >= (size_t)grid.x * 8 ? g_trace : nullptr); \
@@ -2788,7 +2872,16 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
         const bool dense = dense_env && dma && a.y_taps == 7 && a.identity_rows && a.n_slots == 0 && a.Ps == a.Pd && a.dy2 == nullptr && !(dbg_flags() & 32768);   // identity_rows: k_wgrad_dense never reads dcode
 #define ICN_WG(I, J)                                                                                                       \
     do {                                                                                                                   \
-        if (dense)                                                                                                         \
+        if (dense && b3w)                                                                                                  \
+            hipLaunchKernelGGL((k_wgrad_dense<I, J, 1>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.partial, a.bias_partial, a.M,  \
+                               a.Pd, a.Cin, a.Cout, a.Cout, rows, S, (unsigned)x_bytes,                                     \
+                               g_trace_cap >= (size_t)grid.x * 8 ? g_trace : nullptr);                                      \
+        else if (dma && b3w)                                                                                               \
+            hipLaunchKernelGGL((k_wgrad_dma<I, J, 1>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.dy2, a.dcode,               \
+                               a.n_slots > 0 ? a.side : nullptr, a.partial, a.bias_partial, a.M, a.Ps, a.Pd, a.Cin, a.Cout,   \
+                               a.y_taps ? a.Cout : Cout0, a.n_slots, rows, S, (unsigned)x_bytes, (unsigned)side_bytes, a.y_taps, \
+                               g_trace_cap >= (size_t)grid.x * 8 ? g_trace : nullptr); \
+        else if (dense)                                                                                                    \
             hipLaunchKernelGGL((k_wgrad_dense<I, J>), grid, dim3(256), lds_dma, s, a.x, a.dy, a.partial, a.bias_partial, a.M,  \
                                a.Pd, a.Cin, a.Cout, a.Cout, rows, S, (unsigned)x_bytes,                                     \
                                g_trace_cap >= (size_t)grid.x * 8 ? g_trace : nullptr);                                      \
@@ -2801,7 +2894,9 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((k_wgrad<I, J>), grid, dim3(256), lds, s, a.x, a.dy, a.idx, a.partial, a.bias_partial, a.M,   \
                                a.Ps, a.Pd, a.Cin, a.Cout, a.ns, rows, S);                                                  \
     } while (0)
-        prof_mark_begin(dense ? (bi128 ? (bj128 ? PROF_WGDENSE_128x128 : PROF_WGDENSE_128x64) : (bj128 ? PROF_WGDENSE_64x128 : PROF_WGDENSE_64x64))
+        const bool b3w = dma && arith_mode() == 1 && !(dbg_flags() & 131072);   // (debug flag 131072: weight gradients stay exact)
+        prof_mark_begin(b3w ? (dense ? PROF_WGDENSE_B3 : PROF_WGD_B3)
+                        : dense ? (bi128 ? (bj128 ? PROF_WGDENSE_128x128 : PROF_WGDENSE_128x64) : (bj128 ? PROF_WGDENSE_64x128 : PROF_WGDENSE_64x64))
                               : (bi128 ? (bj128 ? PROF_WG_128x128 : PROF_WG_128x64) : (bj128 ? PROF_WG_64x128 : PROF_WG_64x64)) -
                                     (dma ? PROF_WG_128x128 - PROF_WGD_128x128 : 0),
                         a.algo_flops, s);

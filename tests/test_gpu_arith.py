@@ -47,6 +47,8 @@ def _conv_case(case, seed, pair, bias=True):
     torch.autograd.backward(yr, [gy.double() for gy in gys])
     ref = {'y%d' % i: yr[i].detach() for i in range(k)}
     ref['dx'] = xr.grad
+    for i in range(k):
+        ref['dw%d' % i] = wr[i].grad
     return (r, stride, mode, x, ws, bs, gys), ref
 
 
@@ -54,7 +56,7 @@ def _run(inputs, pair):
     from geniconet_amd.ico_conv import ico_conv, ico_conv_pair
     r, stride, mode, x, ws, bs, gys = inputs
     xg = x.cuda().requires_grad_()
-    wg = [w.cuda() for w in ws]
+    wg = [w.cuda().requires_grad_() for w in ws]
     bg = [b.cuda() if b is not None else None for b in bs]
     if pair:
         ys = ico_conv_pair(xg, wg[0], bg[0], wg[1], bg[1], r, stride, mode)
@@ -63,6 +65,8 @@ def _run(inputs, pair):
     torch.autograd.backward(ys, [gy.cuda() for gy in gys])
     out = {'y%d' % i: ys[i].detach() for i in range(len(ys))}
     out['dx'] = xg.grad
+    for i in range(len(ys)):
+        out['dw%d' % i] = wg[i].grad
     return out
 
 
@@ -70,8 +74,8 @@ def _errors(got, ref):
     return {k: rel_l2(got[k].cpu().numpy(), ref[k].numpy()) for k in ref}
 
 
-# stride-1 cases run the split kernels in forward AND data gradient; stride-2 cases in the forward pass only (their data gradients
-# are masked launches and stay on the exact kernels)
+# stride-1 cases run the split kernels in forward, data gradient AND weight gradient (k_wgrad7_b3); stride-2 cases in the forward pass
+# only (their data gradients are masked launches, their weight gradients per-tap launches: exact kernels)
 SINGLE = [c for c in MFMA_CASES if c[2] % 32 == 0 and c[3] % 64 == 0]
 PAIRS = [c for c in PAIR_CASES if c[2] % 32 == 0 and c[3] % 64 == 0]
 
@@ -85,6 +89,8 @@ def test_split_arithmetic_is_fp32_grade_single(case, arith):
     got, kernels = _kernels_of(lambda: _run(inputs, False))
     split = _errors(got, ref)
     assert any(k.startswith('k_conv_b3') for k in kernels), kernels
+    if case[1] == 1 and case[0] >= 2 and case[2] % 64 == 0 and case[3] % 64 == 0:
+        assert 'k_wgrad7_b3' in kernels, kernels
     for k in ref:
         assert split[k] < TOL, (k, split[k])
         assert split[k] <= 2.0 * exact[k] + 1e-9, (k, split[k], exact[k])

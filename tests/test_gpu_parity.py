@@ -153,7 +153,7 @@ W7_CASES = [   # (r, stride, Cin, Cout0, Cout1 (0: single conv), B, corner mode)
 
 
 @pytest.mark.parametrize('case', W7_CASES, ids=lambda c: 'r%d_s%d_%dx%d+%d_b%d_%s' % c)
-def test_all_taps_weight_gradient_kernel_equals_the_per_tap_kernel(case):
+def test_all_taps_weight_gradient_kernel_equals_the_per_tap_kernel(case, exact_arith):
     """k_wgrad7 (a workgroup owns a 64 x 64 tile for all seven taps, the union of a 16-pixel patch's source rows
     staged once, positions from host tables) against k_wgrad_dma (debug flag 2048) on the same inputs: weight and bias
     gradients to 2e-6 (same products, other summation order), for single convolutions and pairs, both strides, both corner
@@ -368,7 +368,7 @@ def test_stream_k_in_the_decoder_heads_dense_gemms(r, cin, cout, B, exact_arith)
 
 @pytest.mark.parametrize('r,cin,cout,B,tile', [(2, 256, 256, 7, '128, 128'), (3, 128, 64, 5, '128, 64'), (3, 64, 128, 5, '64, 128'),
                                                (3, 64, 64, 7, '64, 64'), (2, 128, 128, 1, '128, 128')])
-def test_the_dense_weight_gradient_kernel_equals_the_general_per_tap_kernel(r, cin, cout, B, tile):
+def test_the_dense_weight_gradient_kernel_equals_the_general_per_tap_kernel(r, cin, cout, B, tile, exact_arith):
     """k_wgrad_dense (round 5) is k_wgrad_dma's body with the identity gather compiled in; debug flag 32768 keeps the general
     kernel walking an identity table.  Same row splits, same MFMA order: dW and dbias of both branches BIT-identical, on every
     tile instantiation (the pair's 2 * cout output channels pick the co tile), ragged row splits and a one-sample batch included."""
