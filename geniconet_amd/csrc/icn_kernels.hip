@@ -1324,6 +1324,22 @@ __global__ __launch_bounds__(64 * NW) void k_conv_b3_dense_sk(const float* __res
                                                  src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
 }
 
+// ... and the whole-tile form for the masked launches (stride-2 data gradients: rows permuted into tap-set classes, 1 - 2 taps per tile,
+// tiles dealt to the workgroups by their step counts)
+template <int BM, int BN, int NW>
+__global__ __launch_bounds__(64 * NW) void k_conv_b3(const float* __restrict__ src, const float* __restrict__ src2,
+                                                      const float* __restrict__ wt, const float* __restrict__ bias,
+                                                      float* __restrict__ dst, float* __restrict__ dst2,
+                                                      const int32_t* __restrict__ dcode, const float* __restrict__ side,
+                                                      const float* __restrict__ side2, const int32_t* __restrict__ perm,
+                                                      const uint32_t* __restrict__ mask32, int M, int Ps, int Pd, int K, int N, int N0,
+                                                      int n_slots, unsigned src_bytes, unsigned side_bytes, int ntiles, int T_arg,
+                                                      const RowSegs segs, unsigned long long* __restrict__ trace,
+                                                      const int* __restrict__ tlist) {
+    conv_dma_body<BM, BN, false, false, NW, 7, 1>(src, src2, wt, bias, dst, dst2, dcode, side, side2, perm, mask32, M, Ps, Pd, K, N, N0, n_slots,
+                                                  src_bytes, side_bytes, ntiles, T_arg, segs, 4, nullptr, nullptr, nullptr, 0, trace, nullptr, tlist);
+}
+
 // Eight waves per workgroup (2 x 4 waves of 32 x 32; round 5): the same tile, LDS image, ring and tables as the four-wave kernels, the
 // stage's DMA rows / metadata entries / epilogue columns dealt over twice the waves -- 3 instead of 6 DMA instructions and 16 instead
 // of 32 MFMAs per wave and K-step, four waves per SIMD at two workgroups per CU to cover each other's barriers and stage issues
@@ -1631,8 +1647,17 @@ int set_arith_mode(int mode) {
 // Column tile of the bf16 image this launch would read (128 or 64), or 0: the launch stays on the fp32 kernels.  Covered: what the
 // stream-K kernels cover -- plain 7-tap convolutions (single / pair, forward and stride-1 data gradients) and the dense one-tap
 // GEMMs with identity rows.  The caller (icn_api.cpp) asks BEFORE the prologue so that the weights are packed to match.
+static bool conv_b3_masked(const GatherGemmArgs& a) {      // stride-2 data gradient: plain rows, permuted, tap masks, tile lists
+    return a.segs.nseg == 0 && a.perm != nullptr && a.mask32 != nullptr && a.mask32_host != nullptr && a.mask_key != 0 && (a.T == 0 || a.T == 7) &&
+           !(dbg_flags() & (512 | 262144));                 // (debug flag 262144: masked launches stay exact under bf16x3)
+}
 int conv_b3_bn(const GatherGemmArgs& a) {
-    if (arith_mode() != 1 || !conv_dma_usable(a) || !conv_sk_eligible(a)) return 0;
+    if (arith_mode() != 1 || !conv_dma_usable(a)) return 0;
+    if (conv_b3_masked(a)) {
+        if (a.N % 64 != 0 || a.K % BK != 0 || (size_t)7 * a.N * a.K * 6 >= ((size_t)1 << 31)) return 0;
+        return a.N % 128 == 0 ? 128 : 64;
+    }
+    if (!conv_sk_eligible(a)) return 0;
     const bool dense = a.segs.nseg > 0;
     if (dense && !conv_dense_plain(a)) return 0;
     const int taps = dense ? 1 : 7;
@@ -1671,9 +1696,35 @@ static void launch_conv_b3_sk_t(const GatherGemmArgs& a, hipStream_t s) {
                        sk_boundary_tables(ntiles, grid, DENSE ? a.K / BK : 7 * (a.K / BK), occ));
     prof_mark_end(s);
 }
+template <int BM, int BN, int NW>
+static void launch_conv_b3_masked_t(const GatherGemmArgs& a, hipStream_t s) {
+    constexpr auto kern = &k_conv_b3<BM, BN, NW>;
+    constexpr int occ = 1;
+    check_dma_ranges(a);
+    const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+    int grid = std::min(ntiles, 256 * occ);
+    if (grid >= 8) grid -= grid % 8;
+    const size_t lds = conv_dma_lds(BM, BN, true, a.bias != nullptr, true);
+    static std::atomic<uint64_t> attr_devices{0};
+    if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
+    }
+    const int Ks = a.src2 ? a.K / 2 : a.K;
+    const size_t nb = (size_t)(a.M / a.Pd);
+    const unsigned src_bytes = (unsigned)(nb * a.Ps * Ks * 4), side_bytes = (unsigned)(nb * a.n_slots * Ks * 4);
+    const int* tlist = grid % 8 == 0 ? tile_lists(a, BM, BN, ntiles, grid, occ) : nullptr;
+    prof_mark_begin(PROF_B3_MASKED, a.algo_flops, s);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2,
+                       a.dcode, a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.mask32, a.M,
+                       a.Ps, a.Pd, a.K, a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, 7, RowSegs{},
+                       g_trace_cap >= (size_t)grid * 8 ? g_trace : nullptr, tlist);
+    prof_mark_end(s);
+}
 static void launch_conv_b3(const GatherGemmArgs& a, hipStream_t s) {
     const int bn = conv_b3_bn(a);
     if (bn == 0 || bn != a.arith_bn) throw std::invalid_argument("icn: bf16x3 launch whose weights were packed for another tile");
+    if (conv_b3_masked(a)) return bn == 128 ? launch_conv_b3_masked_t<128, 128, 8>(a, s) : launch_conv_b3_masked_t<128, 64, 4>(a, s);
     const bool dense = a.segs.nseg > 0;
     if (bn == 128) return dense ? launch_conv_b3_sk_t<128, 128, 8, true>(a, s) : launch_conv_b3_sk_t<128, 128, 8, false>(a, s);
     return dense ? launch_conv_b3_sk_t<128, 64, 4, true>(a, s) : launch_conv_b3_sk_t<128, 64, 4, false>(a, s);

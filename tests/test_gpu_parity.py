@@ -401,7 +401,7 @@ def test_the_dense_weight_gradient_kernel_equals_the_general_per_tap_kernel(r, c
 
 
 @pytest.mark.parametrize('r,cin,cout,B,pair', [(4, 128, 256, 36, True), (5, 64, 128, 12, True), (3, 256, 256, 36, False), (3, 256, 512, 5, True)])
-def test_balanced_tile_lists_equal_the_round_robin_walk(r, cin, cout, B, pair):
+def test_balanced_tile_lists_equal_the_round_robin_walk(r, cin, cout, B, pair, exact_arith):
     """Stride-2 data gradients: the tiles of such a launch run 1 or 2 of the 7 taps, and the launcher deals them to the
     workgroups by their step counts (tile lists, debug flag 512 = the round-robin walk b, b + G, ... of rounds 1-2).  A tile is
     computed whole by one workgroup either way, so the results must be BIT-identical."""
