@@ -1309,6 +1309,21 @@ __global__ __launch_bounds__(64 * NW) void k_conv_b3_sk(const float* __restrict_
     conv_dma_body<BM, BN, false, true, NW, 7, 1>(src, src2, wt, bias, dst, dst2, dcode, side, side2, nullptr, nullptr, M, Ps, Pd, K, N, N0, n_slots,
                                                  src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
 }
+// ... a SINGLE convolution (no second source / destination tensor) says so at compile time, as k_conv_single_sk does
+template <int BM, int BN, int NW>
+__global__ __launch_bounds__(64 * NW) void k_conv_b3_single_sk(const float* __restrict__ src, const float* __restrict__ src2,
+                                                                const float* __restrict__ wt, const float* __restrict__ bias,
+                                                                float* __restrict__ dst, float* __restrict__ dst2,
+                                                                const int32_t* __restrict__ dcode, const float* __restrict__ side,
+                                                                const float* __restrict__ side2, const int32_t* __restrict__ perm, int M, int Ps,
+                                                                int Pd, int K, int N, int N0, int n_slots, unsigned src_bytes,
+                                                                unsigned side_bytes, int ntiles, int T_arg, const RowSegs segs, int sk_mp,
+                                                                float* __restrict__ sk_part, int* __restrict__ sk_flag,
+                                                                int* __restrict__ sk_status, int sk_spin_limit,
+                                                                unsigned long long* __restrict__ trace, const int* __restrict__ sk_bnd) {
+    conv_dma_body<BM, BN, false, true, NW, 7, 1>(src, nullptr, wt, bias, dst, nullptr, dcode, side, nullptr, nullptr, nullptr, M, Ps, Pd, K, N, N, n_slots,
+                                                 src_bytes, side_bytes, ntiles, T_arg, segs, sk_mp, sk_part, sk_flag, sk_status, sk_spin_limit, trace, sk_bnd, nullptr);
+}
 template <int BM, int BN, int NW>
 __global__ __launch_bounds__(64 * NW) void k_conv_b3_dense_sk(const float* __restrict__ src, const float* __restrict__ src2,
                                                                const float* __restrict__ wt, const float* __restrict__ bias,
@@ -1668,10 +1683,15 @@ int conv_b3_bn(const GatherGemmArgs& a) {
 
 template <int BM, int BN, int NW, bool DENSE>
 static void launch_conv_b3_sk_t(const GatherGemmArgs& a, hipStream_t s) {
-    constexpr auto kern = [] {
+    constexpr auto kern_general = [] {
         if constexpr (DENSE) return &k_conv_b3_dense_sk<BM, BN, NW>;
         else return &k_conv_b3_sk<BM, BN, NW>;
     }();
+    const bool single = !DENSE && a.src2 == nullptr && a.dst2 == nullptr && !(dbg_flags() & 65536);
+    auto kern = kern_general;
+    if constexpr (!DENSE) {
+        if (single) kern = &k_conv_b3_single_sk<BM, BN, NW>;
+    }
     constexpr int occ = 1;
     check_dma_ranges(a);
     const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
@@ -1679,10 +1699,10 @@ static void launch_conv_b3_sk_t(const GatherGemmArgs& a, hipStream_t s) {
     if ((size_t)grid * BM * BN * sizeof(float) > conv_sk_part_bytes() || grid > CONV_SK_ERROR)
         throw std::invalid_argument("icn: stream-K grid beyond its scratch");
     const size_t lds = conv_dma_lds(BM, BN, false, a.bias != nullptr, true);
-    static std::atomic<uint64_t> attr_devices{0};
-    if (!((attr_devices.load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
+    static std::atomic<uint64_t> attr_devices[2] = {{0}, {0}};
+    if (!((attr_devices[single].load(std::memory_order_relaxed) >> current_device_bit()) & 1)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_devices.fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
+        attr_devices[single].fetch_or((uint64_t)1 << current_device_bit(), std::memory_order_relaxed);
     }
     const int Ks = a.src2 ? a.K / 2 : a.K;
     const size_t nb = (size_t)(a.M / a.Pd);

@@ -503,6 +503,18 @@ int main(int argc, char** argv) {
         check_b3p<128, 128, 4, 1, 3>("... rotated K-step (128x128, 4 waves of 32x128)");
         return 0;
     }
+    if (mode == 'o') {   // occupancy: 12 waves (3 per SIMD) on a 192 x 128 tile against the 8-wave 128 x 128 tile, ~0.2 ms launches
+        g_div = 20;
+        for (int rep = 0; rep < 3; ++rep) {
+            run_b3p<128, 128, 4, 2, 3, 3>(1);
+            run_b3p<192, 128, 6, 2, 3, 3>(1);        // 144 KB ring, 12 waves of 32 x 64
+            run_b3p<192, 128, 6, 2, 3, 1>(1);
+            run_b3p<192, 64, 6, 1, 3, 3>(1);         // 108 KB: 6 waves of 32 x 64 (N = 64 layers)
+            run_b3p<128, 64, 4, 1, 3, 3>(1);
+        }
+        check_b3p<192, 128, 6, 2, 3>("... rotated K-step (192x128, 12 waves)");
+        return 0;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         g_div = pass == 0 ? 1 : 20;
         printf("---- %s launches\n", pass == 0 ? "~4 ms (fp32 form)" : "~0.2 ms (fp32 form)");
