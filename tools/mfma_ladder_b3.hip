@@ -366,6 +366,141 @@ __global__ __launch_bounds__(64 * WR * WC) void k_b3p(const float* src, unsigned
 #endif
 }
 
+// E4: the A operand as the UNION of the tile's seven shifted row sets, staged once per k-chunk.  A 128-row tile of
+// the 64-wide chart is two chart rows; its seven tap sets are rows [r0 + s, r0 + s + 128) for s in {0, +-1, +-63, +-64}: the union is
+// the 256 rows [r0 - 64, r0 + 192) -- 256 row loads per k-chunk instead of 7 x 128 = 896.  The union lives in a double buffer (the next
+// k-chunk's union is issued at the chunk's first step), tap t reads its fragments at union row 64 + shift_t + (tile row); B as before
+// (3-stage ring of 24 KB).  vmcnt is in-order: the step that issues the union leaves 4 + 3 DMAs in flight, every other step 3.
+template <int BM, int BN, int WR, int WC, int LEAD>
+__global__ __launch_bounds__(64 * WR * WC) void k_b3u(const float* src, unsigned src_bytes, float* out, int steps, float* tile_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WR * WC, NST = 3;
+    constexpr int UR = 2 * BM;                                            // union rows
+    constexpr int TM = BM / WR / 32, TN = BN / WC / 32, RU = UR / 8 / NW, BBYTES = BN * 192, RB = BBYTES / 1024 / NW;
+    static_assert(RU >= 1 && RB >= 1 && RB * NW * 1024 == BBYTES && BM == 128, "tile / wave grid mismatch");
+    constexpr int NMF = TM * TN * 6, NVALU = 44 * TM, VPM = (NVALU + (NMF - LEAD) - 1) / (NMF - LEAD);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ubuf = smem;                                                    // [2][UR][128 B]
+    char* bring = smem + 2 * UR * 128;                                    // [NST][BBYTES]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC, l31 = lane & 31, h = lane >> 5, rsub = lane >> 3, pc = lane & 7;
+    for (int i = tid; i < (2 * UR * 128 + NST * BBYTES) / 4; i += 64 * NW) reinterpret_cast<float*>(smem)[i] = 1e-3f * (float)((i * 37) % 101 - 50);
+    __syncthreads();
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+    const unsigned b_base = (unsigned)A_ROWS * 1024u + (unsigned)(7 * BN) * 1024u;
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int ring = 0, iring = NST - 1;
+    auto dma_union = [&](int chunk_step) __attribute__((always_inline)) {      // the union of the k-chunk that `chunk_step` belongs to
+        const int tile = (blockIdx.x + (chunk_step / 56) * gridDim.x) % (A_ROWS / BM);
+        const int kc = (chunk_step / 7) % 8;
+        char* ub = ubuf + (kc & 1) * UR * 128;
+#pragma unroll
+        for (int i = 0; i < RU; ++i) {
+            const int u = 8 * (wave + NW * i) + rsub;
+            int row = tile * BM - 64 + u;
+            row = row < 0 ? row + A_ROWS : (row >= A_ROWS ? row - A_ROWS : row);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(ub + 8 * (wave + NW * i) * 128), 16,
+                                                     (unsigned)row * 1024u + 16u * (pc ^ swz(u)), kc * 128, 0, 0);
+        }
+    };
+    auto dma_b = [&](int slot, int step) __attribute__((always_inline)) {
+        const int t = step % 7, kc = (step / 7) % 8;
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bring + slot * BBYTES + (wave + NW * i) * 1024), 16,
+                                                     b_base + (unsigned)((t * 8 + kc) * BBYTES + (wave + NW * i) * 1024 + lane * 16), 0, 0, 0);
+    };
+    dma_union(0);
+#pragma unroll
+    for (int q = 0; q < NST - 1; ++q) dma_b(q, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int fb_s = swzb(l31);
+    f32x4 ra[TM][2];
+    u32x4 rb0[TN][3], rb1[TN][3];
+    Pieces p0[TM], p1[TM];
+    auto read_frag = [&](int rg, int step, int kb, u32x4 (&rb)[TN][3]) __attribute__((always_inline)) {
+        const int t = step % 7, kc = (step / 7) % 8;
+        const char* ub = ubuf + (kc & 1) * UR * 128;
+        const char* b_row = bring + rg * BBYTES + (wc * (BN / WC) + l31) * 64;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int u = 64 + shift_of(t) + wr * (BM / WR) + i * 32 + l31;
+            const char* a_row = ub + u * 128;
+            ra[i][0] = *reinterpret_cast<const f32x4*>(a_row + 16 * ((4 * kb + 2 * h) ^ swz(u)));
+            ra[i][1] = *reinterpret_cast<const f32x4*>(a_row + 16 * ((4 * kb + 2 * h + 1) ^ swz(u)));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                rb[j][p] = *reinterpret_cast<const u32x4*>(b_row + p * BN * 64 + j * 32 * 64 + 16 * ((2 * kb + h) ^ fb_s));
+    };
+    auto mfmas = [&](const Pieces (&pa)[TM], const u32x4 (&rb)[TN][3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = MF(pa[i].p1, rb[j][2], c);
+                c = MF(pa[i].p3, rb[j][0], c);
+                c = MF(pa[i].p2, rb[j][1], c);
+                c = MF(pa[i].p1, rb[j][1], c);
+                c = MF(pa[i].p2, rb[j][0], c);
+                c = MF(pa[i].p1, rb[j][0], c);
+                acc[i][j] = c;
+            }
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_group_barrier(0x8, LEAD, 0);
+#pragma unroll
+        for (int q = 0; q < NMF - LEAD; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x2, VPM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        }
+    };
+    read_frag(0, 0, 0, rb0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) p0[i] = split8(ra[i][0], ra[i][1]);
+    for (int step = 0; step < steps; ++step) {
+        const bool first_of_chunk = step % 7 == 0;
+        read_frag(ring, step, 1, rb1);
+        if (first_of_chunk) dma_union(step + 7);                 // next k-chunk's union into the other half of the double buffer
+        dma_b(iring, step + NST - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(p0, rb0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) p1[i] = split8(ra[i][0], ra[i][1]);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        if (first_of_chunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RU + RB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RB) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ring = ring == NST - 1 ? 0 : ring + 1;
+        iring = iring == NST - 1 ? 0 : iring + 1;
+        read_frag(ring, step + 1, 0, rb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(p1, rb1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) p0[i] = split8(ra[i][0], ra[i][1]);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tile_out) {
+        if (blockIdx.x == 0)
+            for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r)
+                tile_out[(wr * (BM / WR) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + wc * (BN / WC) + j * 32 + l31] = acc[i][j][r];
+        return;
+    }
+    float sum = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    out[(blockIdx.x * 64 * NW + tid) % (1024 * 256)] = sum;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------------------------- host
 static std::vector<float> g_host;          // host copy of the fp32 part of src (activations + fp32 weights [7][128][256])
 static float* g_src; static unsigned g_src_bytes; static float* g_out; static float* g_tile;
@@ -428,6 +563,25 @@ template <int BM, int BN, int WR, int WC, int NST, int LEAD> void run_b3p(int bp
     const float ms = time_kernel(&k_b3p<BM, BN, WR, WC, NST, LEAD>, blocks, 64 * WR * WC, (size_t)NST * (BM * 128 + BN * 192), steps, g_div > 1 ? 12 : 3);
     printf("bf16x3 tile %3dx%-3d  %2d waves (%d x %d)  %d stages  %d block(s)/CU  rotated K-step, %d lead MFMAs  %.3f ms  %7.1f fp32-equivalent TFLOP/s\n", BM, BN,
            WR * WC, WR, WC, NST, bpc, LEAD, ms, (double)blocks * steps * 2.0 * BM * BN * BK / ms / 1e9);
+}
+
+template <int BM, int BN> static void check(const char* name, const std::vector<float>& got);
+template <int BM, int BN, int WR, int WC, int LEAD> void run_b3u(int bpc) {
+    pack_b_image(BN);
+    const int blocks = 256 * bpc, steps = std::max(56, 4000 / bpc * 8192 / (BM * BN) / g_div * 2) / 7 * 7;
+    const float ms = time_kernel(&k_b3u<BM, BN, WR, WC, LEAD>, blocks, 64 * WR * WC, (size_t)2 * 2 * BM * 128 + 3 * BN * 192, steps, g_div > 1 ? 12 : 3);
+    printf("bf16x3 tile %3dx%-3d  %2d waves (%d x %d)  UNION of the 7 row sets staged once per k-chunk (2 x %d KB) + 3-stage B ring  %.3f ms  %7.1f fp32-equivalent TFLOP/s\n",
+           BM, BN, WR * WC, WR, WC, 2 * BM * 128 / 1024, ms, (double)blocks * steps * 2.0 * BM * BN * BK / ms / 1e9);
+}
+template <int BM, int BN, int WR, int WC, int LEAD> static void check_b3u(const char* name) {
+    pack_b_image(BN);
+    auto kern = &k_b3u<BM, BN, WR, WC, LEAD>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipMemset(g_tile, 0, BM * BN * 4);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64 * WR * WC), (size_t)2 * 2 * BM * 128 + 3 * BN * 192, 0, (const float*)g_src, g_src_bytes, g_out, 56, g_tile);
+    std::vector<float> got((size_t)BM * BN);
+    hipMemcpy(got.data(), g_tile, got.size() * 4, hipMemcpyDeviceToHost);
+    check<BM, BN>(name, got);
 }
 
 // One tile (block 0, tile 0) after 56 K-steps = the full K = 7 * 256 contraction, against float64 on the host.
@@ -501,6 +655,20 @@ int main(int argc, char** argv) {
         check_b3p<128, 128, 4, 2, 3>("... rotated K-step (128x128, 8 waves)");
         check_b3p<64, 128, 2, 2, 3>("... rotated K-step (64x128, 4 waves)");
         check_b3p<128, 128, 4, 1, 3>("... rotated K-step (128x128, 4 waves of 32x128)");
+        return 0;
+    }
+    if (mode == 'u') {   // E4: union staging of A against the per-tap staging, 4 ms and 0.2 ms launches
+        check_b3p<128, 128, 4, 2, 3>("per-tap A staging (128x128, 8 waves)");
+        check_b3u<128, 128, 4, 2, 3>("union A staging   (128x128, 8 waves)");
+        for (int pass = 0; pass < 2; ++pass) {
+            g_div = pass == 0 ? 1 : 20;
+            printf("---- %s launches\n", pass == 0 ? "~4 ms" : "~0.2 ms");
+            for (int rep = 0; rep < 3; ++rep) {
+                run_b3p<128, 128, 4, 2, 3, 3>(1);
+                run_b3u<128, 128, 4, 2, 3>(1);
+                run_b3u<128, 128, 4, 2, 1>(1);
+            }
+        }
         return 0;
     }
     if (mode == 'o') {   // occupancy: 12 waves (3 per SIMD) on a 192 x 128 tile against the 8-wave 128 x 128 tile, ~0.2 ms launches
