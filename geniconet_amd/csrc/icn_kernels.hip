@@ -48,7 +48,8 @@
 // is the product, and compiles to the same instructions as before the switches existed.
 //   1 no tile epilogue (accumulators are dropped)          2 no per-tile metadata DMA + convert (every tile reuses the first tile's tables)
 //   4 no side-row vote / second resource in the stage issue (also in the weight-gradient kernels)     8 no bias in the epilogue
-//   16 epilogue arithmetic and store instructions kept, every offset out of range (no memory side)   64 / 256 epilogue stores with the
+//   16 epilogue arithmetic and store instructions kept, every offset out of range (no memory side)   32 (bf16x3 kernels) no staggered stage issue
+//   64 / 256 epilogue stores with the
 //   non-temporal (nt) / system-scope write-through (sc0 sc1) cache policy
 #ifndef ICN_EXP
 #define ICN_EXP 0
@@ -1004,7 +1005,12 @@ _Pragma("unroll") \
             if constexpr (B3) {
                 b3_read(c_ring, 0);
                 if (meta) ICN_META_ISSUE();
-                ICN_ISSUE_STAGE();
+                // The stage issue is ~100 scalar / address instructions with branches (no MFMA can be scheduled into it), and the two
+                // waves of a SIMD (waves w and w + 4 of the workgroup) reach it together after the step's barrier: the matrix pipe then
+                // idles for its whole length.  The upper four waves therefore issue their stage AFTER their first MFMA group: while one
+                // wave of a SIMD walks the issue code the other one feeds the pipe (ICN_EXP & 32: both first, as before).
+                const bool late_issue = NW == 8 && !(ICN_EXP & 32) && wave >= 4;      // wave-uniform
+                if (!late_issue) ICN_ISSUE_STAGE();
                 __builtin_amdgcn_sched_barrier(0);
                 if (step > 0) {                           // the previous stage's second k-block beside this stage's first split
                     b3_mfmas(1);
@@ -1015,6 +1021,7 @@ _Pragma("unroll") \
                     b3_split(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (late_issue) ICN_ISSUE_STAGE();
                 b3_read(c_ring, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 b3_mfmas(0);
