@@ -289,7 +289,8 @@ int icn_profile_select(const char* kernel);
  * k_conv_dma8 / k_conv_dma_sk8 (round 5: built, bit-identical, not faster in the training step), 32768 = the decoder heads' dense
  * one-tap GEMMs on the class-major kernel k_conv_dma_sk<.., true> instead of the plain-path k_conv_dense_sk and their dense
  * weight gradient on the general k_wgrad_dma instead of k_wgrad_dense, 65536 = single convolutions on the general stream-K kernel instead of
- * k_conv_single_sk.  Returns the previous flags. */
+ * k_conv_single_sk (and k_conv_b3_single_sk), 131072 / 262144 (round 6, only meaningful under ICN_ARITH_BF16X3) = weight gradients /
+ * the masked stride-2 data gradients stay on the exact fp32 kernels.  Returns the previous flags. */
 int icn_set_debug_flags(int flags);
 
 /* Asynchronous failures of the CURRENT device.  Kernels cannot return an error code; the one failure they can detect --
@@ -318,7 +319,9 @@ int icn_device_status(int clear);
  * autocast -- SURVEY F1).  ICN_ARITH_F32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  ICN_ARITH_BF16X3 (the default): every fp32 operand
  * is cut into three bf16 pieces (24 significand bits, exact) and the product is six bf16 MFMAs with fp32 accumulation -- fp32-grade
  * results (1.2 x the exact kernel's rounding error against float64, tests/test_gpu_arith.py) at 2.67 x less matrix-pipe time; used
- * by the stream-K forms of the plain convolutions and the dense GEMMs, everything else stays on the exact kernels.  The process
+ * by every MFMA launch of the path the LDS-DMA kernels cover (convolution forward, data gradients incl. the masked stride-2 form,
+ * the decoder heads' dense GEMMs, all weight gradients); the scalar / register-staged fall-backs and the small virtual-row GEMM of a
+ * stride-1 data gradient stay exact.  The process
  * default is ICN_ARITH_BF16X3; the environment overrides it (ICN_ARITH=f32|bf16x3).  icn_set_arith returns the previous mode, or -1
  * (icn_last_error). */
 #define ICN_ARITH_F32 0
