@@ -366,8 +366,8 @@ def _measure(cfg, args, ctx, headline):
 
 
 def is_split_kernel(name):
-    """Kernels of the three-way bf16 split (ARITH = 1 instantiations of conv_dma_body)."""
-    return name.startswith('k_conv_b3')
+    """Kernels of the three-way bf16 split (the ARITH = 1 instantiations: k_conv_b3*, k_wgrad*<.., 1>)."""
+    return name.startswith('k_conv_b3') or name.endswith(', 1>')
 
 
 def _latest_pmc_summary():

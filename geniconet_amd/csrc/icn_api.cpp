@@ -709,7 +709,8 @@ const char* const PROF_NAMES[PROF_KINDS] = {"k_conv_dma<128, 128, false>", "k_co
                                             "k_conv_single_sk<64, 64>", "k_wgrad_dense<128, 128>", "k_wgrad_dense<128, 64>",
                                             "k_wgrad_dense<64, 128>", "k_wgrad_dense<64, 64>",
                                             "k_conv_b3_sk<128, 128, 8>", "k_conv_b3_sk<128, 64, 4>", "k_conv_b3_dense_sk<128, 128, 8>",
-                                            "k_conv_b3_dense_sk<128, 64, 4>", "k_wgrad7_b3", "k_wgrad_dma_b3", "k_wgrad_dense_b3", "k_conv_b3_masked"};
+                                            "k_conv_b3_dense_sk<128, 64, 4>", "k_wgrad7<.., 1>", "k_wgrad_dma<.., 1>", "k_wgrad_dense<.., 1>", "k_conv_b3<128, BN, NW>",
+                                            "k_conv_b3_single_sk<128, 128, 8>", "k_conv_b3_single_sk<128, 64, 4>"};
 void prof_mark_begin(int kind, double flops, hipStream_t s) {
     if (!g_prof_on) return;
     g_prof_mu.lock();

@@ -1714,7 +1714,7 @@ static void launch_conv_b3_sk_t(const GatherGemmArgs& a, hipStream_t s) {
     const int Ks = a.src2 ? a.K / 2 : a.K;
     const size_t nb = (size_t)(a.M / a.Pd);
     const unsigned src_bytes = (unsigned)(nb * a.Ps * Ks * 4), side_bytes = (unsigned)(nb * a.n_slots * Ks * 4);
-    prof_mark_begin((DENSE ? PROF_B3DENSEK_128x128 : PROF_B3K_128x128) + (BN == 128 ? 0 : 1), a.algo_flops, s);
+    prof_mark_begin((DENSE ? PROF_B3DENSEK_128x128 : single ? PROF_B3SINGLEK_128x128 : PROF_B3K_128x128) + (BN == 128 ? 0 : 1), a.algo_flops, s);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, a.src, a.src2, a.wt, a.bias, a.dst, a.dst2, a.dcode,
                        a.n_slots > 0 ? a.side : nullptr, (a.n_slots > 0 && a.src2) ? a.side2 : nullptr, a.perm, a.M, a.Ps, a.Pd, a.K,
                        a.N, a.dst2 ? a.N0 : a.N, a.n_slots, src_bytes, side_bytes, ntiles, DENSE ? 1 : 7, RowSegs{}, CONV_SK_MIN_PIECE,

@@ -234,7 +234,7 @@ enum ProfKind { PROF_DMA_128x128 = 0, PROF_DMA_128x64, PROF_DMA_64x128, PROF_DMA
                 PROF_SINGLEK_64x128, PROF_SINGLEK_64x64,     // k_conv_single_sk: single convolutions (no second tensors)
                 PROF_WGDENSE_128x128, PROF_WGDENSE_128x64, PROF_WGDENSE_64x128, PROF_WGDENSE_64x64,   // k_wgrad_dense: the heads' dW = x^T g
                 PROF_B3K_128x128, PROF_B3K_128x64, PROF_B3DENSEK_128x128, PROF_B3DENSEK_128x64,       // ARITH = 1 forms (round 6)
-                PROF_WG7_B3, PROF_WGD_B3, PROF_WGDENSE_B3, PROF_B3_MASKED,
+                PROF_WG7_B3, PROF_WGD_B3, PROF_WGDENSE_B3, PROF_B3_MASKED, PROF_B3SINGLEK_128x128, PROF_B3SINGLEK_128x64,
                 PROF_KINDS };
 extern const char* const PROF_NAMES[PROF_KINDS];
 void prof_mark_begin(int kind, double flops, hipStream_t s);   // no-ops unless profiling is on

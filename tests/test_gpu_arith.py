@@ -74,8 +74,8 @@ def _errors(got, ref):
     return {k: rel_l2(got[k].cpu().numpy(), ref[k].numpy()) for k in ref}
 
 
-# stride-1 cases run the split kernels in forward, data gradient and weight gradient (k_wgrad7_b3); stride-2 cases too: their data
-# gradients are the masked launches (k_conv_b3_masked), their weight gradients the per-tap kernel (k_wgrad_dma_b3)
+# stride-1 cases run the split kernels in forward, data gradient and weight gradient (k_wgrad7<.., 1>); stride-2 cases too: their data
+# gradients are the masked launches (k_conv_b3<128, BN, NW>), their weight gradients the per-tap kernel (k_wgrad_dma<.., 1>)
 SINGLE = [c for c in MFMA_CASES if c[2] % 32 == 0 and c[3] % 64 == 0]
 PAIRS = [c for c in PAIR_CASES if c[2] % 32 == 0 and c[3] % 64 == 0]
 
@@ -90,7 +90,7 @@ def test_split_arithmetic_is_fp32_grade_single(case, arith):
     split = _errors(got, ref)
     assert any(k.startswith('k_conv_b3') for k in kernels), kernels
     if case[1] == 1 and case[0] >= 2 and case[2] % 64 == 0 and case[3] % 64 == 0:
-        assert 'k_wgrad7_b3' in kernels, kernels
+        assert 'k_wgrad7<.., 1>' in kernels, kernels
     for k in ref:
         assert split[k] < TOL, (k, split[k])
         assert split[k] <= 2.0 * exact[k] + 1e-9, (k, split[k], exact[k])
@@ -106,7 +106,7 @@ def test_split_arithmetic_is_fp32_grade_pair(case, arith):
     split = _errors(got, ref)
     assert any(k.startswith('k_conv_b3') for k in kernels), kernels
     if case[1] == 2:
-        assert 'k_conv_b3_masked' in kernels and 'k_wgrad_dma_b3' in kernels, kernels
+        assert 'k_conv_b3<128, BN, NW>' in kernels and 'k_wgrad_dma<.., 1>' in kernels, kernels
     for k in ref:
         assert split[k] < TOL, (k, split[k])
         assert split[k] <= 2.0 * exact[k] + 1e-9, (k, split[k], exact[k])
