@@ -41,8 +41,30 @@ def _worker(rank, world, port, out_dir):
     loss.backward()
     grads = {k: q.grad.clone() for k, q in tr.model.named_parameters()}
     losses = [float(tr.step(xs, ts)) for _ in range(3)]
-    torch.save({'w0': w0, 'grads': grads, 'losses': losses, 'w_end': tr.model.state_dict(), 'x': x, 't': t},
-               os.path.join(out_dir, 'rank%d.pt' % rank))
+    # the collective status check: one verdict for all ranks -- a failure reported by ONE rank raises on EVERY rank,
+    # and a clean check passes everywhere; then only rank 0 writes the checkpoint and a stale '<name>.tmp<pid>' of a killed writer goes
+    from geniconet_amd import train as icn_train
+    tr.check_status_collective()
+    real = tr.check_status
+
+    def failing(synchronize=False):
+        if rank == world - 1:
+            raise RuntimeError('libicn: injected failure on rank %d' % rank)
+    tr.check_status = failing
+    try:
+        tr.check_status_collective()
+        raised = None
+    except RuntimeError as e:
+        raised = str(e)
+    tr.check_status = real
+    stale = os.path.join(out_dir, 'savedModel', 'ico2ico_E1.pt.tmp99999')
+    if rank == 0:
+        os.makedirs(os.path.dirname(stale), exist_ok=True)
+        open(stale, 'w').write('half a checkpoint')
+    dist.barrier()
+    path = icn_train.save_checkpoint(tr, out_dir, 1, val_loss=0.0)
+    torch.save({'w0': w0, 'grads': grads, 'losses': losses, 'w_end': tr.model.state_dict(), 'x': x, 't': t, 'raised': raised,
+                'ckpt': path, 'stale_left': os.path.exists(stale)}, os.path.join(out_dir, 'rank%d.pt' % rank))
     dist.destroy_process_group()
 
 
@@ -73,6 +95,11 @@ def test_two_rank_gradients_equal_single_process_full_batch(tmp_path):
     for k in a['w_end']:
         assert torch.equal(a['w_end'][k], b['w_end'][k]), k
     assert all(abs(x) < 1e9 for x in a['losses'])
+    # collective status check: the failure injected on the LAST rank raised on both; the checkpoint was written by rank 0 only and the
+    # stale temporary of a killed writer is gone
+    assert a['raised'] and 'another rank' in a['raised'] and 'injected failure' in b['raised'], (a['raised'], b['raised'])
+    assert a['ckpt'] and a['ckpt'].endswith('ico2ico_E1.pt') and b['ckpt'] is None
+    assert not a['stale_left']
 
 
 @pytest.mark.timeout(600)
