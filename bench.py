@@ -483,8 +483,10 @@ def run(args):
             # tensors, accumulation and results are fp32 in both modes; 'bf16x3' forms every fp32 product of the stream-K convolution /
             # dense GEMM launches from three bf16 pieces per operand (24 significand bits, exact) -- fp32-grade: its error against
             # float64 is within 2 x the exact kernels' (tests/test_gpu_arith.py); the exact-fp32 run of the same step is in also[]
-            'arithmetic': ('bf16x3 split (%d bf16 MFMA products per fp32 product), fp32 accumulate; weight gradients and stride-2 data '
-                           'gradients on exact fp32 MFMA' % B3_PRODUCTS) if arith == 'bf16x3' else 'exact fp32 MFMA',
+            'arithmetic': ('bf16x3 split (%d bf16 MFMA products per fp32 product), fp32 accumulate, in every convolution, data-gradient, '
+                           'dense-GEMM and weight-gradient launch of the stream-K / masked classes; the three small launches outside them '
+                           '(k_conv_dma<64, 64>, k_gather_gemm<64, 64>: 0.08 ms of the step) on exact fp32 MFMA' % B3_PRODUCTS) if arith == 'bf16x3'
+                          else 'exact fp32 MFMA',
             'library': _lib.build_info(),
             'config': {'workload': cfg['workload'], 'per_gpu_batch': cfg['batch'], 'global_batch': cfg['batch'] * world,
                        'subdivisions': cfg['R'], 'parallelism': 'dp%d' % world + (' (DDP over RCCL forced at world size 1)' if forced else ''),
