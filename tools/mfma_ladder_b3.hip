@@ -139,6 +139,28 @@ __device__ __forceinline__ Pieces split8(const f32x4 lo, const f32x4 hi) {
     }
     return o;
 }
+// the same cut with the two subtractions as packed fp32 (v_pk_add_f32 on register pairs): 9 instead of 11 instructions per two values
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ Pieces split8_pk(const f32x4 lo, const f32x4 hi) {
+    Pieces o;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float e0 = m < 2 ? lo[2 * m] : hi[2 * m - 4], e1 = m < 2 ? lo[2 * m + 1] : hi[2 * m - 3];
+        const f32x2 x = {e0, e1};
+        const f32x2 a1 = {__uint_as_float(__float_as_uint(e0) & 0xffff0000u), __uint_as_float(__float_as_uint(e1) & 0xffff0000u)};
+        f32x2 r;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(a1));
+        const float r0 = r[0], r1 = r[1];
+        const f32x2 a2 = {__uint_as_float(__float_as_uint(r0) & 0xffff0000u), __uint_as_float(__float_as_uint(r1) & 0xffff0000u)};
+        f32x2 q;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(q) : "v"(r), "v"(a2));
+        const float q0 = q[0], q1 = q[1];
+        o.p1[m] = __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
+        o.p2[m] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+        o.p3[m] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+    }
+    return o;
+}
 #define MF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
 
 template <int BM, int BN, int WR, int WC, int NST, int NP>
@@ -244,7 +266,10 @@ __global__ __launch_bounds__(64 * WR * WC) void k_b3(const float* src, unsigned 
 // the fragment reads and the split of the next step's first k-block, so no wave waits for LDS latency + 44 VALU instructions with
 // an empty matrix pipe.  sched_group_barrier fixes the interleave: LEAD MFMAs alone (covers the read latency), then one MFMA per
 // VPM VALU instructions.
-template <int BM, int BN, int WR, int WC, int NST, int LEAD>
+// KO (mode 'k'): knock-outs that price the parts of the K-step -- 1: no stage DMA (and no vmcnt wait), 2: no B fragment reads, 4: no A
+// fragment reads and no split (pieces stay in registers), 8: A read but not split, 16: no step barrier.  Results are garbage by design.
+__device__ unsigned long long g_stamps[2];
+template <int BM, int BN, int WR, int WC, int NST, int LEAD, int KO = 0>
 __global__ __launch_bounds__(64 * WR * WC) void k_b3p(const float* src, unsigned src_bytes, float* out, int steps, float* tile_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WR * WC;
@@ -264,6 +289,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_b3p(const float* src, unsigned
     for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     int ring = 0, iring = NST - 1;
     auto dma = [&](int slot, int step) __attribute__((always_inline)) {
+        if (KO & 1) return;
         const int tile = (blockIdx.x + (step / 56) * gridDim.x) % (A_ROWS / BM);
         const int t = step % 7, kc = (step / 7) % 8;
         char* st = smem + slot * STAGE;
@@ -287,20 +313,44 @@ __global__ __launch_bounds__(64 * WR * WC) void k_b3p(const float* src, unsigned
     f32x4 ra[TM][2];
     u32x4 rb0[TN][3], rb1[TN][3];
     Pieces p0[TM], p1[TM];
+    if (KO & 2)
+        for (int j = 0; j < TN; ++j) for (int p = 0; p < 3; ++p) for (int e = 0; e < 4; ++e) rb0[j][p][e] = rb1[j][p][e] = 0x3c003c00u + lane + 64 * (j + p + e);
+    if (KO & 4)
+        for (int i = 0; i < TM; ++i) for (int e = 0; e < 4; ++e) {
+            p0[i].p1[e] = p1[i].p1[e] = 0x3c003c00u + lane + e; p0[i].p2[e] = p1[i].p2[e] = 0x38003800u + lane + e;
+            p0[i].p3[e] = p1[i].p3[e] = 0x34003400u + lane + e;
+        }
     auto read_frag = [&](int rg, int kb, u32x4 (&rb)[TN][3]) __attribute__((always_inline)) {
         const char* st = smem + rg * STAGE;
         const char* a_row = st + (wr * (BM / WR) + l31) * 128;
         const char* b_row = st + BM * 128 + (wc * (BN / WC) + l31) * 64;
+        if (!(KO & 4)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ra[i][0] = *reinterpret_cast<const f32x4*>(a_row + i * 32 * 128 + 16 * ((4 * kb + 2 * h) ^ fa_s));
+                ra[i][1] = *reinterpret_cast<const f32x4*>(a_row + i * 32 * 128 + 16 * ((4 * kb + 2 * h + 1) ^ fa_s));
+            }
+        }
+        if (!(KO & 2)) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    rb[j][p] = *reinterpret_cast<const u32x4*>(b_row + p * BN * 64 + j * 32 * 64 + 16 * ((2 * kb + h) ^ fb_s));
+        }
+    };
+    auto split_to = [&](Pieces (&pp)[TM]) __attribute__((always_inline)) {
+        if (KO & 4) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            ra[i][0] = *reinterpret_cast<const f32x4*>(a_row + i * 32 * 128 + 16 * ((4 * kb + 2 * h) ^ fa_s));
-            ra[i][1] = *reinterpret_cast<const f32x4*>(a_row + i * 32 * 128 + 16 * ((4 * kb + 2 * h + 1) ^ fa_s));
+            if (KO & 8) {
+                pp[i].p1 = __builtin_bit_cast(u32x4, ra[i][0]); pp[i].p2 = __builtin_bit_cast(u32x4, ra[i][1]); pp[i].p3 = __builtin_bit_cast(u32x4, ra[i][0]);
+            } else if (KO & 32) {
+                pp[i] = split8_pk(ra[i][0], ra[i][1]);
+            } else {
+                pp[i] = split8(ra[i][0], ra[i][1]);
+            }
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                rb[j][p] = *reinterpret_cast<const u32x4*>(b_row + p * BN * 64 + j * 32 * 64 + 16 * ((2 * kb + h) ^ fb_s));
     };
     auto mfmas = [&](const Pieces (&pa)[TM], const u32x4 (&rb)[TN][3]) __attribute__((always_inline)) {
 #pragma unroll
@@ -318,6 +368,17 @@ __global__ __launch_bounds__(64 * WR * WC) void k_b3p(const float* src, unsigned
             }
     };
     auto interleave = [&]() __attribute__((always_inline)) {
+        if (KO & 12) return;
+        if (KO & 32) {
+            constexpr int VPM2 = (28 * TM + (NMF - LEAD) - 1) / (NMF - LEAD);   // (the packed subtractions are inline asm: not VALU to the scheduler)
+            __builtin_amdgcn_sched_group_barrier(0x8, LEAD, 0);
+#pragma unroll
+            for (int q = 0; q < NMF - LEAD; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x2, VPM2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            }
+            return;
+        }
         __builtin_amdgcn_sched_group_barrier(0x8, LEAD, 0);
 #pragma unroll
         for (int q = 0; q < NMF - LEAD; ++q) {
@@ -327,8 +388,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_b3p(const float* src, unsigned
     };
     // first step's first k-block
     read_frag(0, 0, rb0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) p0[i] = split8(ra[i][0], ra[i][1]);
+    split_to(p0);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int step = 0; step < steps; ++step) {
         // (a) stage `ring` is visible; p0 / rb0 hold its first k-block.  Second k-block's reads, the next stage's DMA, then the
         //     first k-block's MFMAs beside the split of the second.
@@ -336,24 +397,23 @@ __global__ __launch_bounds__(64 * WR * WC) void k_b3p(const float* src, unsigned
         dma(iring, step + NST - 1);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(p0, rb0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) p1[i] = split8(ra[i][0], ra[i][1]);
+        split_to(p1);
         interleave();
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NDMA) : "memory");
+        if (!(KO & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NDMA) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(KO & 16)) __builtin_amdgcn_s_barrier();
         ring = ring == NST - 1 ? 0 : ring + 1;
         iring = iring == NST - 1 ? 0 : iring + 1;
         // (b) the next stage is visible: its first k-block's reads, then this step's second k-block's MFMAs beside their split
         read_frag(ring, 0, rb0);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(p1, rb1);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) p0[i] = split8(ra[i][0], ra[i][1]);
+        split_to(p0);
         interleave();
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (blockIdx.x == 7 && tid == 0) { g_stamps[0] = __builtin_amdgcn_s_memtime() - t0; g_stamps[1] = __builtin_amdgcn_s_memrealtime() - r0; }
     if (tile_out) {
         if (blockIdx.x == 0)
             for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r)
@@ -565,6 +625,17 @@ template <int BM, int BN, int WR, int WC, int NST, int LEAD> void run_b3p(int bp
            WR * WC, WR, WC, NST, bpc, LEAD, ms, (double)blocks * steps * 2.0 * BM * BN * BK / ms / 1e9);
 }
 
+template <int BM, int BN, int WR, int WC, int KO, int NST = 3> void run_ko(const char* what) {
+    pack_b_image(BN);
+    const int blocks = 256, steps = std::max(56, 4000 * 8192 / (BM * BN) / g_div * 2);
+    const float ms = time_kernel(&k_b3p<BM, BN, WR, WC, NST, 3, KO>, blocks, 64 * WR * WC, (size_t)NST * (BM * 128 + BN * 192), steps, g_div > 1 ? 12 : 3);
+    unsigned long long st[2]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), 16);
+    const double ghz = (double)st[0] / (double)st[1] * 0.1, cyc = (double)st[0] / steps;      // s_memrealtime ticks at 100 MHz
+    const double tf = (double)blocks * steps * 2.0 * BM * BN * BK / ms / 1e9;
+    printf("KO %2d  %-58s %.3f ms  %6.1f fp32-eq TF/s  %.2f GHz  %5.0f cycles / K-step (MFMA alone: %d)  pipe %.0f %%\n", KO, what, ms, tf, ghz, cyc,
+           (BM / WR / 32) * (BN / WC / 32) * 12 * 32 * (WR * WC / 4), 100.0 * (BM / WR / 32) * (BN / WC / 32) * 12 * 32 * (WR * WC / 4) / cyc);
+}
+
 template <int BM, int BN> static void check(const char* name, const std::vector<float>& got);
 template <int BM, int BN, int WR, int WC, int LEAD> void run_b3u(int bpc) {
     pack_b_image(BN);
@@ -667,6 +738,65 @@ int main(int argc, char** argv) {
                 run_b3p<128, 128, 4, 2, 3, 3>(1);
                 run_b3u<128, 128, 4, 2, 3>(1);
                 run_b3u<128, 128, 4, 2, 1>(1);
+            }
+        }
+        return 0;
+    }
+    if (mode == 'k') {   // knock-outs on the production rung (128 x 128, 8 waves as 4 x 2, 3-stage ring, rotated K-step)
+        for (int pass = 0; pass < 2; ++pass) {
+            g_div = pass == 0 ? 1 : 20;
+            printf("---- %s launches\n", pass == 0 ? "~5 ms" : "~0.25 ms");
+            for (int rep = 0; rep < 2; ++rep) {
+                run_ko<128, 128, 4, 2, 0>("full K-step");
+                run_ko<128, 128, 4, 2, 1>("no stage DMA");
+                run_ko<128, 128, 4, 2, 16>("no step barrier (races: timing only)");
+                run_ko<128, 128, 4, 2, 8>("A read, not split");
+                run_ko<128, 128, 4, 2, 4>("no A read, no split");
+                run_ko<128, 128, 4, 2, 2>("no B fragment reads");
+                run_ko<128, 128, 4, 2, 6>("no fragment reads at all, no split (DMA + barrier + MFMA)");
+                run_ko<128, 128, 4, 2, 7>("MFMA + barrier only");
+                run_ko<128, 128, 4, 2, 23>("MFMA only");
+                run_ko<128, 128, 4, 2, 9>("no DMA, A not split");
+                run_ko<128, 128, 4, 2, 3>("no DMA, no B reads");
+            }
+        }
+        return 0;
+    }
+    if (mode == 'p') {   // the split with packed subtractions
+        auto chk = [&]() {
+            pack_b_image(128);
+            auto kern = &k_b3p<128, 128, 4, 2, 3, 3, 32>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipMemset(g_tile, 0, 128 * 128 * 4);
+            hipLaunchKernelGGL(kern, dim3(1), dim3(512), (size_t)3 * (128 * 128 + 128 * 192), 0, (const float*)g_src, g_src_bytes, g_out, 56, g_tile);
+            std::vector<float> got((size_t)128 * 128);
+            hipMemcpy(got.data(), g_tile, got.size() * 4, hipMemcpyDeviceToHost);
+            check<128, 128>("packed-subtraction split (128x128, 8 waves)", got);
+        };
+        chk();
+        check_b3p<128, 128, 4, 2, 3>("production split (128x128, 8 waves)");
+        for (int pass = 0; pass < 2; ++pass) {
+            g_div = pass == 0 ? 1 : 20;
+            printf("---- %s launches\n", pass == 0 ? "~5 ms" : "~0.25 ms");
+            for (int rep = 0; rep < 3; ++rep) {
+                run_ko<128, 128, 4, 2, 0>("production split: and, sub, and, sub, perm x 1.5");
+                run_ko<128, 128, 4, 2, 32>("packed subtractions (v_pk_add_f32)");
+            }
+        }
+        return 0;
+    }
+    if (mode == 's') {   // shapes under the power limit: fewer split instructions and LDS reads per MFMA
+        for (int pass = 0; pass < 2; ++pass) {
+            g_div = pass == 0 ? 1 : 20;
+            printf("---- %s launches\n", pass == 0 ? "~5 ms" : "~0.25 ms");
+            for (int rep = 0; rep < 2; ++rep) {
+                run_ko<128, 128, 4, 2, 0>("128x128, 8 waves of 32x64, 3 stages (production)");
+                run_ko<128, 128, 4, 1, 0>("128x128, 4 waves of 32x128, 3 stages");
+                run_ko<256, 128, 8, 1, 0, 2>("256x128, 8 waves of 32x128, 2 stages");
+                run_ko<256, 128, 4, 2, 0, 2>("256x128, 8 waves of 64x64, 2 stages");
+                run_ko<256, 128, 8, 1, 8, 2>("256x128, 8 waves of 32x128, 2 stages, A not split");
+                run_ko<256, 128, 8, 1, 1, 2>("256x128, 8 waves of 32x128, 2 stages, no DMA");
+                run_ko<128, 256, 4, 2, 0, 2>("128x256, 8 waves of 32x128, 2 stages");
             }
         }
         return 0;

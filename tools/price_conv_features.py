@@ -31,7 +31,9 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--tag', default=os.path.basename(os.environ.get('ICN_LIB_PATH', 'libicn.so')))
     ap.add_argument('--only', default='')
+    ap.add_argument('--batch', type=int, default=B)
     a = ap.parse_args()
+    globals()['B'] = a.batch
     torch.manual_seed(0)
     for label, kind, cin, cout, r, stride, what in CASES:
         if a.only and a.only not in label:
