@@ -317,6 +317,9 @@ def _measure(cfg, args, ctx, headline):
             'arithmetic': ('bf16x3 split: %d v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulate; achieved / peak count '
                            'EXECUTED bf16 FLOPs against the dense bf16 MFMA peak' % B3_PRODUCTS) if split
                           else 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32)',
+            # why frac stops where it does (not measured by this run: ladder knock-outs with the CU clock read inside the K-loop)
+            'what_bounds_it': ('the power limit: in cycles the K-step keeps the matrix pipe 75 % busy, but the CUs run it at 1.62-1.75 GHz '
+                               '(the peak is quoted at 2.4); K-steps are 86 % of a launch -- profiles/r06_ladder_b3_knockouts.txt') if split else None,
             'fp32_equivalent_tflops': round(equiv, 2),
             'fp32_equivalent_frac_of_fp32_mfma_peak': round(equiv / PEAK_FP32_MFMA_TFLOPS, 4),
             'kernel': dom_name, 'launches_per_step': iso['launches'] / n_survey,
