@@ -1107,17 +1107,21 @@ _Pragma("unroll") \
                     }
                     asm volatile("" ::: "memory");
                     const unsigned base = (unsigned)blk * (unsigned)(BM * BN * 4) + tid * 16u;
+                    // all of a piece's loads in flight before the first add (they are system-scope loads: ~2 us each; left to itself
+                    // the scheduler of the build without packed fp32 waited for every one of them in turn)
+                    f32x4 pv[TM * TN * 4];
+#pragma unroll
+                    for (int q = 0; q < TM * TN * 4; ++q)
+                        pv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, base + q * (NTHR * 16u), 0, SYS));
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
 #pragma unroll
-                            for (int r4 = 0; r4 < 4; ++r4) {
-                                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                                               rsrc_k, base + ((i * TN + j) * 4 + r4) * (NTHR * 16u), 0, SYS));
+                            for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += v[e];
-                            }
+                                for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += pv[(i * TN + j) * 4 + r4][e];
                     pos = max(lt * nku, rs);                        // block nb's range starts there
                     --nb;
                     __syncthreads();                               // everyone has read lost_s before lane 0 writes it again

@@ -304,16 +304,9 @@ class _IcoConvFn(torch.autograd.Function):
                 #  the current stream as well loses 1 - 1.5 %)
                 side = _wgrad_stream(gyp.device, [(ctx.params[0], dw), (ctx.params[1], db)], xp, gyp, ws,
                                      allow=bool(ctx.needs_input_grad[0]))
-                if side is None and not ctx.needs_input_grad[0] and _pending[0] and _wgrad_mode[0] != 'off':
-                    # Round 6: this launch (the stem's k_stem_wgrad + k_wgrad_reduce) first waits for what is on the side stream.  With
-                    # the weight gradients on the bf16x3 kernels the side stream no longer lags the chain by milliseconds: the first
-                    # residual block's pair gradient (k_wgrad_dma<64, 128, 1>) and its k_wgrad_reduce end WHILE k_stem_wgrad runs, and
-                    # the stem's weight gradient then came out different from run to run (30 - 300 of its 1344 elements, 1e-4
-                    # relative, every other gradient bit-identical; deterministic again with the pair gradient on the exact kernel,
-                    # with a 100 us pause in front of k_stem_wgrad, or with this join -- profiles/r06_stem_wgrad_race.txt; the
-                    # mechanism is not understood, the kernels touch no common memory).  Cost: the side stream's remaining backlog
-                    # (< 0.1 ms) is no longer hidden behind these two launches.
-                    _join_now()
+                # (Round 6: for a while this launch first joined the side stream -- the stem's weight gradient came out different from
+                #  run to run while the first residual block's bf16x3 pair gradient ran beside it.  The cause was in k_stem_wgrad's machine
+                #  code, not in the streams: v_pk_fma_f32 with a cross-dword op_sel, see csrc/Makefile and profiles/r06_stem_wgrad_race.txt.)
                 rc = L.icn_conv_bwd_weight(xp.data_ptr(), gyp.data_ptr(), dw.data_ptr(),
                                            db.data_ptr() if db is not None else None, B, Cin, Cout, r, stride, mode,
                                            ws.data_ptr(), ws_bytes, side.cuda_stream if side is not None else _stream())

@@ -7,7 +7,8 @@ cd "$(dirname "$0")/../geniconet_amd/csrc"
 mkdir -p build_exp
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-const-variable"
 for n in "$@"; do
-  /opt/rocm/bin/hipcc $FLAGS -DICN_EXP=$n ${EXTRA_DEFS} -c -o build_exp/icn_kernels_$n.o icn_kernels.hip &
+  # (icn_kernels.hip is built without packed fp32 instructions, as in the Makefile)
+  /opt/rocm/bin/hipcc $FLAGS -Xclang -target-feature -Xclang -packed-fp32-ops -DICN_EXP=$n ${EXTRA_DEFS} -c -o build_exp/icn_kernels_$n.o icn_kernels.hip 2> >(grep -v "is not a recognized feature for this target" >&2) &
 done
 wait
 for n in "$@"; do
