@@ -353,6 +353,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_b3p(const float* src, unsigned
         }
     };
     auto mfmas = [&](const Pieces (&pa)[TM], const u32x4 (&rb)[TN][3]) __attribute__((always_inline)) {
+        if (KO & 64) return;                                     // (mode 'h': no MFMA at all)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_b3p(const float* src, unsigned
             }
     };
     auto interleave = [&]() __attribute__((always_inline)) {
-        if (KO & 12) return;
+        if (KO & (12 | 64)) return;
         if (KO & 32) {
             constexpr int VPM2 = (28 * TM + (NMF - LEAD) - 1) / (NMF - LEAD);   // (the packed subtractions are inline asm: not VALU to the scheduler)
             __builtin_amdgcn_sched_group_barrier(0x8, LEAD, 0);
@@ -559,6 +560,49 @@ __global__ __launch_bounds__(64 * WR * WC) void k_b3u(const float* src, unsigned
     for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
     out[(blockIdx.x * 64 * NW + tid) % (1024 * 256)] = sum;
 #endif
+}
+
+// Probe for mode 'h' (round 6, profiles/r06_stem_wgrad_race.txt): the arithmetic of k_stem_wgrad -- float4 accumulators += float4 * scalar,
+// the scalars read pairwise from LDS, which hipcc compiles into v_pk_fma_f32 with op_sel:[0,1,0] for the odd scalars -- beside the same
+// sums formed with scalar v_fmac_f32 (inline asm) in the same thread.  The two must agree bit for bit (both are single-rounding FMAs in
+// the same order); a mismatch is counted per (parity of k, component).  Launched while the bf16x3 ladder kernel holds the CUs.
+constexpr int PROBE_KT = 8;
+__global__ __launch_bounds__(256) void k_pk_probe(const float* __restrict__ dy, const float* __restrict__ xsrc, unsigned* __restrict__ bad,
+                                                   float* __restrict__ sink, int rows) {
+    __shared__ float xs[256 * PROBE_KT];
+    for (int i = threadIdx.x; i < 256 * PROBE_KT; i += 256) xs[i] = xsrc[(blockIdx.x * 256 * PROBE_KT + i) & 0xfffff];
+    __syncthreads();
+    const int g = threadIdx.x / 16, c4 = threadIdx.x % 16;
+    f32x4 acc[PROBE_KT], ref[PROBE_KT];
+#pragma unroll
+    for (int k = 0; k < PROBE_KT; ++k) { acc[k] = f32x4{0.f, 0.f, 0.f, 0.f}; ref[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int row = g; row < rows; row += 16) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + ((size_t)(blockIdx.x * rows + row) * 64 + 4 * c4 & 0x3fffffc));
+        const float* xg = xs + (row & 255) * PROBE_KT;
+#pragma unroll
+        for (int k = 0; k < PROBE_KT; ++k) acc[k] += d * xg[k];                    // hipcc: v_pk_fma_f32, op_sel:[0,1,0] for odd k
+#pragma unroll
+        for (int k = 0; k < PROBE_KT; ++k) {
+            const float x = xg[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a_ = ref[k][e];
+                const float d_ = d[e];
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a_) : "v"(d_), "v"(x));
+                ref[k][e] = a_;
+            }
+        }
+    }
+    float keep = 0.f;
+#pragma unroll
+    for (int k = 0; k < PROBE_KT; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a_ = acc[k][e], r_ = ref[k][e];
+            if (__float_as_uint(a_) != __float_as_uint(r_)) atomicAdd(bad + (k & 1) * 4 + e, 1u);
+            keep += a_;
+        }
+    if (keep == 1.2345e-30f) sink[0] = keep;
 }
 
 // ------------------------------------------------------------------------------------------------------------------- host
@@ -760,6 +804,52 @@ int main(int argc, char** argv) {
                 run_ko<128, 128, 4, 2, 3>("no DMA, no B reads");
             }
         }
+        return 0;
+    }
+    if (mode == 'h') {   // the packed-fma probe beside the bf16x3 ladder kernel (two streams), and alone
+        pack_b_image(128);
+        hipStream_t sa, sb; hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+        unsigned* bad; float* sink; hipMalloc(&bad, 64); hipMalloc(&sink, 64);
+        const int rows = 512, pblocks = 720, launches = 400;
+        auto run = [&](const char* what, auto heater, int threads, size_t lds, int steps) {
+            if (heater) hipFuncSetAttribute(reinterpret_cast<const void*>(heater), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            for (int rep = 0; rep < 2; ++rep) {
+                hipMemset(bad, 0, 64);
+                hipDeviceSynchronize();
+                if (heater) {
+                    for (int q = 0; q < 4; ++q)
+                        hipLaunchKernelGGL(heater, dim3(256), dim3(threads), lds, sa, (const float*)g_src, g_src_bytes, g_out, steps, (float*)nullptr);
+                    hipLaunchKernelGGL(k_pk_probe, dim3(pblocks), dim3(256), 0, sb, (const float*)g_src, (const float*)g_src + (4 << 20), bad, sink, 16);   // (a short one: the heater gets ahead)
+                    hipStreamSynchronize(sb);
+                    hipMemsetAsync(bad, 0, 64, sb);
+                }
+                for (int l = 0; l < launches; ++l)
+                    hipLaunchKernelGGL(k_pk_probe, dim3(pblocks), dim3(256), 0, sb, (const float*)g_src, (const float*)g_src + (4 << 20), bad, sink, rows);
+                hipStreamSynchronize(sb);
+                const bool outlasted = heater && hipStreamQuery(sa) == hipErrorNotReady;
+                hipDeviceSynchronize();
+                unsigned h[8]; hipMemcpy(h, bad, 32, hipMemcpyDeviceToHost);
+                printf("%-62s %s  mismatching accumulators  even k, components 0..3: %u %u %u %u   odd k: %u %u %u %u\n", what,
+                       heater ? (outlasted ? "(heater outlasted the probes)" : "(HEATER ENDED FIRST)        ") : "                             ",
+                       h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+                if (hipGetLastError() != hipSuccess) printf("  !! launch failed\n");
+            }
+        };
+        typedef void (*kern_t)(const float*, unsigned, float*, int, float*);
+        const size_t l3 = (size_t)3 * (128 * 128 + 128 * 192);
+        printf("%d launches of the probe (%d workgroups of 256 threads: 16 v_pk_fma_f32 per row, 4 of them with op_sel:[0,1,0]) against scalar v_fmac_f32 in the same thread\n", launches, pblocks);
+        run("alone", (kern_t) nullptr, 0, 0, 0);
+        run("beside the bf16x3 ladder kernel (full K-step)", (kern_t)&k_b3p<128, 128, 4, 2, 3, 3, 0>, 512, l3, 20000);
+        run("beside ... without the stage DMA", (kern_t)&k_b3p<128, 128, 4, 2, 3, 3, 1>, 512, l3, 20000);
+        run("beside ... A read but not split (no v_and / v_sub / v_perm)", (kern_t)&k_b3p<128, 128, 4, 2, 3, 3, 8>, 512, l3, 20000);
+        run("beside ... no fragment reads, no split (DMA + barrier + MFMA)", (kern_t)&k_b3p<128, 128, 4, 2, 3, 3, 6>, 512, l3, 20000);
+        run("beside ... bf16 MFMA + barrier only", (kern_t)&k_b3p<128, 128, 4, 2, 3, 3, 7>, 512, l3, 30000);
+        run("beside the exact fp32 ladder kernel (v_mfma_f32_32x32x2_f32, same DMA)", (kern_t)&k_f32<128, 128, 2, 4, 3>, 512, (size_t)3 * (128 + 128) * BK * 4, 8000);
+        run("beside ... stage DMA + barrier only (no MFMA, no reads)", (kern_t)&k_b3p<128, 128, 4, 2, 3, 3, 70>, 512, l3, 60000);
+        run("beside ... stage DMA + fragment reads + split, no MFMA", (kern_t)&k_b3p<128, 128, 4, 2, 3, 3, 64>, 512, l3, 40000);
+        run("beside ... fragment reads + split + MFMA, no DMA (again)", (kern_t)&k_b3p<128, 128, 4, 2, 3, 3, 1>, 512, l3, 20000);
+        run("beside the bf16x3 ladder kernel (full K-step, again)", (kern_t)&k_b3p<128, 128, 4, 2, 3, 3, 0>, 512, l3, 20000);
+        run("alone again", (kern_t) nullptr, 0, 0, 0);
         return 0;
     }
     if (mode == 'p') {   // the split with packed subtractions
